@@ -1,0 +1,189 @@
+/*
+ * umhs_hip.h -- C ABI of libumhs_hip.so: the MI355X (gfx950) implementation of the UMHS
+ * volumetric-rendering hot path (hash-grid encode, density/spectral MLPs + endmember mixing,
+ * per-ray alpha compositing over B bands, spectrum->sRGB, fused Adam).
+ *
+ * The reference (Factral/unsupervised-hyperspectral-nerf) has no C ABI: its boundary is the
+ * nerfstudio plugin API in Python, and the native code it reaches lives in tiny-cuda-nn / nerfacc.
+ * This header sits where those libraries' Python bindings used to sit; each entry point cites the
+ * reference call site (file:line relative to the reference repo) it replaces.  The Python mirror of
+ * the plugin surface (UMHSField, SpectralRenderer, ColourSystem, UMHSModel ...) binds these symbols
+ * with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns UMHS_OK (0) or a negative error code (umhs_strerror), never throws;
+ *   - never allocates, never synchronises the stream; workspaces are caller-provided and sized by
+ *     the matching *_workspace_bytes query;
+ *   - all pointers are DEVICE pointers to contiguous row-major fp32 unless stated (int64 for
+ *     ray_indices / packed_info, exactly the dtypes nerfacc hands out);
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are re-entrant on distinct streams;
+ *   - no torch types anywhere in the signatures.
+ */
+#ifndef UMHS_HIP_H
+#define UMHS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMHS_ABI_VERSION 1
+
+enum {
+  UMHS_OK = 0,
+  UMHS_ERR_ARG = -1,         /* NULL / negative / inconsistent argument            */
+  UMHS_ERR_UNSUPPORTED = -2, /* shape outside what the gfx950 kernels are built for */
+  UMHS_ERR_WORKSPACE = -3,   /* workspace missing or too small                     */
+  UMHS_ERR_LAUNCH = -4       /* hipGetLastError() != hipSuccess after a launch      */
+};
+
+typedef void* umhs_stream_t; /* hipStream_t */
+
+const char* umhs_strerror(int code);
+int umhs_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* R1 (prefix): sample positions.  Replaces Frustums.get_positions + SceneContraction(L-inf) +  */
+/* (p+2)/4 + in-box selector of UMHSField.get_density, umhs_field.py:302-310.                   */
+/* Either (origins,directions,starts,ends) [N,3],[N,3],[N],[N] or world_pos_in [N,3] is given   */
+/* (the latter is the density_fn(positions) path used by the occupancy grid,                    */
+/* umhs_model.py:208,553).  contraction != 0 -> L-inf contraction then (p+2)/4;                 */
+/* contraction == 0 -> (p - aabb_min)/(aabb_max-aabb_min) with aabb = 6 HOST floats.            */
+/* Outputs: world_pos_out [N,3] (optional), pos01_out [N,3] (already multiplied by selector),   */
+/* selector_out [N] (1.0f / 0.0f).                                                              */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_positions_fwd(const float* origins, const float* directions, const float* starts, const float* ends,
+                       const float* world_pos_in, int64_t n, int contraction, const float* aabb_host6,
+                       float* world_pos_out, float* pos01_out, float* selector_out, umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* R2: multiresolution hash-grid encode.  Replaces nerfstudio HashEncoding.forward (torch path) */
+/* / tcnn HashGrid reached through self.mlp_base(positions_flat), umhs_field.py:320.            */
+/* pos01 [N,3]; table [L*T, 2]; scalings [L] (device, = floor(16*g^l) as float32);              */
+/* enc element (n,l,f) is written at enc[n*stride_n + l*stride_l + f] (f in {0,1}):             */
+/*   stride_n=2L, stride_l=2  -> the reference's [N, L*F] layout;                               */
+/*   stride_n=2,  stride_l=2N -> level-major [L][N][2] (what the fused field kernels prefer).   */
+/* hashgrid_bwd ACCUMULATES into d_table (caller zeroes it): d_table[idx] += w_corner * d_enc.  */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_hashgrid_fwd(const float* pos01, const float* table, const float* scalings, int64_t n, int n_levels,
+                      int log2_table_size, float* enc, int64_t stride_n, int64_t stride_l, umhs_stream_t stream);
+int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
+                      const float* scalings, int64_t n, int n_levels, int log2_table_size, float* d_table,
+                      umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* R3-R9, R18: fused per-sample field.  Replaces mlp_base's MLP, NeRFEncoding, SHEncoding,      */
+/* mlp_head, feature_mlp, mlp_directional, softmax/sigmoid and the [N,B,C] endmember mixing of  */
+/* UMHSField.get_density / get_outputs, umhs_field.py:160-261,320-328 (tcnn.Network /           */
+/* nerfstudio MLP call sites :211,:219,:250).                                                   */
+/* Weights are the reference's nn.Linear tensors as they sit in the state dict: W [out,in]      */
+/* row-major, b [out].  hidden = 64, geo_feat_dim = 15, 16 hash levels x 2 features are fixed   */
+/* (NerfactoField defaults); n_classes <= 15, n_bands <= 256.                                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct umhs_field_cfg {
+  int32_t n_bands;       /* B: wavelengths                                   */
+  int32_t n_classes;     /* C: endmembers ("num_classes")                    */
+  int32_t pred_specular; /* 1: feature_mlp has C+1 outputs, mlp_directional used */
+  int32_t density_only;  /* 1: hash features -> sigma, emb only (density_fn)  */
+  float temperature;     /* softmax(logits / temperature), umhs_field.py:226  */
+} umhs_field_cfg;
+
+typedef struct umhs_field_params {
+  const float *base_w0, *base_b0, *base_w1, *base_b1;                       /* 32->64->16            */
+  const float *head_w0, *head_b0, *head_w1, *head_b1, *head_w2, *head_b2;   /* 27->64->64->C         */
+  const float *feat_w0, *feat_b0, *feat_w1, *feat_b1, *feat_w2, *feat_b2;   /* 27->64->64->C(+1)     */
+  const float *dir_w0, *dir_b0, *dir_w1, *dir_b1;                           /* 28->16->B (specular)  */
+  const float* endmembers;                                                  /* [C,B]                 */
+} umhs_field_params;
+
+typedef struct umhs_field_grads {
+  float *base_w0, *base_b0, *base_w1, *base_b1;
+  float *head_w0, *head_b0, *head_w1, *head_b1, *head_w2, *head_b2;
+  float *feat_w0, *feat_b0, *feat_w1, *feat_b1, *feat_w2, *feat_b2;
+  float *dir_w0, *dir_b0, *dir_w1, *dir_b1;
+  float* endmembers;
+} umhs_field_grads;
+
+/* Forward.  enc is addressed with (stride_n, stride_l) as above.  world_pos [N,3] (raw, for the */
+/* NeRF positional encoding, umhs_field.py:183-184), directions [N,3] (raw; (d+1)/2 applied     */
+/* inside, :160), selector [N].  Outputs (any may be NULL except sigma):                        */
+/*   sigma [N] = trunc_exp(raw)*selector (:327-328); sigma_raw [N]; emb [N,15];                 */
+/*   spectral [N,B] (= spec + s1*specular when pred_specular, else spec), spectral2 [N,B] (spec),*/
+/*   specular [N,B] (s1*specular), abundances [N,C].                                            */
+int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
+                   int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
+                   int64_t n, float* sigma, float* sigma_raw, float* emb, float* spectral, float* spectral2,
+                   float* specular, float* abundances, umhs_stream_t stream);
+
+/* Backward (recomputes the forward per tile; nothing but enc is saved).  d_sigma [N] and        */
+/* d_spectral [N,B] are the gradients w.r.t. the forward's sigma / spectral outputs; d_emb_ext    */
+/* [N,15] (optional) is an extra gradient on emb.  Writes d_enc (same strides as enc) and the     */
+/* parameter gradients (OVERWRITTEN, not accumulated).  workspace: umhs_field_bwd_workspace_bytes.*/
+size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int64_t n);
+int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
+                   int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
+                   int64_t n, const float* d_sigma, const float* d_spectral, const float* d_emb_ext,
+                   float* d_enc, const umhs_field_grads* grads, void* workspace, size_t workspace_bytes,
+                   umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* R11: packed transmittance/weights.  Replaces nerfacc.pack_info + render_weight_from_density, */
+/* umhs_model.py:245-252 (dense twin: get_weights_spectral, umhs_renderer.py:117-139).          */
+/* R12/R13: per-ray accumulation.  Replaces nerfacc.accumulate_along_rays behind                */
+/* SpectralRenderer.forward (umhs_renderer.py:28-30) and nerfstudio's Accumulation/Depth        */
+/* renderers (umhs_model.py:254-258).  ray_indices must be sorted ascending (nerfacc invariant). */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_pack_info(const int64_t* ray_indices, int64_t n, int64_t n_rays, int64_t* packed_info, umhs_stream_t stream);
+
+#define UMHS_MAX_STREAMS 4
+typedef struct umhs_value_streams {
+  int32_t n_streams;                     /* 0..4 value tensors composited with the same weights */
+  int32_t k[UMHS_MAX_STREAMS];           /* channels of each [N,k] tensor                       */
+  const float* values[UMHS_MAX_STREAMS]; /* [N,k]                                               */
+  float* out[UMHS_MAX_STREAMS];          /* [R,k]                                               */
+} umhs_value_streams;
+
+/* weights [N] (out), accumulation [R] (out, optional), depth [R] (out, optional: sum w*t_mid /  */
+/* (acc+1e-10), NOT yet clipped to [min t_mid, max t_mid] -- that global clip is the caller's).  */
+int umhs_composite_fwd(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                       int64_t n_rays, int64_t n, const umhs_value_streams* streams, float* weights,
+                       float* accumulation, float* depth, umhs_stream_t stream);
+
+typedef struct umhs_value_grads {
+  int32_t n_streams;
+  int32_t k[UMHS_MAX_STREAMS];
+  const float* values[UMHS_MAX_STREAMS]; /* [N,k] forward inputs                    */
+  const float* d_out[UMHS_MAX_STREAMS];  /* [R,k] gradient of the composited output */
+  float* d_values[UMHS_MAX_STREAMS];     /* [N,k] (out)                             */
+} umhs_value_grads;
+
+/* d_accumulation [R] optional.  grad_scaling != 0 multiplies d_sigma and d_values by              */
+/* clamp(((t0+t1)/2)^2, 0, 1) (scale_gradients_by_distance_squared, umhs_model.py:241-242).        */
+int umhs_composite_bwd(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                       int64_t n_rays, int64_t n, const float* weights, const umhs_value_grads* grads,
+                       const float* d_accumulation, int grad_scaling, float* d_sigma, umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* R14: spectrum -> sRGB.  Replaces ColourSystem.forward, utils/spec_to_rgb.py:103-127:         */
+/* rgb = clamp(gamma(spec @ M), 0, 1), M [B,3].  bwd writes d_spec [R,B] (accumulate != 0: +=). */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_spec2rgb_fwd(const float* spec, const float* M, int64_t n_rays, int n_bands, float* rgb, umhs_stream_t stream);
+int umhs_spec2rgb_bwd(const float* spec, const float* M, const float* d_rgb, int64_t n_rays, int n_bands,
+                      float* d_spec, int accumulate, umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Optimizer: torch.optim.Adam step for param group "fields" (AdamOptimizerConfig(lr=2e-2,      */
+/* eps=1e-15), umhs_config.py:59-64) over one flat fp32 buffer, with the clamp_endmembers        */
+/* callback (umhs_model.py:568-572) fused for elements [clamp_begin, clamp_end).  grad_scale     */
+/* multiplies the gradient first (1/world_size for averaged DDP gradients).                      */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, int64_t step, float grad_scale, int64_t clamp_begin,
+                   int64_t clamp_end, umhs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMHS_HIP_H */

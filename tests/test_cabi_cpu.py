@@ -1,0 +1,65 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/umhs_hip.h declares, and the Python binding declares a signature for each (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "umhs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(umhs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from umhsnerf import _hip
+
+    assert os.path.exists(_hip.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in umhs_hip.h but not exported"
+        assert s in _hip.SIGNATURES, f"{s} has no ctypes signature in umhsnerf/_hip.py"
+    assert set(_hip.SIGNATURES) == set(syms)
+    assert _hip.lib().umhs_abi_version() == 1
+    assert _hip.lib().umhs_strerror(-3) == b"workspace missing or too small"
+
+
+def test_struct_sizes_match_header():
+    from umhsnerf import _hip
+
+    assert ctypes.sizeof(_hip.FieldCfg) == 20
+    assert ctypes.sizeof(_hip.FieldParams) == 21 * 8 == ctypes.sizeof(_hip.FieldGrads)
+    assert ctypes.sizeof(_hip.ValueStreams) == 4 + 16 + 4 + 32 + 32  # n, k[4], pad, values[4], out[4]
+    assert ctypes.sizeof(_hip.ValueGrads) == 4 + 16 + 4 + 32 * 3
+
+
+def test_no_cpu_fallback():
+    from umhsnerf import ops
+
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.spec2rgb_fwd(torch.rand(4, 21), torch.rand(21, 3))
+
+
+def test_flat_layout_names_and_alignment():
+    from umhsnerf import ops
+
+    L = ops.FieldLayout(6, 31, True, 19)
+    assert L.entries["mlp_base.encoder.hash_table"] == (0, (16 << 19, 2))
+    assert L.entries["feature_mlp.layers.2.weight"][1] == (7, 64)
+    assert L.entries["mlp_head.layers.2.weight"][1] == (6, 64)
+    assert L.entries["mlp_directional.layers.1.weight"][1] == (31, 16)
+    assert L.entries["endmembers"][1] == (6, 31)
+    assert all(off % 4 == 0 for off, _ in L.entries.values()) and L.total % 4 == 0
+    n_mlp = L.total - (16 << 19) * 2
+    assert 16000 < n_mlp < 18500  # ~16.5 k MLP weights + endmembers
+    flat = torch.arange(L.total, dtype=torch.float32)
+    v = L.view(flat, "endmembers")
+    assert v.shape == (6, 31) and v.data_ptr() == flat.data_ptr() + 4 * L.offset("endmembers")
+    assert ops.hash_scalings()[15] == 2047 and ops.hash_scalings().dtype == torch.float32

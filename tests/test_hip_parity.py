@@ -1,0 +1,350 @@
+"""GPU parity tests: every C-ABI operator of libumhs_hip.so against the CPU oracle (oracle/torch_ref.py)
+on the same seeded inputs.  Tolerances: north_star asks 1e-4 relative on rendered radiance; per-operator
+checks are tighter where the arithmetic allows.  Integer/index outputs (pack_info) are bit-exact."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as T
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from umhsnerf import ops
+
+    return ops
+
+
+def relerr(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def assert_close(name, got, want, rtol):
+    e = relerr(got, want)
+    assert e <= rtol, f"{name}: max|diff|/max|ref| = {e:.3e} > {rtol:.1e} (shape {tuple(want.shape)})"
+
+
+def make_case(C, B, spec, R, S, ragged=False, log2_T=19, seed=0, temperature=0.4):
+    ops = _ops()
+    p = T.FieldParams(C, B, spec, log2_hashmap_size=log2_T, table_scale=0.5, seed=seed)
+    with torch.no_grad():
+        p.base_b[1][0] += 1.0  # raise sigma so a good share of samples has alpha > 0.01
+    batch = T.synthetic_batch(R, S, B, seed=seed + 1, ragged=ragged)
+    layout = ops.FieldLayout(C, B, spec, log2_T)
+    flat = torch.zeros(layout.total)
+    for k, v in p.reference_state_dict().items():
+        layout.view(flat, k).copy_(v)
+    fs = ops.FieldSpec(layout, temperature, True, scalings=ops.hash_scalings().to(DEV))
+    return p, batch, layout, flat.to(DEV), fs
+
+
+def dev(batch):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+# --------------------------------------------------------------------------------------------- #
+def test_positions_and_selector():
+    ops = _ops()
+    _, b, _, _, fs = make_case(4, 8, False, 64, 16, log2_T=12)
+    d = dev(b)
+    wpos, pos01, sel = ops.positions_fwd(d["origins"], d["directions"], d["starts"].view(-1), d["ends"].view(-1), fs)
+    pos = T.frustum_positions(b["origins"], b["directions"], b["starts"], b["ends"])
+    q = (T.scene_contraction_linf(pos) + 2.0) / 4.0
+    s = ((q > 0) & (q < 1)).all(-1)
+    assert_close("world_pos", wpos, pos, 1e-6)
+    assert_close("pos01", pos01, q * s[:, None], 1e-6)
+    assert torch.equal(sel.cpu() > 0.5, s)
+    # density_fn path (positions given) and the aabb-normalised branch, incl. points outside the box
+    g = torch.Generator().manual_seed(3)
+    P = (torch.rand(500, 3, generator=g) * 6 - 3)
+    fs2 = ops.FieldSpec(fs.layout, 0.4, False, aabb=(-1, -1, -1, 1, 1, 1), scalings=fs.scalings)
+    _, p2, s2 = ops.positions_fwd(None, None, None, None, fs2, world_pos_in=P.to(DEV))
+    q2 = (P + 1) / 2
+    m2 = ((q2 > 0) & (q2 < 1)).all(-1)
+    assert torch.equal(s2.cpu() > 0.5, m2) and 0 < int(m2.sum()) < 500
+    assert_close("pos01_aabb", p2, q2 * m2[:, None], 1e-6)
+
+
+@pytest.mark.parametrize("level_major", [True, False])
+@pytest.mark.parametrize("log2_T", [19, 12])
+def test_hashgrid_fwd_bwd(level_major, log2_T):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    N = 3000
+    x = torch.rand(N, 3, generator=g)
+    x[:7] = 0.0  # masked samples sit exactly on a vertex
+    x[7] = torch.tensor([1.0 / 16, 0.5, 0.25])  # exact integer coordinates at level 0 (ceil == floor)
+    table = ((torch.rand(16 << log2_T, 2, generator=g) * 2 - 1) * 0.5).requires_grad_()
+    sc = T.hash_scalings()
+    ref = T.hash_encode(x, table, sc, log2_T)
+    enc = ops.hashgrid_fwd(x.to(DEV), table.detach().to(DEV), sc.to(DEV), log2_T, level_major)
+    got = enc.permute(1, 0, 2).reshape(N, 32) if level_major else enc
+    assert_close("enc", got, ref, 2e-6)
+    cot = torch.rand(N, 32, generator=g)
+    cot[100:200] = 0.0
+    (gref,) = torch.autograd.grad((ref * cot).sum(), table)
+    d_enc = cot.view(N, 16, 2).permute(1, 0, 2).contiguous() if level_major else cot
+    d_table = torch.zeros_like(table.detach()).to(DEV)
+    ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, level_major)
+    assert_close("d_table", d_table, gref, 2e-5)
+
+
+CASES = [
+    pytest.param(6, 31, True, 0.4, id="C6_B31_spec"),
+    pytest.param(9, 128, True, 0.3, id="C9_B128_spec"),
+    pytest.param(4, 141, False, 0.7, id="C4_B141_nospec"),
+    pytest.param(4, 21, True, 0.5, id="C4_B21_spec"),
+    pytest.param(15, 3, True, 0.2, id="C15_B3_spec"),
+]
+
+
+def _oracle_field(p, b, temperature):
+    density, emb, sraw, sel = T.field_density(p, b["origins"], b["directions"], b["starts"], b["ends"])
+    outs = T.field_outputs(p, b["origins"], b["directions"], b["starts"], b["ends"], emb, temperature)
+    return density, emb, sraw, sel, outs
+
+
+@pytest.mark.parametrize("C,B,spec,temp", CASES)
+def test_field_fwd(C, B, spec, temp):
+    """R3-R9 with the hash features taken from the ORACLE (isolates the MFMA kernels from the gather kernel)."""
+    ops = _ops()
+    p, b, layout, flat, fs = make_case(C, B, spec, 7, 29, log2_T=12, temperature=temp)  # N = 203: ragged tail tile
+    density, emb, sraw, sel, outs = _oracle_field(p, b, temp)
+    pos = T.frustum_positions(b["origins"], b["directions"], b["starts"], b["ends"])
+    q = (T.scene_contraction_linf(pos) + 2.0) / 4.0
+    enc = T.hash_encode(q * sel[:, None], p.hash_table, p.scalings, p.log2_T).detach()
+    N = enc.shape[0]
+    for level_major in (True, False):
+        e = enc.view(N, 16, 2).permute(1, 0, 2).contiguous() if level_major else enc
+        out = ops.field_fwd(fs, flat, e.to(DEV), level_major, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV), want_emb=True)
+        assert_close("sigma_raw", out["sigma_raw"], sraw.view(-1), 2e-5)
+        assert_close("sigma", out["sigma"], density.view(-1), 2e-5)
+        assert_close("emb", out["emb"], emb, 2e-5)
+        assert_close("abundances", out["abundances"], outs["abundances"].view(N, C), 2e-5)
+        assert_close("spectral", out["spectral"], outs["spectral"].view(N, B), 2e-5)
+        if spec:
+            assert_close("spectral2", out["spectral2"], outs["spectral2"].view(N, B), 2e-5)
+            assert_close("specular", out["specular"], outs["specular"].view(N, B), 2e-5)
+
+
+def test_density_only():
+    ops = _ops()
+    p, b, layout, flat, fs = make_case(6, 31, True, 5, 40, log2_T=14)
+    pos = T.frustum_positions(b["origins"], b["directions"], b["starts"], b["ends"])
+    sig, emb = ops.DensityFn.apply(flat, pos.to(DEV), fs)
+    q = (T.scene_contraction_linf(pos) + 2.0) / 4.0
+    sel = ((q > 0) & (q < 1)).all(-1)
+    h = T.mlp_forward(T.hash_encode(q * sel[:, None], p.hash_table, p.scalings, p.log2_T), list(p.base_w), list(p.base_b))
+    assert_close("density_fn", sig, torch.exp(h[:, :1]) * sel[:, None], 2e-5)
+    assert_close("density_fn emb", emb, h[:, 1:], 2e-5)
+
+
+@pytest.mark.parametrize("C,B,spec,temp", CASES)
+def test_field_bwd(C, B, spec, temp):
+    ops = _ops()
+    p, b, layout, flat, fs = make_case(C, B, spec, 9, 23, log2_T=12, temperature=temp, seed=4)  # N = 207
+    pos = T.frustum_positions(b["origins"], b["directions"], b["starts"], b["ends"])
+    q = (T.scene_contraction_linf(pos) + 2.0) / 4.0
+    sel = ((q > 0) & (q < 1)).all(-1)
+    enc = T.hash_encode(q * sel[:, None], p.hash_table, p.scalings, p.log2_T).detach().requires_grad_()
+    N = enc.shape[0]
+    # oracle forward from enc
+    h = T.mlp_forward(enc, list(p.base_w), list(p.base_b))
+    sraw, emb = torch.split(h, [1, 15], dim=-1)
+    density = T.trunc_exp(sraw) * sel[:, None]
+    outs = T.field_outputs(p, b["origins"], b["directions"], b["starts"], b["ends"], emb, temp)
+    g = torch.Generator().manual_seed(9)
+    cot_s = torch.rand(N, B, generator=g) - 0.3
+    cot_d = torch.rand(N, 1, generator=g) - 0.3
+    cot_e = torch.rand(N, 15, generator=g) - 0.5
+    loss = (outs["spectral"].view(N, B) * cot_s).sum() + (density * cot_d).sum() + (emb * cot_e).sum()
+    names = [k for k, _ in p.named_parameters() if k != "hash_table"]
+    params = [v for k, v in p.named_parameters() if k != "hash_table"]
+    grads = torch.autograd.grad(loss, [enc] + params, allow_unused=True)
+    d_enc_ref, pgrads = grads[0], dict(zip(names, grads[1:]))
+    d_flat = torch.zeros_like(flat)
+    e = enc.detach().view(N, 16, 2).permute(1, 0, 2).contiguous()
+    d_enc = ops.field_bwd(fs, flat, e.to(DEV), True, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV),
+                          cot_d.view(-1).to(DEV), cot_s.to(DEV), cot_e.to(DEV), d_flat)
+    assert_close("d_enc", d_enc.permute(1, 0, 2).reshape(N, 32), d_enc_ref, 5e-5)
+    key = {"base_w": "mlp_base.mlp", "head_w": "mlp_head", "feat_w": "feature_mlp", "dir_w": "mlp_directional",
+           "base_b": "mlp_base.mlp", "head_b": "mlp_head", "feat_b": "feature_mlp", "dir_b": "mlp_directional"}
+    for k, gref in pgrads.items():
+        if k == "endmembers":
+            got = layout.view(d_flat, "endmembers")
+        else:
+            pre, idx = k.rsplit(".", 1)
+            got = layout.view(d_flat, f"{key[pre]}.layers.{idx}.{'weight' if pre.endswith('_w') else 'bias'}")
+        if gref is None:
+            assert float(got.abs().max()) == 0.0, k
+        else:
+            assert_close(f"grad {k}", got, gref, 5e-5)
+
+
+# --------------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("S,K", [(64, 31), (100, 5), (7, 141)])
+def test_composite_fwd_bwd(ragged, S, K):
+    ops = _ops()
+    R = 37
+    b = T.synthetic_batch(R, S, K, seed=13, ragged=ragged)
+    N = b["origins"].shape[0]
+    g = torch.Generator().manual_seed(2)
+    sigma = torch.exp(torch.randn(N, generator=g) * 1.5 + 2.0).requires_grad_()
+    v1 = torch.rand(N, K, generator=g).requires_grad_()
+    v2 = torch.rand(N, 3, generator=g)
+    t0, t1, ri = b["starts"], b["ends"], b["ray_indices"]
+    pinfo = T.pack_info(ri, R)
+    got_pinfo = ops.pack_info(ri.to(DEV), R)
+    assert torch.equal(got_pinfo.cpu(), pinfo)  # index work: bit-exact (incl. empty rays)
+    fo = T.scale_gradients_by_distance_squared({"density": sigma[:, None], "v1": v1}, t0, t1)
+    w = T.render_weight_from_density(t0[:, 0], t1[:, 0], fo["density"][:, 0], pinfo)[0]
+    o1 = T.accumulate_along_rays(w, fo["v1"], ri, R)
+    o2 = T.accumulate_along_rays(w, v2, ri, R)
+    acc = T.accumulate_along_rays(w, None, ri, R)
+    steps = (t0 + t1) / 2
+    depth = T.accumulate_along_rays(w, steps, ri, R) / (acc + 1e-10)
+    cot1, cota = torch.rand(R, K, generator=g) - 0.5, torch.rand(R, 1, generator=g) - 0.5
+    gs, gv = torch.autograd.grad((o1 * cot1).sum() + (acc * cota).sum(), [sigma, v1])
+
+    sd, vd = sigma.detach().to(DEV).requires_grad_(), v1.detach().to(DEV).requires_grad_()
+    outs = ops.CompositeFn.apply(sd.view(-1, 1), t0.to(DEV), t1.to(DEV), got_pinfo, True, vd, v2.to(DEV))
+    wg, accg, depthg, o1g, o2g = outs
+    assert_close("weights", wg.view(-1), w, 1e-5)
+    assert_close("acc", accg, acc, 1e-5)
+    assert_close("depth", depthg, depth, 1e-5)
+    assert_close("out1", o1g, o1, 1e-5)
+    assert_close("out2", o2g, o2, 1e-5)
+    ((o1g * cot1.to(DEV)).sum() + (accg * cota.to(DEV)).sum()).backward()
+    assert_close("d_sigma", sd.grad, gs, 1e-4)
+    assert_close("d_values", vd.grad, gv, 1e-5)
+
+
+@pytest.mark.parametrize("bands", ["b21", "b31", "b128", "b141"])
+def test_spec2rgb_golden_and_grad(golden_dir, bands):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "g1_colour.npz"))
+    M = torch.from_numpy(g[f"{bands}_M"])
+    spec = torch.from_numpy(g[f"{bands}_spec"])
+    rgb = ops.spec2rgb_fwd(spec.to(DEV), M.to(DEV))
+    np.testing.assert_allclose(rgb.cpu().numpy(), g[f"{bands}_rgb"], rtol=0, atol=2e-6)  # reference's own output
+    s = spec.clone().requires_grad_()
+    cot = torch.rand(spec.shape[0], 3, generator=torch.Generator().manual_seed(1))
+    (gref,) = torch.autograd.grad((T.colour_system(s, M) * cot).sum(), s)
+    got = ops.spec2rgb_bwd(spec.to(DEV), M.to(DEV), cot.to(DEV))
+    assert_close("d_spec", got, gref, 2e-5)
+
+
+def test_adam_matches_torch_optim():
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    n = 10007
+    p0 = torch.rand(n, generator=g)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=2e-2, eps=1e-15)
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pad = (-n) % 4
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * 0.1
+        grad[::3] = 0.0  # untouched hash slots still decay m/v
+        ref.grad = grad.clone()
+        opt.step()
+        with torch.no_grad():
+            ref[100:200].clamp_(0, 1)  # clamp_endmembers epilogue
+        ops.adam_step(p, grad.to(DEV), m, v, step, 2e-2, clamp_range=(100, 200))
+        assert_close(f"adam step {step}", p, ref, 2e-6)
+    assert pad >= 0
+
+
+@pytest.mark.parametrize("case,C,B,spec", [("c6b31s", 6, 31, True), ("c9b128s", 9, 128, True), ("c4b141n", 4, 141, False)])
+def test_field_against_reference_golden(golden_dir, case, C, B, spec):
+    """G4: outputs/grads produced by the reference's own UMHSField.get_density/get_outputs code."""
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, f"g4_field_{case}.npz"))
+    layout = ops.FieldLayout(C, B, spec, 12)
+    flat = torch.zeros(layout.total)
+    p = T.FieldParams(C, B, spec, log2_hashmap_size=12, seed=0)
+    with torch.no_grad():
+        for k, v in p.named_parameters():
+            v.copy_(torch.from_numpy(g[f"param_{k}"]))
+    for k, v in p.reference_state_dict().items():
+        layout.view(flat, k).copy_(v)
+    flat = flat.to(DEV).requires_grad_()
+    fs = ops.FieldSpec(layout, float(g["temperature"]), True, scalings=ops.hash_scalings().to(DEV))
+    o, d, s, e = (torch.from_numpy(g[k]).to(DEV) for k in ("origins", "directions", "starts", "ends"))
+    density, emb, spectral, spectral2, specular, abund = ops.FieldFn.apply(flat, o, d, s, e, fs)
+    N = o.shape[0]
+    np.testing.assert_allclose(density.detach().cpu().numpy(), g["density"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(emb.detach().cpu().numpy(), g["emb"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(spectral.detach().cpu().numpy(), g["out_spectral"].reshape(N, B), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(abund.cpu().numpy(), g["out_abundances"].reshape(N, C), rtol=1e-4, atol=1e-6)
+    if spec:
+        np.testing.assert_allclose(spectral2.cpu().numpy(), g["out_spectral2"].reshape(N, B), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(specular.cpu().numpy(), g["out_specular"].reshape(N, B), rtol=1e-4, atol=1e-6)
+    loss = (spectral * torch.from_numpy(g["cot_spec"]).to(DEV).view(N, B)).sum() + (density * torch.from_numpy(g["cot_den"]).to(DEV)).sum()
+    loss.backward()
+    gflat = flat.grad
+    tab = layout.view(gflat, "mlp_base.encoder.hash_table").cpu()
+    rows = torch.from_numpy(g["grad_hash_rows"])
+    assert_close("d_table rows", tab[rows], torch.from_numpy(g["grad_hash_vals"]), 1e-4)
+    mask = torch.ones(tab.shape[0], dtype=torch.bool)
+    mask[rows] = False
+    assert float(tab[mask].abs().max()) == 0.0
+    assert_close("d_endmembers", layout.view(gflat, "endmembers"), torch.from_numpy(g["grad_endmembers"]), 1e-4)
+    assert_close("d_head_w1", layout.view(gflat, "mlp_head.layers.1.weight"), torch.from_numpy(g["grad_head_w.1"]), 1e-4)
+    assert_close("d_base_w0", layout.view(gflat, "mlp_base.mlp.layers.0.weight"), torch.from_numpy(g["grad_base_w.0"]), 1e-4)
+
+
+@pytest.mark.parametrize("C,B,spec,temp,ragged", [(6, 31, True, 0.4, False), (4, 141, False, 0.7, True)])
+def test_end_to_end_loss_and_grads(C, B, spec, temp, ragged):
+    """FieldFn -> CompositeFn -> Spec2RgbFn -> loss, against oracle model_outputs/model_loss (radiance 1e-4, PSNR 0.05 dB)."""
+    ops = _ops()
+    R = 48
+    p, b, layout, flat, fs = make_case(C, B, spec, R, 24, ragged=ragged, log2_T=15, temperature=temp, seed=21)
+    M = T.colour_matrix(np.linspace(400, 700, B))
+    gt_rgb = T.colour_system(b["gt_spectral"], M)
+    out = T.model_outputs(p, b["origins"], b["directions"], b["starts"], b["ends"], b["ray_indices"], R, temp, M)
+    loss = T.model_loss(out, b["gt_spectral"], gt_rgb, b["bg_random"], "rgb+spectral")
+    total = loss["spectral_loss"] + loss["rgb_loss"]
+    names = [k for k, _ in p.named_parameters()]
+    grads = dict(zip(names, torch.autograd.grad(total, [v for _, v in p.named_parameters()], allow_unused=True)))
+
+    d = dev(b)
+    flat = flat.requires_grad_()
+    density, emb, spectral, spectral2, specular, abund = ops.FieldFn.apply(flat, d["origins"], d["directions"], d["starts"], d["ends"], fs)
+    pinfo = ops.pack_info(d["ray_indices"], R)
+    vals = [spectral] + ([spectral2, specular] if spec else []) + [abund]
+    w, acc, depth, *outs = ops.CompositeFn.apply(density, d["starts"], d["ends"], pinfo, True, *vals)
+    rgb = ops.Spec2RgbFn.apply(outs[0], M.to(DEV))
+    pred_rgb = rgb + d["bg_random"] * (1.0 - acc)
+    l_spec = 5 * torch.nn.functional.mse_loss(outs[0], d["gt_spectral"])
+    l_rgb = torch.nn.functional.mse_loss(pred_rgb, gt_rgb.to(DEV))
+    (l_spec + l_rgb).backward()
+
+    assert_close("spectral", outs[0], out["spectral"], 1e-4)
+    assert_close("rgb", rgb, out["rgb"], 1e-4)
+    assert_close("accumulation", acc, out["accumulation"], 1e-4)
+    assert_close("abundances", outs[-1], out["abundances"], 1e-4)
+    if spec:
+        assert_close("spectral2", outs[1], out["spectral2"], 1e-4)
+        assert_close("specular", outs[2], out["specular"], 1e-4)
+    psnr_ref = float(T.psnr(out["spectral"], b["gt_spectral"]))
+    psnr_got = float(T.psnr(outs[0].detach().cpu(), b["gt_spectral"]))
+    assert abs(psnr_ref - psnr_got) < 0.05
+    assert abs(float(l_spec) - float(loss["spectral_loss"])) <= 1e-4 * abs(float(loss["spectral_loss"]))
+    assert abs(float(l_rgb) - float(loss["rgb_loss"])) <= 1e-4 * abs(float(loss["rgb_loss"]))
+    g = flat.grad
+    assert_close("grad hash_table", layout.view(g, "mlp_base.encoder.hash_table"), grads["hash_table"], 2e-4)
+    assert_close("grad endmembers", layout.view(g, "endmembers"), grads["endmembers"], 2e-4)
+    assert_close("grad base_w0", layout.view(g, "mlp_base.mlp.layers.0.weight"), grads["base_w.0"], 2e-4)
+    assert_close("grad feat_w2", layout.view(g, "feature_mlp.layers.2.weight"), grads["feat_w.2"], 2e-4)
+    assert_close("grad head_b0", layout.view(g, "mlp_head.layers.0.bias"), grads["head_b.0"], 2e-4)
+    if spec:
+        assert_close("grad dir_w1", layout.view(g, "mlp_directional.layers.1.weight"), grads["dir_w.1"], 2e-4)

@@ -1,0 +1,982 @@
+// Fused per-sample UMHS field for gfx950 (R3-R9, R18): mlp_base MLP, NeRF/SH encodings, mlp_head,
+// feature_mlp, mlp_directional, sigmoid / temperature-softmax and endmember mixing, forward and
+// backward, on the f32-input MFMA (v_mfma_f32_16x16x4_f32: exact f32 fmaf chain, needed for the 1e-4
+// radiance parity).  Reference: umhs_field.py:151-261,300-329.
+//
+// Data flow ("samples on lanes"): every GEMM is computed transposed, Y^T[out][sample] = W[out][in] X^T,
+// with the WEIGHTS as the MFMA A operand and the ACTIVATIONS as the B operand.  A 16x16 result tile
+// then has its 16 samples on lane&15 and its 16 output features on (lane>>4, reg) -- which is exactly
+// the B-operand shape of the next layer (k-slot <-> lane>>4), so an accumulator register feeds the
+// next MFMA directly: no LDS transpose, no cross-lane traffic between layers.  The price is a permuted
+// k order, paid once by packing each weight matrix in the matching order (fwd image in LDS; the
+// transposed images for dX come from global/L2).  Bias rides in as the initial accumulator.
+//
+// Backward recomputes the forward per 16-sample tile (nothing but the hash features is saved), runs
+// the dX chain the same way with transposed packs, and forms dW = dZ X^T (contraction over samples,
+// i.e. over lanes) by staging [sample][feature] tiles of dZ and X in LDS and re-reading them
+// transposed as MFMA operands; each wave keeps a quarter of every layer's dW tiles in registers for
+// the whole launch, partial slabs are summed by a small reduce kernel.
+#include "umhs_common.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+enum InKind { IN_ENC = 0, IN_HID64 = 1, IN_HID16 = 2, IN_27 = 3, IN_DIR28 = 4, IN_MIX = 5 };
+enum LayerId { L_B0 = 0, L_B1, L_H0, L_H1, L_H2, L_F0, L_F1, L_F2, L_D0, L_D1, L_MX, NLAYERS };
+
+struct LayerDesc {
+  const float* W;  // [OUT][IN] row-major (L_MX: endmembers [C][B], addressed transposed)
+  const float* b;  // [OUT] or null
+  int kind, KS, OT, OUT, IN;
+  int off_w, off_b;  // float offsets in the forward pack image
+};
+struct PackDesc {
+  LayerDesc L[NLAYERS];
+  int total_w, total;  // floats
+};
+
+// k-slot (step s, lane quarter q) -> column of the reference weight matrix, or -1
+__device__ __forceinline__ int kmap_in(int kind, int s, int q) {
+  switch (kind) {
+    case IN_ENC: return 8 * q + s;
+    case IN_HID64: return 16 * (s >> 2) + 4 * q + (s & 3);
+    case IN_HID16: return 4 * q + s;
+    case IN_27: {
+      if (s < 3) return 3 * q + s;            // positional encoding p = 3q+s
+      int e = 4 * q + (s - 3) - 1;            // base-MLP output slot 4q+r, slot 0 is sigma_raw
+      return e >= 0 ? 12 + e : -1;
+    }
+    case IN_DIR28: return s < 4 ? 4 * q + s : 16 + 3 * q + (s - 4);
+    default: return 4 * q + s;  // IN_MIX: class index
+  }
+}
+
+// forward pack image: for each layer, A-operand values in the exact order the waves consume them:
+//   w[off_w + ((t*KS4 + s4)*64 + lane)*4 + ss] = W[16t + (lane&15)][kmap(4*s4+ss, lane>>4)]
+__device__ __forceinline__ float fwd_pack_value(const PackDesc& pd, int idx) {
+  int li = 0;
+  while (li + 1 < NLAYERS && idx >= pd.L[li + 1].off_w) ++li;
+  const LayerDesc& L = pd.L[li];
+  const int rel = idx - L.off_w;
+  const int ss = rel & 3, ln = (rel >> 2) & 63, blk = rel >> 8;
+  const int KS4 = (L.KS + 3) >> 2;
+  const int t = blk / KS4, s = (blk % KS4) * 4 + ss;
+  const int out = 16 * t + (ln & 15), q = ln >> 4;
+  if (s >= L.KS || out >= L.OUT) return 0.0f;
+  const int in = kmap_in(L.kind, s, q);
+  if (li == L_MX) return (in >= 0 && in < L.IN) ? L.W[(size_t)in * L.OUT + out] : 0.0f;  // E[c][b]
+  return (in >= 0 && in < L.IN) ? L.W[(size_t)out * L.IN + in] : 0.0f;
+}
+
+__device__ __forceinline__ void build_fwd_image(float* lds, const PackDesc& pd) {
+  for (int idx = threadIdx.x; idx < pd.total_w; idx += blockDim.x) lds[idx] = fwd_pack_value(pd, idx);
+  for (int li = 0; li < NLAYERS; ++li) {
+    const LayerDesc& L = pd.L[li];
+    if (li == L_MX) continue;
+    for (int o = threadIdx.x; o < 16 * L.OT; o += blockDim.x) lds[L.off_b + o] = (L.b && o < L.OUT) ? L.b[o] : 0.0f;
+  }
+}
+
+// acc[ct][t] (+)= W-pack(t, :) x B-operand regs b[ct][:]   (A from LDS or global, 16 B per lane per 4 k-steps)
+template <int OT, int KS, int NT, bool INIT>
+__device__ __forceinline__ void gemm_pack(v4f (&acc)[NT][OT], const float (&b)[NT][KS], const float* __restrict__ w,
+                                          const float* __restrict__ bias, int lane) {
+  constexpr int KS4 = (KS + 3) / 4;
+  if (INIT) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (bias) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct][t] = bv;
+    }
+  }
+#pragma unroll
+  for (int s4 = 0; s4 < KS4; ++s4) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      const v4f a = *reinterpret_cast<const v4f*>(w + ((t * KS4 + s4) * 64 + lane) * 4);
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        if (s4 * 4 + ss < KS) {
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) acc[ct][t] = MFMA(a[ss], b[ct][s4 * 4 + ss], acc[ct][t]);
+        }
+      }
+    }
+  }
+}
+
+template <int OT, int NT>
+__device__ __forceinline__ void relu_to(float (&x)[NT][OT * 4], const v4f (&acc)[NT][OT]) {
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[ct][4 * t + r] = fmaxf(acc[ct][t][r], 0.0f);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float xq_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xq_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float sel4(const v4f& v, int r) { return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3])); }
+
+struct FieldIO {
+  const float* enc;
+  int64_t sn, sl;
+  const float *wpos, *dirs, *sel;
+  int64_t n;
+  int B, C, TB;
+  float temperature;
+  // forward outputs
+  float *sigma, *sigma_raw, *emb, *spectral, *spectral2, *specular, *abund;
+  // backward
+  const float *d_sigma, *d_spectral, *d_emb;
+  float* d_enc;
+};
+
+// NeRF positional encoding slots of quarter q (3 per lane) and SH slots (4 per lane)
+__device__ __forceinline__ void pe_slots(float (&pe)[3], float x, float y, float z, int q) {
+  const float TWO_PI = 6.2831855f, HALF_PI = 1.5707964f;
+  const bool odd = q & 1;
+  const float c0 = odd ? y : x, c1 = odd ? z : x, c2 = odd ? z : y;
+  const float f0 = odd ? 2.0f : 1.0f, f1 = odd ? 1.0f : 2.0f, f2 = odd ? 2.0f : 1.0f;
+  float a0 = (TWO_PI * c0) * f0, a1 = (TWO_PI * c1) * f1, a2 = (TWO_PI * c2) * f2;
+  if (q >= 2) a0 += HALF_PI, a1 += HALF_PI, a2 += HALF_PI;
+  pe[0] = sinf(a0), pe[1] = sinf(a1), pe[2] = sinf(a2);
+}
+
+__device__ __forceinline__ void sh_slots(float (&sh)[4], float dx, float dy, float dz, int q) {
+  const float x = (dx + 1.0f) / 2.0f, y = (dy + 1.0f) / 2.0f, z = (dz + 1.0f) / 2.0f;
+  const float xx = x * x, yy = y * y, zz = z * z;
+  if (q == 0) {
+    sh[0] = 0.28209479177387814f, sh[1] = 0.4886025119029199f * y, sh[2] = 0.4886025119029199f * z;
+    sh[3] = 0.4886025119029199f * x;
+  } else if (q == 1) {
+    sh[0] = 1.0925484305920792f * x * y, sh[1] = 1.0925484305920792f * y * z;
+    sh[2] = 0.9461746957575601f * zz - 0.31539156525251999f, sh[3] = 1.0925484305920792f * x * z;
+  } else if (q == 2) {
+    sh[0] = 0.5462742152960396f * (xx - yy), sh[1] = 0.5900435899266435f * y * (3.0f * xx - yy);
+    sh[2] = 2.890611442640554f * x * y * z, sh[3] = 0.4570457994644658f * y * (5.0f * zz - 1.0f);
+  } else {
+    sh[0] = 0.3731763325901154f * z * (5.0f * zz - 3.0f), sh[1] = 0.4570457994644658f * x * (5.0f * zz - 1.0f);
+    sh[2] = 1.445305721320277f * z * (xx - yy), sh[3] = 0.5900435899266435f * x * (xx - 3.0f * yy);
+  }
+}
+
+// Everything the heads need, recomputed per 16-sample column tile (NT tiles per wave).
+template <int NT>
+struct HeadState {
+  float m[NT][4];   // sigmoid(head) * softmax(feat/T)   (rows c = 4q+r, zero for c >= C)
+  float sg[NT][4];  // sigmoid(head)
+  float ab[NT][4];  // abundances
+  float s1[NT];     // sigmoid of the extra feature logit (specular gate)
+};
+
+template <int NT, bool SPEC>
+__device__ __forceinline__ void head_epilogue(HeadState<NT>& hs, const v4f (&hd4)[NT][1], const v4f (&fl4)[NT][1], int C,
+                                              float temperature, int lane) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    float z[4], zmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      z[r] = fl4[ct][0][r] / temperature;
+      if (4 * q + r < C) zmax = fmaxf(zmax, z[r]);
+    }
+    zmax = xq_max(zmax);
+    float e[4], sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e[r] = (4 * q + r < C) ? expf(z[r] - zmax) : 0.0f;
+      sum += e[r];
+    }
+    sum = xq_sum(sum);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool v = 4 * q + r < C;
+      hs.ab[ct][r] = e[r] / sum;
+      hs.sg[ct][r] = v ? sigmoidf_(hd4[ct][0][r]) : 0.0f;
+      hs.m[ct][r] = hs.sg[ct][r] * hs.ab[ct][r];
+    }
+    if (SPEC) {
+      const float mine = sel4(fl4[ct][0], C & 3);
+      hs.s1[ct] = sigmoidf_(__shfl(mine, ((C >> 2) << 4) | (lane & 15), 64));
+    } else {
+      hs.s1[ct] = 0.0f;
+    }
+  }
+}
+
+// =============================================================================================
+// Forward
+// =============================================================================================
+template <bool SPEC, bool DENSITY_ONLY>
+__global__ __launch_bounds__(256, 2) void field_fwd_kernel(FieldIO io, PackDesc pd) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  build_fwd_image(lds, pd);
+  __syncthreads();
+  constexpr int NT = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int64_t ntiles = (io.n + 127) / 128;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t nn[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      int64_t n = tile * 128 + wave * 32 + ct * 16 + j;
+      ok[ct] = n < io.n;
+      nn[ct] = ok[ct] ? n : io.n - 1;
+    }
+    float encf[NT][8];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int lv = 0; lv < 4; ++lv) {
+        const float2 v = *reinterpret_cast<const float2*>(io.enc + nn[ct] * io.sn + (int64_t)(4 * q + lv) * io.sl);
+        encf[ct][2 * lv] = v.x, encf[ct][2 * lv + 1] = v.y;
+      }
+    // ---- mlp_base: 32 -> 64 -> 16 -------------------------------------------------------------
+    v4f h4[NT][4];
+    gemm_pack<4, 8, NT, true>(h4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+    float h[NT][16];
+    relu_to<4, NT>(h, h4);
+    v4f bo4[NT][1];
+    gemm_pack<1, 16, NT, true>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      if (ok[ct]) {
+        if (q == 0) {
+          const float raw = bo4[ct][0][0];
+          io.sigma[nn[ct]] = expf(raw) * io.sel[nn[ct]];
+          if (io.sigma_raw) io.sigma_raw[nn[ct]] = raw;
+        }
+        if (io.emb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = 4 * q + r - 1;
+            if (e >= 0) io.emb[nn[ct] * 15 + e] = bo4[ct][0][r];
+          }
+        }
+      }
+    }
+    if (DENSITY_ONLY) continue;
+    // ---- encodings -----------------------------------------------------------------------------
+    float in27[NT][7], dir28[NT][7];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      float pe[3];
+      pe_slots(pe, io.wpos[3 * nn[ct]], io.wpos[3 * nn[ct] + 1], io.wpos[3 * nn[ct] + 2], q);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) in27[ct][s] = pe[s];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) in27[ct][3 + r] = bo4[ct][0][r];
+      if (SPEC) {
+        float sh[4];
+        sh_slots(sh, io.dirs[3 * nn[ct]], io.dirs[3 * nn[ct] + 1], io.dirs[3 * nn[ct] + 2], q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dir28[ct][s] = sh[s];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dir28[ct][4 + s] = pe[s];
+      }
+    }
+    // ---- mlp_head / feature_mlp: 27 -> 64 -> 64 -> C(+1) ----------------------------------------
+    v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
+    float a1[NT][16], a2[NT][16];
+    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+    relu_to<4, NT>(a1, t4);
+    gemm_pack<4, 16, NT, true>(t4, a1, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+    relu_to<4, NT>(a2, t4);
+    gemm_pack<1, 16, NT, true>(hd4, a2, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+    relu_to<4, NT>(a1, t4);
+    gemm_pack<4, 16, NT, true>(t4, a1, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+    relu_to<4, NT>(a2, t4);
+    gemm_pack<1, 16, NT, true>(fl4, a2, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    HeadState<NT> hs;
+    head_epilogue<NT, SPEC>(hs, hd4, fl4, io.C, io.temperature, lane);
+    if (io.abund) {
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ok[ct] && 4 * q + r < io.C) io.abund[nn[ct] * io.C + 4 * q + r] = hs.ab[ct][r];
+    }
+    // ---- mlp_directional hidden: 28 -> 16 ---------------------------------------------------------
+    float hdir[NT][4];
+    if (SPEC) {
+      v4f d4[NT][1];
+      gemm_pack<1, 7, NT, true>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+      relu_to<1, NT>(hdir, d4);
+    }
+    // ---- per 16-band tile: mixing (K = classes) and specular (K = 16 hidden) -------------------------
+    for (int t = 0; t < io.TB; ++t) {
+      v4f sp[NT][1], sc[NT][1];
+      gemm_pack<1, 4, NT, true>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
+      if (SPEC) gemm_pack<1, 4, NT, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = 16 * t + 4 * q + r;
+          if (ok[ct] && b < io.B) {
+            const float spec = sp[ct][0][r];
+            const float spl = SPEC ? hs.s1[ct] * sigmoidf_(sc[ct][0][r]) : 0.0f;
+            const int64_t o = nn[ct] * io.B + b;
+            io.spectral[o] = SPEC ? spec + spl : spec;
+            if (SPEC && io.spectral2) io.spectral2[o] = spec;
+            if (SPEC && io.specular) io.specular[o] = spl;
+          }
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// Backward: transposed pack images (A operands of the dX chain), built once per call in global memory
+// =============================================================================================
+enum TLayerId { T_B1 = 0, T_B0, T_H2, T_H1, T_H0, T_F2, T_F1, T_F0, T_D1, T_MX, NTLAYERS };
+struct TDesc {
+  const float* W;
+  int OUT, IN, KS, OT, rowmap, off;  // rowmap 0: in = rho, 1: emb slots of the 27-d input, 2: L_MX (E[c=rho][b=k])
+};
+struct TPackDesc {
+  TDesc L[NTLAYERS];
+  int total;
+};
+
+//   wT[off + ((t*KS4 + s4)*64 + lane)*4 + ss] = W[k(4*s4+ss, lane>>4)][rowmap(16t + (lane&15))]
+__global__ __launch_bounds__(256) void field_pack_T_kernel(TPackDesc td, float* __restrict__ dst) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < td.total; idx += gridDim.x * 256) {
+    int li = 0;
+    while (li + 1 < NTLAYERS && idx >= td.L[li + 1].off) ++li;
+    const TDesc& L = td.L[li];
+    const int rel = idx - L.off;
+    const int ss = rel & 3, ln = (rel >> 2) & 63, blk = rel >> 8;
+    const int KS4 = (L.KS + 3) >> 2;
+    const int t = blk / KS4, s = (blk % KS4) * 4 + ss;
+    const int rho = 16 * t + (ln & 15), q = ln >> 4;
+    const int k = 16 * (s >> 2) + 4 * q + (s & 3);  // dZ row held by (step s, quarter q)
+    float v = 0.0f;
+    if (L.rowmap == 2) {
+      if (rho < L.OUT && k < L.IN) v = L.W[(size_t)rho * L.IN + k];  // E[c][b], OUT=C, IN=B
+    } else if (s < L.KS && k < L.OUT) {
+      int in = rho;
+      if (L.rowmap == 1) in = (rho >= 1 && rho <= 15) ? 12 + rho - 1 : -1;
+      if (in >= 0 && in < L.IN) v = L.W[(size_t)k * L.IN + in];
+    }
+    dst[idx] = v;
+  }
+}
+
+// ---- LDS staging of [sample][feature] tiles (row stride FS = 16 mod 32: conflict-free transposed reads)
+template <int OT>
+__device__ __forceinline__ void stage_hid(float* st, int FS, int row, int q, const float (&x)[OT * 4]) {
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+    *reinterpret_cast<v4f*>(st + row * FS + 16 * t + 4 * q) = v4f{x[4 * t], x[4 * t + 1], x[4 * t + 2], x[4 * t + 3]};
+}
+
+// dW tile pairs of one layer, quarter-split over the 4 waves: pair p = idx*4 + wave, (to,ti) = (p/TI, p%TI)
+//   D[out=16to+4q+r][in=16ti+j] += sum_samples Z[sample][out] * X[sample][in]
+template <int NACC>
+__device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restrict__ stZ, int FSz,
+                                         const float* __restrict__ stX, int FSx, int TO, int TI, int wave, int lane) {
+  const int j = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+    for (int idx = 0; idx < NACC; ++idx) {
+      const int p = idx * 4 + wave;
+      if (p < TO * TI) {
+        const int to = p / TI, ti = p - to * TI;
+        const float a = stZ[(4 * ks + q) * FSz + 16 * to + j];
+        const float b = stX[(4 * ks + q) * FSx + 16 * ti + j];
+        acc[idx] = MFMA(a, b, acc[idx]);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float col_sum64(const float* __restrict__ st, int FS, int col) {
+  float s = 0.0f;
+#pragma unroll 8
+  for (int r = 0; r < 64; ++r) s += st[r * FS + col];
+  return s;
+}
+
+// slab layout (floats) of one workgroup's partial parameter gradients
+struct SlabLayout {
+  int off[NLAYERS];   // dW tiles of layer l: [wave 4][nacc][64 lanes][4]
+  int nacc[NLAYERS];
+  int TO[NLAYERS], TI[NLAYERS];
+  int off_db[NLAYERS];
+  int total;
+};
+
+template <int MT4>
+struct DwAcc {
+  v4f B0[2], B1[1], H0[2], H1[4], H2[1], F0[2], F1[4], F2[1], D0[1], D1[MT4], MX[MT4];
+};
+
+template <int N>
+__device__ __forceinline__ void zero_acc(v4f (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+}
+template <int N>
+__device__ __forceinline__ void store_acc(const v4f (&a)[N], float* slab, int off, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) *reinterpret_cast<v4f*>(slab + off + ((wave * N + i) * 64 + lane) * 4) = a[i];
+}
+
+template <bool SPEC, int MT4>
+__global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc pd, TPackDesc td,
+                                                           const float* __restrict__ wT, SlabLayout sl,
+                                                           float* __restrict__ slabs, int stage_off, int FSd) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  build_fwd_image(lds, pd);
+  float* const st = lds + stage_off;  // staging region
+  constexpr int NT = 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int row = wave * 16 + j;  // sample row of this lane inside the workgroup's 64-sample tile
+  const int tid = threadIdx.x;
+  DwAcc<MT4> A;
+  zero_acc(A.B0), zero_acc(A.B1), zero_acc(A.H0), zero_acc(A.H1), zero_acc(A.H2), zero_acc(A.F0), zero_acc(A.F1);
+  zero_acc(A.F2), zero_acc(A.D0), zero_acc(A.D1), zero_acc(A.MX);
+  float db[NLAYERS];
+#pragma unroll
+  for (int l = 0; l < NLAYERS; ++l) db[l] = 0.0f;
+  __syncthreads();
+  const int64_t ntiles = (io.n + 63) / 64;
+  const int C = io.C, B = io.B, TB = io.TB;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * 64;
+    int64_t n = n0 + row;
+    const bool ok = n < io.n;
+    if (!ok) n = io.n - 1;
+    // =================== forward recompute ======================================================
+    float encf[NT][8];
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv) {
+      const float2 v = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
+      encf[0][2 * lv] = v.x, encf[0][2 * lv + 1] = v.y;
+    }
+    v4f t4[NT][4];
+    float h[NT][16];
+    gemm_pack<4, 8, NT, true>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+    relu_to<4, NT>(h, t4);
+    v4f bo4[NT][1];
+    gemm_pack<1, 16, NT, true>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+    float in27[NT][7], dir28[NT][7];
+    {
+      float pe[3];
+      pe_slots(pe, io.wpos[3 * n], io.wpos[3 * n + 1], io.wpos[3 * n + 2], q);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) in27[0][3 + r] = bo4[0][0][r];
+      if (SPEC) {
+        float sh[4];
+        sh_slots(sh, io.dirs[3 * n], io.dirs[3 * n + 1], io.dirs[3 * n + 2], q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
+      }
+    }
+    float a1h[NT][16], a2h[NT][16], a1f[NT][16], a2f[NT][16];
+    v4f hd4[NT][1], fl4[NT][1];
+    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+    relu_to<4, NT>(a1h, t4);
+    gemm_pack<4, 16, NT, true>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+    relu_to<4, NT>(a2h, t4);
+    gemm_pack<1, 16, NT, true>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+    relu_to<4, NT>(a1f, t4);
+    gemm_pack<4, 16, NT, true>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+    relu_to<4, NT>(a2f, t4);
+    gemm_pack<1, 16, NT, true>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    HeadState<NT> hs;
+    head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
+    float hdir[NT][4];
+    if (SPEC) {
+      v4f d4[NT][1];
+      gemm_pack<1, 7, NT, true>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+      relu_to<1, NT>(hdir, d4);
+    }
+    // =================== phase A: band tiles (mixing + specular tail) ============================
+    float* const stZd = st;                  // [64][FSd]   dZ of mlp_directional's output layer
+    float* const stXh = st + 64 * FSd;       // [64][16]    hidden of mlp_directional
+    float* const stXm = stXh + 64 * 16;      // [64][16]    mixing coefficients m
+    v4f dm4[NT][1], dhd4[NT][1];
+    dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    float ds1 = 0.0f;
+    __syncthreads();  // previous tile's staging reads are done
+    for (int t = 0; t < TB; ++t) {
+      float dsp[NT][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int b = 16 * t + 4 * q + r;
+        dsp[0][r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
+      }
+      gemm_pack<1, 4, NT, false>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+      if (SPEC) {
+        v4f sc[NT][1];
+        gemm_pack<1, 4, NT, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+        float dzd[NT][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sp = sigmoidf_(sc[0][0][r]);
+          ds1 += dsp[0][r] * sp;
+          dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
+        }
+        gemm_pack<1, 4, NT, false>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
+        *reinterpret_cast<v4f*>(stZd + row * FSd + 16 * t + 4 * q) = v4f{dzd[0][0], dzd[0][1], dzd[0][2], dzd[0][3]};
+      }
+    }
+    if (SPEC) *reinterpret_cast<v4f*>(stXh + row * 16 + 4 * q) = v4f{hdir[0][0], hdir[0][1], hdir[0][2], hdir[0][3]};
+    *reinterpret_cast<v4f*>(stXm + row * 16 + 4 * q) = v4f{hs.m[0][0], hs.m[0][1], hs.m[0][2], hs.m[0][3]};
+    ds1 = xq_sum(ds1);
+    __syncthreads();
+    if (SPEC) {
+      dw_accum<MT4>(A.D1, stZd, FSd, stXh, 16, TB, 1, wave, lane);
+      if (tid < 16 * TB) db[L_D1] += col_sum64(stZd, FSd, tid);
+    }
+    {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: rows are samples)
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int64_t ns = n0 + 4 * ks + q;
+#pragma unroll
+        for (int idx = 0; idx < MT4; ++idx) {
+          const int to = idx * 4 + wave;
+          if (to < TB) {
+            const int b = 16 * to + j;
+            const float a = (ns < io.n && b < B) ? io.d_spectral[ns * B + b] : 0.0f;
+            A.MX[idx] = MFMA(a, stXm[(4 * ks + q) * 16 + j], A.MX[idx]);
+          }
+        }
+      }
+    }
+    // =================== phase B: heads ===========================================================
+    float dhs[NT][4], dfl[NT][4];
+    {
+      float da[4], dot = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dmr = dm4[0][0][r];
+        const float dsg = dmr * hs.ab[0][r];
+        dhs[0][r] = dsg * hs.sg[0][r] * (1.0f - hs.sg[0][r]);
+        da[r] = (4 * q + r < C) ? dmr * hs.sg[0][r] : 0.0f;
+        dot += hs.ab[0][r] * da[r];
+      }
+      dot = xq_sum(dot);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * q + r;
+        float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) / io.temperature : 0.0f;
+        if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
+        dfl[0][r] = g;
+        if (c >= C) dhs[0][r] = 0.0f;
+      }
+    }
+    float* const stZ = st;             // [64][<=80]
+    float* const stX = st + 64 * 80;   // [64][<=80]
+    if (SPEC) {  // mlp_directional hidden layer: dZ = d_hd * [hd > 0]; X = dir28 (staging order = reference order)
+      float dz[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
+      __syncthreads();
+      *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dz[0], dz[1], dz[2], dz[3]};
+      *reinterpret_cast<v4f*>(stX + row * 48 + 4 * q) = v4f{dir28[0][0], dir28[0][1], dir28[0][2], dir28[0][3]};
+#pragma unroll
+      for (int s = 0; s < 3; ++s) stX[row * 48 + 16 + 3 * q + s] = dir28[0][4 + s];
+      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      __syncthreads();
+      dw_accum<1>(A.D0, stZ, 16, stX, 48, 1, 2, wave, lane);
+      if (tid < 16) db[L_D0] += col_sum64(stZ, 16, tid);
+    }
+    v4f dbo4[NT][1];
+    dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    // one 27->64->64->out MLP (head or feature): dW for its three layers, dX down to the base-MLP slots
+    auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f(&acc2)[1],
+                        v4f(&acc1)[4], v4f(&acc0)[2], int l2, int l1, int l0, int t2, int t1, int t0) __attribute__((always_inline)) {
+      __syncthreads();
+      *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
+      stage_hid<4>(stX, 80, row, q, a2[0]);
+      __syncthreads();
+      dw_accum<1>(acc2, stZ, 16, stX, 80, 1, 4, wave, lane);
+      if (tid < 16) db[l2] += col_sum64(stZ, 16, tid);
+      v4f g4[NT][4];
+      gemm_pack<4, 4, NT, true>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
+      float dz1[NT][16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+      __syncthreads();
+      stage_hid<4>(stZ, 80, row, q, dz1[0]);
+      stage_hid<4>(stX, 80, row, q, a1[0]);
+      __syncthreads();
+      dw_accum<4>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
+      if (tid < 64) db[l1] += col_sum64(stZ, 80, tid);
+      gemm_pack<4, 16, NT, true>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
+      float dz0[NT][16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+      __syncthreads();
+      stage_hid<4>(stZ, 80, row, q, dz0[0]);
+      // X = [pe(12) | base-MLP output slots(16)] : 28 columns, 28..31 zero
+#pragma unroll
+      for (int s = 0; s < 3; ++s) stX[row * 48 + 3 * q + s] = in27[0][s];
+      *reinterpret_cast<v4f*>(stX + row * 48 + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
+      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      __syncthreads();
+      dw_accum<2>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
+      if (tid < 64) db[l0] += col_sum64(stZ, 80, tid);
+      gemm_pack<1, 16, NT, false>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
+    };
+    mlp3_bwd(dhs, a2h, a1h, A.H2, A.H1, A.H0, L_H2, L_H1, L_H0, T_H2, T_H1, T_H0);
+    mlp3_bwd(dfl, a2f, a1f, A.F2, A.F1, A.F0, L_F2, L_F1, L_F0, T_F2, T_F1, T_F0);
+    // =================== base MLP ====================================================================
+    float dzb1[NT][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float g = dbo4[0][0][r];
+      const int e = 4 * q + r - 1;
+      if (io.d_emb && ok && e >= 0) g += io.d_emb[n * 15 + e];
+      dzb1[0][r] = g;
+    }
+    if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
+      const float raw = bo4[0][0][0];
+      dzb1[0][0] = ok ? io.d_sigma[n] * io.sel[n] * expf(fminf(fmaxf(raw, -15.0f), 15.0f)) : 0.0f;
+    }
+    __syncthreads();
+    *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzb1[0][0], dzb1[0][1], dzb1[0][2], dzb1[0][3]};
+    stage_hid<4>(stX, 80, row, q, h[0]);
+    __syncthreads();
+    dw_accum<1>(A.B1, stZ, 16, stX, 80, 1, 4, wave, lane);
+    if (tid < 16) db[L_B1] += col_sum64(stZ, 16, tid);
+    v4f g4[NT][4];
+    gemm_pack<4, 4, NT, true>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
+    float dzb0[NT][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+    __syncthreads();
+    stage_hid<4>(stZ, 80, row, q, dzb0[0]);
+    *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q) = v4f{encf[0][0], encf[0][1], encf[0][2], encf[0][3]};
+    *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q + 4) = v4f{encf[0][4], encf[0][5], encf[0][6], encf[0][7]};
+    __syncthreads();
+    dw_accum<2>(A.B0, stZ, 80, stX, 48, 4, 2, wave, lane);
+    if (tid < 64) db[L_B0] += col_sum64(stZ, 80, tid);
+    v4f de4[NT][2];
+    gemm_pack<2, 16, NT, true>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
+    if (ok && io.d_enc) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int lv = 8 * t + 2 * q + rr;  // feature e = 16t+4q+r -> level e>>1, component e&1
+          *reinterpret_cast<float2*>(io.d_enc + n * io.sn + (int64_t)lv * io.sl) =
+              make_float2(de4[0][t][2 * rr], de4[0][t][2 * rr + 1]);
+        }
+    }
+  }
+  // =================== partial slabs ==================================================================
+  float* const slab = slabs + (size_t)blockIdx.x * sl.total;
+  store_acc(A.B0, slab, sl.off[L_B0], wave, lane), store_acc(A.B1, slab, sl.off[L_B1], wave, lane);
+  store_acc(A.H0, slab, sl.off[L_H0], wave, lane), store_acc(A.H1, slab, sl.off[L_H1], wave, lane);
+  store_acc(A.H2, slab, sl.off[L_H2], wave, lane), store_acc(A.F0, slab, sl.off[L_F0], wave, lane);
+  store_acc(A.F1, slab, sl.off[L_F1], wave, lane), store_acc(A.F2, slab, sl.off[L_F2], wave, lane);
+  store_acc(A.D0, slab, sl.off[L_D0], wave, lane), store_acc(A.D1, slab, sl.off[L_D1], wave, lane);
+  store_acc(A.MX, slab, sl.off[L_MX], wave, lane);
+#pragma unroll
+  for (int l = 0; l < NLAYERS; ++l)
+    if (l != L_MX && tid < 16 * pd.L[l].OT) slab[sl.off_db[l] + tid] = db[l];
+}
+
+// ---- sum the per-workgroup slabs and scatter into the reference-layout gradient tensors ------------
+struct GradPtrs {
+  float* W[NLAYERS];
+  float* b[NLAYERS];
+};
+
+__device__ __forceinline__ int stage_col_to_in(int kind, int col) {
+  if (kind == IN_27) return col < 12 ? col : (col >= 13 && col < 28 ? col - 1 : -1);
+  if (kind == IN_DIR28) return col < 28 ? col : -1;
+  return col;
+}
+
+__global__ __launch_bounds__(256) void field_reduce_kernel(const float* __restrict__ slabs, int nslabs, SlabLayout sl,
+                                                           PackDesc pd, GradPtrs gp) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= sl.total) return;
+  float s = 0.0f;
+  for (int w = 0; w < nslabs; ++w) s += slabs[(size_t)w * sl.total + idx];
+  // which entry is this?
+  for (int l = 0; l < NLAYERS; ++l) {
+    const LayerDesc& L = pd.L[l];
+    const int nw = 4 * sl.nacc[l] * 256;
+    if (idx >= sl.off[l] && idx < sl.off[l] + nw) {
+      const int rel = idx - sl.off[l];
+      const int r = rel & 3, ln = (rel >> 2) & 63, blk = rel >> 8;
+      const int wave = blk / sl.nacc[l], i = blk % sl.nacc[l];
+      const int p = i * 4 + wave;
+      if (p >= sl.TO[l] * sl.TI[l]) return;
+      const int to = p / sl.TI[l], ti = p % sl.TI[l];
+      const int out = 16 * to + 4 * (ln >> 4) + r, col = 16 * ti + (ln & 15);
+      if (l == L_MX) {  // slab holds dE^T[b][c]
+        if (out < L.OUT && col < L.IN && gp.W[l]) gp.W[l][(size_t)col * L.OUT + out] = s;
+        return;
+      }
+      const int in = stage_col_to_in(L.kind, col);
+      if (out < L.OUT && in >= 0 && in < L.IN && gp.W[l]) gp.W[l][(size_t)out * L.IN + in] = s;
+      return;
+    }
+    if (l != L_MX && idx >= sl.off_db[l] && idx < sl.off_db[l] + 16 * L.OT) {
+      const int o = idx - sl.off_db[l];
+      if (o < L.OUT && gp.b[l]) gp.b[l][o] = s;
+      return;
+    }
+  }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static int round16(int x) { return (x + 15) & ~15; }
+
+static int build_pack_desc(const umhs_field_cfg* cfg, const umhs_field_params* p, PackDesc* pd, int* TB_out) {
+  const int B = cfg->n_bands, C = cfg->n_classes, spec = cfg->pred_specular != 0, dens = cfg->density_only != 0;
+  const int TB = dens ? 0 : (B + 15) / 16;
+  *TB_out = TB;
+  auto set = [&](int l, const float* W, const float* b, int kind, int KS, int OT, int OUT, int IN) {
+    pd->L[l].W = W, pd->L[l].b = b, pd->L[l].kind = kind, pd->L[l].KS = KS, pd->L[l].OT = OT, pd->L[l].OUT = OUT,
+    pd->L[l].IN = IN;
+  };
+  set(L_B0, p->base_w0, p->base_b0, IN_ENC, 8, 4, 64, 32);
+  set(L_B1, p->base_w1, p->base_b1, IN_HID64, 16, 1, 16, 64);
+  const int h = dens ? 0 : 1;
+  set(L_H0, p->head_w0, p->head_b0, IN_27, 7, 4 * h, 64, 27);
+  set(L_H1, p->head_w1, p->head_b1, IN_HID64, 16, 4 * h, 64, 64);
+  set(L_H2, p->head_w2, p->head_b2, IN_HID64, 16, 1 * h, C, 64);
+  set(L_F0, p->feat_w0, p->feat_b0, IN_27, 7, 4 * h, 64, 27);
+  set(L_F1, p->feat_w1, p->feat_b1, IN_HID64, 16, 4 * h, 64, 64);
+  set(L_F2, p->feat_w2, p->feat_b2, IN_HID64, 16, 1 * h, spec ? C + 1 : C, 64);
+  const int d = (!dens && spec) ? 1 : 0;
+  set(L_D0, p->dir_w0, p->dir_b0, IN_DIR28, 7, 1 * d, 16, 28);
+  set(L_D1, p->dir_w1, p->dir_b1, IN_HID16, 4, TB * d, B, 16);
+  set(L_MX, p->endmembers, nullptr, IN_MIX, 4, TB * h, B, C);  // "W" = E [C][B]: OUT = B, IN = C
+  int off = 0;
+  for (int l = 0; l < NLAYERS; ++l) {
+    pd->L[l].off_w = off;
+    off += pd->L[l].OT * ((pd->L[l].KS + 3) / 4) * 256;
+  }
+  pd->total_w = off;
+  for (int l = 0; l < NLAYERS; ++l) {
+    pd->L[l].off_b = off;
+    if (l != L_MX) off += 16 * pd->L[l].OT;
+  }
+  pd->total = off;
+  // pointers required for the layers in use
+  for (int l = 0; l < NLAYERS; ++l)
+    if (pd->L[l].OT > 0 && (!pd->L[l].W || (l != L_MX && !pd->L[l].b))) return UMHS_ERR_ARG;
+  return UMHS_OK;
+}
+
+static int check_cfg(const umhs_field_cfg* cfg) {
+  if (!cfg) return UMHS_ERR_ARG;
+  if (cfg->density_only) return UMHS_OK;
+  if (cfg->n_bands < 1 || cfg->n_classes < 1 || !(cfg->temperature > 0.0f)) return UMHS_ERR_ARG;
+  if (cfg->n_classes > 15 || cfg->n_bands > 256) return UMHS_ERR_UNSUPPORTED;
+  return UMHS_OK;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return UMHS_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+      hipSuccess)
+    return UMHS_ERR_LAUNCH;
+  return UMHS_OK;
+}
+
+extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
+                              int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
+                              const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
+                              float* spectral, float* spectral2, float* specular, float* abundances,
+                              umhs_stream_t stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!params || !enc || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
+  if ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;
+  const bool dens = cfg->density_only != 0, spec = cfg->pred_specular != 0;
+  if (!dens && (!world_pos || !spectral || (spec && !directions))) return UMHS_ERR_ARG;
+  if (n == 0) return UMHS_OK;
+  PackDesc pd;
+  int TB;
+  rc = build_pack_desc(cfg, params, &pd, &TB);
+  if (rc) return rc;
+  FieldIO io = {};
+  io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
+  io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
+  io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
+  io.specular = specular, io.abund = abundances;
+  const size_t lds_bytes = (size_t)pd.total * 4;
+  const int64_t ntiles = (n + 127) / 128;
+  const int blocks_per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
+  const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
+#define LAUNCH_FWD(S, D)                                                                                       \
+  do {                                                                                                         \
+    rc = set_lds(field_fwd_kernel<S, D>, lds_bytes);                                                           \
+    if (rc) return rc;                                                                                         \
+    hipLaunchKernelGGL((field_fwd_kernel<S, D>), dim3(grid), dim3(256), lds_bytes, umhs_s(stream), io, pd);     \
+  } while (0)
+  if (dens)
+    LAUNCH_FWD(false, true);
+  else if (spec)
+    LAUNCH_FWD(true, false);
+  else
+    LAUNCH_FWD(false, false);
+#undef LAUNCH_FWD
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+static void build_bwd_layouts(const umhs_field_cfg* cfg, const umhs_field_params* p, const PackDesc& pd, int TB,
+                              TPackDesc* td, SlabLayout* sl, int* MT4, int* FSd, int* stage_floats) {
+  const int B = cfg->n_bands, C = cfg->n_classes, spec = cfg->pred_specular != 0;
+  auto sett = [&](int l, const float* W, int OUT, int IN, int KS, int OT, int rowmap) {
+    td->L[l].W = W, td->L[l].OUT = OUT, td->L[l].IN = IN, td->L[l].KS = KS, td->L[l].OT = OT, td->L[l].rowmap = rowmap;
+  };
+  sett(T_B1, p->base_w1, 16, 64, 4, 4, 0);
+  sett(T_B0, p->base_w0, 64, 32, 16, 2, 0);
+  sett(T_H2, p->head_w2, C, 64, 4, 4, 0);
+  sett(T_H1, p->head_w1, 64, 64, 16, 4, 0);
+  sett(T_H0, p->head_w0, 64, 27, 16, 1, 1);
+  sett(T_F2, p->feat_w2, spec ? C + 1 : C, 64, 4, 4, 0);
+  sett(T_F1, p->feat_w1, 64, 64, 16, 4, 0);
+  sett(T_F0, p->feat_w0, 64, 27, 16, 1, 1);
+  sett(T_D1, p->dir_w1, B, 16, 4 * TB, spec ? 1 : 0, 0);
+  sett(T_MX, p->endmembers, C, B, 4 * TB, 1, 2);  // E [C][B]
+  int off = 0;
+  for (int l = 0; l < NTLAYERS; ++l) {
+    td->L[l].off = off;
+    off += td->L[l].OT * ((td->L[l].KS + 3) / 4) * 256;
+  }
+  td->total = off;
+  *MT4 = (TB + 3) / 4;
+  const int TOs[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1, 1, TB, TB};
+  const int TIs[NLAYERS] = {2, 4, 2, 4, 4, 2, 4, 4, 2, 1, 1};
+  const int naccs[NLAYERS] = {2, 1, 2, 4, 1, 2, 4, 1, 1, *MT4, *MT4};
+  off = 0;
+  for (int l = 0; l < NLAYERS; ++l) {
+    sl->TO[l] = TOs[l], sl->TI[l] = TIs[l], sl->nacc[l] = naccs[l], sl->off[l] = off;
+    off += 4 * naccs[l] * 256;
+  }
+  for (int l = 0; l < NLAYERS; ++l) {
+    sl->off_db[l] = off;
+    if (l != L_MX) off += 16 * pd.L[l].OT;
+  }
+  sl->total = (off + 3) & ~3;
+  *FSd = (TB & 1) ? 16 * TB : 16 * TB + 16;
+  const int tail = 64 * (*FSd) + 2 * 64 * 16;
+  *stage_floats = tail > 2 * 64 * 80 ? tail : 2 * 64 * 80;
+}
+
+static unsigned bwd_grid(int64_t n) {
+  const int64_t ntiles = (n + 63) / 64;
+  return (unsigned)(ntiles < 256 ? ntiles : 256);
+}
+
+extern "C" size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int64_t n) {
+  if (check_cfg(cfg) || cfg->density_only || n <= 0) return 0;
+  umhs_field_params dummy = {};
+  PackDesc pd;
+  int TB;
+  const float one = 0.0f;
+  const float** pp = reinterpret_cast<const float**>(&dummy);
+  for (size_t i = 0; i < sizeof(dummy) / sizeof(float*); ++i) pp[i] = &one;  // layout only, never dereferenced
+  if (build_pack_desc(cfg, &dummy, &pd, &TB)) return 0;
+  TPackDesc td;
+  SlabLayout sl;
+  int MT4, FSd, stage;
+  build_bwd_layouts(cfg, &dummy, pd, TB, &td, &sl, &MT4, &FSd, &stage);
+  return ((size_t)td.total + (size_t)bwd_grid(n) * sl.total) * 4 + 256;
+}
+
+extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
+                              int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
+                              const float* selector, int64_t n, const float* d_sigma, const float* d_spectral,
+                              const float* d_emb_ext, float* d_enc, const umhs_field_grads* grads, void* workspace,
+                              size_t workspace_bytes, umhs_stream_t stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
+  if (!params || !enc || !selector || !world_pos || !d_sigma || !d_spectral || !grads || n < 0) return UMHS_ERR_ARG;
+  const bool spec = cfg->pred_specular != 0;
+  if (spec && !directions) return UMHS_ERR_ARG;
+  if ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7) || ((uintptr_t)d_enc & 7)) return UMHS_ERR_ARG;
+  if (n == 0) return UMHS_OK;
+  PackDesc pd;
+  int TB;
+  rc = build_pack_desc(cfg, params, &pd, &TB);
+  if (rc) return rc;
+  TPackDesc td;
+  SlabLayout sl;
+  int MT4, FSd, stage_floats;
+  build_bwd_layouts(cfg, params, pd, TB, &td, &sl, &MT4, &FSd, &stage_floats);
+  if (MT4 > 3) return UMHS_ERR_UNSUPPORTED;  // n_bands <= 192 in the backward
+  const unsigned grid = bwd_grid(n);
+  const size_t need = ((size_t)td.total + (size_t)grid * sl.total) * 4 + 256;
+  if (!workspace || workspace_bytes < need) return UMHS_ERR_WORKSPACE;
+  float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float* slabs = wT + td.total;
+  hipLaunchKernelGGL(field_pack_T_kernel, dim3((td.total + 255) / 256), dim3(256), 0, umhs_s(stream), td, wT);
+  UMHS_CHECK_LAUNCH();
+  FieldIO io = {};
+  io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
+  io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
+  io.d_sigma = d_sigma, io.d_spectral = d_spectral, io.d_emb = d_emb_ext, io.d_enc = d_enc;
+  const int stage_off = (pd.total + 3) & ~3;
+  const size_t lds_bytes = (size_t)(stage_off + stage_floats) * 4;
+#define LAUNCH_BWD(S, M)                                                                                      \
+  do {                                                                                                        \
+    rc = set_lds(field_bwd_kernel<S, M>, lds_bytes);                                                          \
+    if (rc) return rc;                                                                                        \
+    hipLaunchKernelGGL((field_bwd_kernel<S, M>), dim3(grid), dim3(256), lds_bytes, umhs_s(stream), io, pd, td, \
+                       (const float*)wT, sl, slabs, stage_off, FSd);                                          \
+  } while (0)
+  if (spec) {
+    if (MT4 == 1) LAUNCH_BWD(true, 1);
+    else if (MT4 == 2) LAUNCH_BWD(true, 2);
+    else LAUNCH_BWD(true, 3);
+  } else {
+    if (MT4 == 1) LAUNCH_BWD(false, 1);
+    else if (MT4 == 2) LAUNCH_BWD(false, 2);
+    else LAUNCH_BWD(false, 3);
+  }
+#undef LAUNCH_BWD
+  UMHS_CHECK_LAUNCH();
+  GradPtrs gp;
+  float* const gw[NLAYERS] = {grads->base_w0, grads->base_w1, grads->head_w0, grads->head_w1, grads->head_w2,
+                              grads->feat_w0, grads->feat_w1, grads->feat_w2, grads->dir_w0,  grads->dir_w1,
+                              grads->endmembers};
+  float* const gb[NLAYERS] = {grads->base_b0, grads->base_b1, grads->head_b0, grads->head_b1, grads->head_b2,
+                              grads->feat_b0, grads->feat_b1, grads->feat_b2, grads->dir_b0,  grads->dir_b1,
+                              nullptr};
+  for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
+  hipLaunchKernelGGL(field_reduce_kernel, dim3((sl.total + 255) / 256), dim3(256), 0, umhs_s(stream),
+                     (const float*)slabs, (int)grid, sl, pd, gp);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}

@@ -1,0 +1,590 @@
+// gfx950 kernels for the memory-bound rows of the UMHS hot path: sample positions (R1 prefix),
+// multires hash-grid encode fwd/bwd (R2), packed transmittance + per-ray band accumulation fwd/bwd
+// (R11-R13), spectrum->sRGB fwd/bwd (R14) and the fused Adam step.  The MFMA field kernels live in
+// umhs_field.hip.  Reference citations are in include/umhs_hip.h.
+#include "umhs_common.h"
+
+// =============================================================================================
+// R1 prefix: positions
+// =============================================================================================
+__global__ __launch_bounds__(256) void positions_kernel(const float* __restrict__ origins,
+                                                        const float* __restrict__ directions,
+                                                        const float* __restrict__ starts,
+                                                        const float* __restrict__ ends,
+                                                        const float* __restrict__ world_in, int64_t n,
+                                                        int contraction, float ax, float ay, float az, float bx,
+                                                        float by, float bz, float* __restrict__ world_out,
+                                                        float* __restrict__ pos01, float* __restrict__ selector) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float p[3];
+  if (world_in) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = world_in[3 * i + c];
+  } else {
+    float t = starts[i] + ends[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = origins[3 * i + c] + directions[3 * i + c] * t / 2.0f;
+  }
+  if (world_out) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) world_out[3 * i + c] = p[c];
+  }
+  float q[3];
+  if (contraction) {
+    float mag = fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2])));
+    if (mag < 1.0f) {
+      q[0] = p[0], q[1] = p[1], q[2] = p[2];
+    } else {
+      float sc = 2.0f - (1.0f / mag);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) q[c] = sc * (p[c] / mag);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = (q[c] + 2.0f) / 4.0f;
+  } else {
+    q[0] = (p[0] - ax) / (bx - ax);
+    q[1] = (p[1] - ay) / (by - ay);
+    q[2] = (p[2] - az) / (bz - az);
+  }
+  bool sel = q[0] > 0.0f && q[0] < 1.0f && q[1] > 0.0f && q[1] < 1.0f && q[2] > 0.0f && q[2] < 1.0f;
+  float sf = sel ? 1.0f : 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pos01[3 * i + c] = q[c] * sf;
+  if (selector) selector[i] = sf;
+}
+
+extern "C" int umhs_positions_fwd(const float* origins, const float* directions, const float* starts,
+                                  const float* ends, const float* world_pos_in, int64_t n, int contraction,
+                                  const float* aabb, float* world_pos_out, float* pos01_out, float* selector_out,
+                                  umhs_stream_t stream) {
+  if (n < 0 || !pos01_out) return UMHS_ERR_ARG;
+  if (!world_pos_in && (!origins || !directions || !starts || !ends)) return UMHS_ERR_ARG;
+  if (!contraction && !aabb) return UMHS_ERR_ARG;
+  if (n == 0) return UMHS_OK;
+  float a[6] = {-1, -1, -1, 1, 1, 1};
+  if (aabb)
+    for (int i = 0; i < 6; ++i) a[i] = aabb[i];
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipLaunchKernelGGL(positions_kernel, grid, dim3(256), 0, umhs_s(stream), origins, directions, starts, ends,
+                     world_pos_in, n, contraction, a[0], a[1], a[2], a[3], a[4], a[5], world_pos_out, pos01_out,
+                     selector_out);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
+// R2: multires hash grid.  One thread per (sample, level); grid.y = level, so blocks are dispatched
+// level-major and the resident waves of an XCD gather from one 4 MiB level slab (= one XCD L2) at
+// a time instead of from the whole 64 MiB table.
+// =============================================================================================
+#define HASH_P1 2654435761u
+#define HASH_P2 805459861u
+
+struct HashCorners {
+  uint32_t idx[8];
+  float ox, oy, oz;
+};
+
+__device__ __forceinline__ HashCorners hash_corners(float px, float py, float pz, float s, uint32_t mask,
+                                                    uint32_t base) {
+  float sx = px * s, sy = py * s, sz = pz * s;
+  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  uint32_t xf = (uint32_t)(int)fx, yf = (uint32_t)(int)fy * HASH_P1, zf = (uint32_t)(int)fz * HASH_P2;
+  uint32_t xc = (uint32_t)(int)ceilf(sx), yc = (uint32_t)(int)ceilf(sy) * HASH_P1,
+           zc = (uint32_t)(int)ceilf(sz) * HASH_P2;
+  HashCorners h;
+  h.ox = sx - fx, h.oy = sy - fy, h.oz = sz - fz;
+  // corner order of nerfstudio HashEncoding.pytorch_fwd: 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
+  h.idx[0] = ((xc ^ yc ^ zc) & mask) + base;
+  h.idx[1] = ((xc ^ yf ^ zc) & mask) + base;
+  h.idx[2] = ((xf ^ yf ^ zc) & mask) + base;
+  h.idx[3] = ((xf ^ yc ^ zc) & mask) + base;
+  h.idx[4] = ((xc ^ yc ^ zf) & mask) + base;
+  h.idx[5] = ((xc ^ yf ^ zf) & mask) + base;
+  h.idx[6] = ((xf ^ yf ^ zf) & mask) + base;
+  h.idx[7] = ((xf ^ yc ^ zf) & mask) + base;
+  return h;
+}
+
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restrict__ pos01,
+                                                           const float2* __restrict__ table,
+                                                           const float* __restrict__ scalings, int64_t n,
+                                                           int log2_T, float* __restrict__ enc, int64_t stride_n,
+                                                           int64_t stride_l) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int l = blockIdx.y;
+  float s = scalings[l];
+  HashCorners h = hash_corners(pos01[3 * i], pos01[3 * i + 1], pos01[3 * i + 2], s, (1u << log2_T) - 1u,
+                               (uint32_t)l << log2_T);
+  float2 f[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) f[c] = table[h.idx[c]];
+  float ox = h.ox, oy = h.oy, oz = h.oz, rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
+  float out[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float f0 = k ? f[0].y : f[0].x, f1 = k ? f[1].y : f[1].x, f2 = k ? f[2].y : f[2].x, f3 = k ? f[3].y : f[3].x;
+    float f4 = k ? f[4].y : f[4].x, f5 = k ? f[5].y : f[5].x, f6 = k ? f[6].y : f[6].x, f7 = k ? f[7].y : f[7].x;
+    float f03 = f0 * ox + f3 * rx, f12 = f1 * ox + f2 * rx, f56 = f5 * ox + f6 * rx, f47 = f4 * ox + f7 * rx;
+    float f0312 = f03 * oy + f12 * ry, f4756 = f47 * oy + f56 * ry;
+    out[k] = f0312 * oz + f4756 * rz;
+  }
+  float* o = enc + i * stride_n + (int64_t)l * stride_l;
+  if (((stride_n | stride_l) & 1) == 0) {
+    *reinterpret_cast<float2*>(o) = make_float2(out[0], out[1]);
+  } else {
+    o[0] = out[0], o[1] = out[1];
+  }
+}
+
+extern "C" int umhs_hashgrid_fwd(const float* pos01, const float* table, const float* scalings, int64_t n,
+                                 int n_levels, int log2_T, float* enc, int64_t stride_n, int64_t stride_l,
+                                 umhs_stream_t stream) {
+  if (n < 0 || !pos01 || !table || !scalings || !enc) return UMHS_ERR_ARG;
+  if (n_levels < 1 || n_levels > 32 || log2_T < 1 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (((uintptr_t)table & 7) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;
+  if (n == 0) return UMHS_OK;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
+  hipLaunchKernelGGL(hashgrid_fwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01,
+                     reinterpret_cast<const float2*>(table), scalings, n, log2_T, enc, stride_n, stride_l);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// Backward v1: memory-side float atomics, one (sample, level) per thread, level-major grid.
+__global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restrict__ pos01,
+                                                           const float* __restrict__ d_enc, int64_t stride_n,
+                                                           int64_t stride_l, const float* __restrict__ scalings,
+                                                           int64_t n, int log2_T, float* __restrict__ d_table) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int l = blockIdx.y;
+  const float* g = d_enc + i * stride_n + (int64_t)l * stride_l;
+  float g0 = g[0], g1 = g[1];
+  if (g0 == 0.0f && g1 == 0.0f) return;  // masked / zero-weight samples contribute exact zeros
+  HashCorners h = hash_corners(pos01[3 * i], pos01[3 * i + 1], pos01[3 * i + 2], scalings[l],
+                               (1u << log2_T) - 1u, (uint32_t)l << log2_T);
+  float ox = h.ox, oy = h.oy, oz = h.oz, rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
+  float w[8];
+  w[0] = ox * oy * oz, w[3] = rx * oy * oz, w[1] = ox * ry * oz, w[2] = rx * ry * oz;
+  w[4] = ox * oy * rz, w[7] = rx * oy * rz, w[5] = ox * ry * rz, w[6] = rx * ry * rz;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (w[c] != 0.0f) {
+      atomicAdd(d_table + 2 * (size_t)h.idx[c], w[c] * g0);
+      atomicAdd(d_table + 2 * (size_t)h.idx[c] + 1, w[c] * g1);
+    }
+  }
+}
+
+extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
+                                 const float* scalings, int64_t n, int n_levels, int log2_T, float* d_table,
+                                 umhs_stream_t stream) {
+  if (n < 0 || !pos01 || !d_enc || !scalings || !d_table) return UMHS_ERR_ARG;
+  if (n_levels < 1 || n_levels > 32 || log2_T < 1 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (n == 0) return UMHS_OK;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
+  hipLaunchKernelGGL(hashgrid_bwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01, d_enc, stride_n, stride_l,
+                     scalings, n, log2_T, d_table);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
+// R11: pack_info  (ray_indices sorted ascending -> (start, count) per ray, by binary search)
+// =============================================================================================
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void pack_info_kernel(const int64_t* __restrict__ ray_indices, int64_t n,
+                                                        int64_t n_rays, int64_t* __restrict__ packed) {
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rays) return;
+  int64_t s = lower_bound_i64(ray_indices, n, r);
+  int64_t e = lower_bound_i64(ray_indices, n, r + 1);
+  packed[2 * r] = s;
+  packed[2 * r + 1] = e - s;
+}
+
+extern "C" int umhs_pack_info(const int64_t* ray_indices, int64_t n, int64_t n_rays, int64_t* packed_info,
+                              umhs_stream_t stream) {
+  if (n < 0 || n_rays < 0 || !packed_info || (n > 0 && !ray_indices)) return UMHS_ERR_ARG;
+  if (n_rays == 0) return UMHS_OK;
+  hipLaunchKernelGGL(pack_info_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, umhs_s(stream),
+                     ray_indices, n, n_rays, packed_info);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
+// R11-R13: compositing.  One wavefront per ray; lane = sample for the transmittance scan (64-lane
+// shuffle prefix sum with a carry across 64-sample chunks), then lane = band for the accumulation so
+// every [N,K] row is read as one coalesced run.  Accumulation order is the sample order: results are
+// bitwise reproducible (the reference's index_add_ is not).
+// =============================================================================================
+struct CompStreams {
+  int n;
+  int k[UMHS_MAX_STREAMS];
+  const float* v[UMHS_MAX_STREAMS];
+  float* out[UMHS_MAX_STREAMS];
+};
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sigma,
+                                                            const float* __restrict__ t0,
+                                                            const float* __restrict__ t1,
+                                                            const int64_t* __restrict__ pinfo, int64_t n_rays,
+                                                            CompStreams st, float* __restrict__ weights,
+                                                            float* __restrict__ acc_out,
+                                                            float* __restrict__ depth_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (r >= n_rays) return;
+  const int64_t start = pinfo[2 * r];
+  const int cnt = (int)pinfo[2 * r + 1];
+  float carry = 0.0f, acc = 0.0f, dnum = 0.0f;
+  for (int base = 0; base < cnt || base == 0; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < cnt;
+    const int64_t nidx = start + i;
+    float a = 0.0f, b = 0.0f, x = 0.0f;
+    if (valid) {
+      a = t0[nidx], b = t1[nidx];
+      x = sigma[nidx] * (b - a);
+    }
+    float incl = wave_inclusive_scan(x, lane);
+    float T = expf(-(carry + (incl - x)));
+    float alpha = 1.0f - expf(-x);
+    float w = valid ? alpha * T : 0.0f;
+    if (valid) weights[nidx] = w;
+    acc += w;
+    dnum += w * ((a + b) / 2.0f);
+    carry += __shfl(incl, 63, 64);
+    const int nvalid = min(64, cnt - base);
+    for (int s = 0; s < st.n; ++s) {
+      const int K = st.k[s];
+      const float* __restrict__ v = st.v[s] + (start + base) * (int64_t)K;
+      for (int kc = 0; kc < K; kc += 64) {
+        const int k = kc + lane;
+        const bool kv = k < K;
+        float p0 = 0.0f, p1 = 0.0f;
+        int j = 0;
+        for (; j + 1 < nvalid; j += 2) {
+          float w0 = __shfl(w, j, 64), w1 = __shfl(w, j + 1, 64);
+          float v0 = kv ? v[(int64_t)j * K + k] : 0.0f;
+          float v1 = kv ? v[(int64_t)(j + 1) * K + k] : 0.0f;
+          p0 += w0 * v0;
+          p1 += w1 * v1;
+        }
+        if (j < nvalid) p0 += __shfl(w, j, 64) * (kv ? v[(int64_t)j * K + k] : 0.0f);
+        if (kv) {
+          float* o = st.out[s] + r * K + k;
+          *o = (base == 0) ? (p0 + p1) : (*o + (p0 + p1));
+        }
+      }
+    }
+    if (cnt == 0) break;
+  }
+  acc = wave_reduce_sum(acc);
+  dnum = wave_reduce_sum(dnum);
+  if (lane == 0) {
+    if (acc_out) acc_out[r] = acc;
+    if (depth_out) depth_out[r] = dnum / (acc + 1e-10f);
+  }
+}
+
+extern "C" int umhs_composite_fwd(const float* sigma, const float* t_starts, const float* t_ends,
+                                  const int64_t* packed_info, int64_t n_rays, int64_t n,
+                                  const umhs_value_streams* streams, float* weights, float* accumulation,
+                                  float* depth, umhs_stream_t stream) {
+  if (n_rays < 0 || n < 0 || !packed_info || !weights) return UMHS_ERR_ARG;
+  if (n > 0 && (!sigma || !t_starts || !t_ends)) return UMHS_ERR_ARG;
+  CompStreams st;
+  st.n = streams ? streams->n_streams : 0;
+  if (st.n < 0 || st.n > UMHS_MAX_STREAMS) return UMHS_ERR_ARG;
+  for (int s = 0; s < UMHS_MAX_STREAMS; ++s) {
+    st.k[s] = 0, st.v[s] = nullptr, st.out[s] = nullptr;
+    if (s < st.n) {
+      st.k[s] = streams->k[s], st.v[s] = streams->values[s], st.out[s] = streams->out[s];
+      if (st.k[s] < 1 || !st.out[s] || (n > 0 && !st.v[s])) return UMHS_ERR_ARG;
+    }
+  }
+  if (n_rays == 0) return UMHS_OK;
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), sigma,
+                     t_starts, t_ends, packed_info, n_rays, st, weights, accumulation, depth);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+struct CompGrads {
+  int n;
+  int k[UMHS_MAX_STREAMS];
+  const float* v[UMHS_MAX_STREAMS];
+  const float* dout[UMHS_MAX_STREAMS];
+  float* dv[UMHS_MAX_STREAMS];
+};
+
+// w_n = alpha_n T_n,  alpha = 1-exp(-x_n),  T_n = exp(-X_n),  X_n = sum_{m<n} x_m,  x = sigma*delta
+//   dL/dx_n = dw_n * T_n * exp(-x_n)  -  sum_{m>n} dw_m w_m
+// pass 1 walks the ray forward and parks exp(-(X_n + x_n)) in d_sigma[n]; pass 2 walks it backward with a
+// suffix scan of dw*w.  The lane<->sample mapping is identical in both passes (same-thread RAW only).
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ sigma,
+                                                            const float* __restrict__ t0,
+                                                            const float* __restrict__ t1,
+                                                            const int64_t* __restrict__ pinfo, int64_t n_rays,
+                                                            const float* __restrict__ weights, CompGrads gr,
+                                                            const float* __restrict__ d_acc, int grad_scaling,
+                                                            float* __restrict__ d_sigma) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (r >= n_rays) return;
+  const int64_t start = pinfo[2 * r];
+  const int cnt = (int)pinfo[2 * r + 1];
+  if (cnt == 0) return;
+  const int nchunks = (cnt + 63) >> 6;
+  float carry = 0.0f;
+  for (int c = 0; c < nchunks; ++c) {
+    const int i = c * 64 + lane;
+    const bool valid = i < cnt;
+    const int64_t nidx = start + i;
+    float x = valid ? sigma[nidx] * (t1[nidx] - t0[nidx]) : 0.0f;
+    float incl = wave_inclusive_scan(x, lane);
+    if (valid) d_sigma[nidx] = expf(-(carry + incl));
+    carry += __shfl(incl, 63, 64);
+  }
+  const float dacc = d_acc ? d_acc[r] : 0.0f;
+  float carry_after = 0.0f;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int i = c * 64 + lane;
+    const bool valid = i < cnt;
+    const int64_t nidx = start + i;
+    float dw = 0.0f, w = 0.0f, delta = 0.0f, scale = 1.0f, tnext = 0.0f;
+    if (valid) {
+      float a = t0[nidx], b = t1[nidx];
+      delta = b - a;
+      if (grad_scaling) {
+        float m = (a + b) / 2.0f;
+        scale = fminf(fmaxf(m * m, 0.0f), 1.0f);
+      }
+      w = weights[nidx];
+      tnext = d_sigma[nidx];
+      dw = dacc;
+      for (int s = 0; s < gr.n; ++s) {
+        const int K = gr.k[s];
+        const float* __restrict__ vrow = gr.v[s] + nidx * (int64_t)K;
+        const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
+        float d0 = 0.0f, d1 = 0.0f;
+        int k = 0;
+        for (; k + 1 < K; k += 2) {
+          d0 += drow[k] * vrow[k];
+          d1 += drow[k + 1] * vrow[k + 1];
+        }
+        if (k < K) d0 += drow[k] * vrow[k];
+        dw += d0 + d1;
+      }
+    }
+    float p = dw * w;
+    float suf = wave_inclusive_scan_rev(p, lane);
+    float S = carry_after + (suf - p);
+    if (valid) d_sigma[nidx] = (dw * tnext - S) * delta * scale;
+    carry_after += __shfl(suf, 0, 64);
+    // d_values[n][k] = scale_n * w_n * d_out[r][k]   (lane = band: coalesced row stores)
+    const float ws = w * scale;
+    const int nvalid = min(64, cnt - c * 64);
+    for (int s = 0; s < gr.n; ++s) {
+      if (!gr.dv[s]) continue;
+      const int K = gr.k[s];
+      float* __restrict__ dv = gr.dv[s] + (start + c * 64) * (int64_t)K;
+      const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
+      for (int kc = 0; kc < K; kc += 64) {
+        const int k = kc + lane;
+        const bool kv = k < K;
+        const float d = kv ? drow[k] : 0.0f;
+        for (int j = 0; j < nvalid; ++j) {
+          const float wj = __shfl(ws, j, 64);  // all lanes take part in the shuffle
+          if (kv) dv[(int64_t)j * K + k] = wj * d;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int umhs_composite_bwd(const float* sigma, const float* t_starts, const float* t_ends,
+                                  const int64_t* packed_info, int64_t n_rays, int64_t n, const float* weights,
+                                  const umhs_value_grads* grads, const float* d_accumulation, int grad_scaling,
+                                  float* d_sigma, umhs_stream_t stream) {
+  if (n_rays < 0 || n < 0 || !packed_info || !d_sigma) return UMHS_ERR_ARG;
+  if (n > 0 && (!sigma || !t_starts || !t_ends || !weights)) return UMHS_ERR_ARG;
+  CompGrads gr;
+  gr.n = grads ? grads->n_streams : 0;
+  if (gr.n < 0 || gr.n > UMHS_MAX_STREAMS) return UMHS_ERR_ARG;
+  for (int s = 0; s < UMHS_MAX_STREAMS; ++s) {
+    gr.k[s] = 0, gr.v[s] = nullptr, gr.dout[s] = nullptr, gr.dv[s] = nullptr;
+    if (s < gr.n) {
+      gr.k[s] = grads->k[s], gr.v[s] = grads->values[s], gr.dout[s] = grads->d_out[s], gr.dv[s] = grads->d_values[s];
+      if (gr.k[s] < 1 || !gr.dout[s] || (n > 0 && !gr.v[s])) return UMHS_ERR_ARG;
+    }
+  }
+  if (n_rays == 0 || n == 0) return UMHS_OK;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), sigma,
+                     t_starts, t_ends, packed_info, n_rays, weights, gr, d_accumulation, grad_scaling, d_sigma);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
+// R14: spectrum -> sRGB (one thread per ray; M [B,3] is tiny and stays in L1/scalar cache)
+// =============================================================================================
+#define GAMMA_KNEE 0.0031308f
+
+__device__ __forceinline__ float srgb_gamma(float x) {
+  return x < GAMMA_KNEE ? 12.92f * x : 1.055f * powf(fmaxf(x, 1e-6f), 1.0f / 2.4f) - 0.055f;
+}
+
+__global__ __launch_bounds__(256) void spec2rgb_fwd_kernel(const float* __restrict__ spec,
+                                                           const float* __restrict__ M, int64_t n_rays, int B,
+                                                           float* __restrict__ rgb) {
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rays) return;
+  const float* row = spec + r * B;
+  float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    float s = row[b];
+    x0 += s * M[3 * b], x1 += s * M[3 * b + 1], x2 += s * M[3 * b + 2];
+  }
+  rgb[3 * r] = fminf(fmaxf(srgb_gamma(x0), 0.0f), 1.0f);
+  rgb[3 * r + 1] = fminf(fmaxf(srgb_gamma(x1), 0.0f), 1.0f);
+  rgb[3 * r + 2] = fminf(fmaxf(srgb_gamma(x2), 0.0f), 1.0f);
+}
+
+__device__ __forceinline__ float srgb_gamma_grad(float x) {
+  // d/dx of clamp(gamma(x), 0, 1): torch passes the clamp gradient where 0 <= y <= 1
+  float y = srgb_gamma(x);
+  if (!(y >= 0.0f && y <= 1.0f)) return 0.0f;
+  if (x < GAMMA_KNEE) return 12.92f;
+  return 1.055f * (1.0f / 2.4f) * powf(fmaxf(x, 1e-6f), 1.0f / 2.4f - 1.0f);
+}
+
+__global__ __launch_bounds__(256) void spec2rgb_bwd_kernel(const float* __restrict__ spec,
+                                                           const float* __restrict__ M,
+                                                           const float* __restrict__ d_rgb, int64_t n_rays, int B,
+                                                           float* __restrict__ d_spec, int accumulate) {
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rays) return;
+  const float* row = spec + r * B;
+  float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    float s = row[b];
+    x0 += s * M[3 * b], x1 += s * M[3 * b + 1], x2 += s * M[3 * b + 2];
+  }
+  float g0 = d_rgb[3 * r] * srgb_gamma_grad(x0);
+  float g1 = d_rgb[3 * r + 1] * srgb_gamma_grad(x1);
+  float g2 = d_rgb[3 * r + 2] * srgb_gamma_grad(x2);
+  float* drow = d_spec + r * B;
+  for (int b = 0; b < B; ++b) {
+    float v = g0 * M[3 * b] + g1 * M[3 * b + 1] + g2 * M[3 * b + 2];
+    drow[b] = accumulate ? drow[b] + v : v;
+  }
+}
+
+extern "C" int umhs_spec2rgb_fwd(const float* spec, const float* M, int64_t n_rays, int B, float* rgb,
+                                 umhs_stream_t stream) {
+  if (n_rays < 0 || B < 1 || !spec || !M || !rgb) return UMHS_ERR_ARG;
+  if (n_rays == 0) return UMHS_OK;
+  hipLaunchKernelGGL(spec2rgb_fwd_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, umhs_s(stream), spec,
+                     M, n_rays, B, rgb);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+extern "C" int umhs_spec2rgb_bwd(const float* spec, const float* M, const float* d_rgb, int64_t n_rays, int B,
+                                 float* d_spec, int accumulate, umhs_stream_t stream) {
+  if (n_rays < 0 || B < 1 || !spec || !M || !d_rgb || !d_spec) return UMHS_ERR_ARG;
+  if (n_rays == 0) return UMHS_OK;
+  hipLaunchKernelGGL(spec2rgb_bwd_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, umhs_s(stream), spec,
+                     M, d_rgb, n_rays, B, d_spec, accumulate);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
+// Fused Adam over the flat "fields" parameter buffer (28 B/param of pure HBM streaming, float4 lanes)
+// =============================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_bc1,
+                                                   float b1, float b2, float eps, float sqrt_bc2, float gscale,
+                                                   int64_t cb, int64_t ce) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
+      float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+      float* pa = reinterpret_cast<float*>(&pp);
+      float* ga = reinterpret_cast<float*>(&gg);
+      float* ma = reinterpret_cast<float*>(&mm);
+      float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gk = ga[k] * gscale;
+        ma[k] = ma[k] * b1 + gk * (1.0f - b1);
+        va[k] = va[k] * b2 + gk * gk * (1.0f - b2);
+        float denom = sqrtf(va[k]) / sqrt_bc2 + eps;
+        pa[k] = pa[k] - lr_bc1 * (ma[k] / denom);
+        if (i + k >= cb && i + k < ce) pa[k] = fminf(fmaxf(pa[k], 0.0f), 1.0f);
+      }
+      *reinterpret_cast<float4*>(p + i) = pp;
+      *reinterpret_cast<float4*>(m + i) = mm;
+      *reinterpret_cast<float4*>(v + i) = vv;
+    } else {
+      for (int64_t j = i; j < n; ++j) {
+        float gk = g[j] * gscale;
+        float mk = m[j] * b1 + gk * (1.0f - b1);
+        float vk = v[j] * b2 + gk * gk * (1.0f - b2);
+        float denom = sqrtf(vk) / sqrt_bc2 + eps;
+        float pk = p[j] - lr_bc1 * (mk / denom);
+        if (j >= cb && j < ce) pk = fminf(fmaxf(pk, 0.0f), 1.0f);
+        p[j] = pk, m[j] = mk, v[j] = vk;
+      }
+    }
+  }
+}
+
+extern "C" int umhs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                              int64_t clamp_begin, int64_t clamp_end, umhs_stream_t stream) {
+  if (n < 0 || step < 1 || !params || !grads || !exp_avg || !exp_avg_sq) return UMHS_ERR_ARG;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return UMHS_ERR_ARG;
+  if (n == 0) return UMHS_OK;
+  double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, umhs_s(stream), params, grads, exp_avg,
+                     exp_avg_sq, n, (float)(lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale,
+                     clamp_begin, clamp_end);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
+extern "C" const char* umhs_strerror(int code) {
+  switch (code) {
+    case UMHS_OK: return "ok";
+    case UMHS_ERR_ARG: return "invalid argument";
+    case UMHS_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    case UMHS_ERR_WORKSPACE: return "workspace missing or too small";
+    case UMHS_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown error";
+  }
+}
+extern "C" int umhs_abi_version(void) { return UMHS_ABI_VERSION; }

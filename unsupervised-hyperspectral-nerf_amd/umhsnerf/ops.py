@@ -1,0 +1,370 @@
+"""Host-side operators of the UMHS hot path: thin tensor wrappers over the C ABI plus the
+``torch.autograd.Function`` glue that lets nerfstudio's Trainer drive them.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every number is produced by
+libumhs_hip.so.  Nothing in this module has a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import ptr
+
+NUM_LEVELS = 16
+FEATURES_PER_LEVEL = 2
+GEO_FEAT_DIM = 15
+HIDDEN = 64
+
+
+def hash_scalings(num_levels: int = NUM_LEVELS, min_res: int = 16, max_res: int = 2048) -> torch.Tensor:
+    """``scalings`` buffer of nerfstudio's HashEncoding (mlp_base, umhs_field.py:51 / umhs_model.py:183-184).
+    Deliberately the same expression: the numpy float64 growth factor is raised to an int64 tensor, which torch
+    evaluates in float32, so the top level is floor(2047.99..) = 2047."""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1.0
+    return torch.floor(min_res * growth**levels)
+
+
+# --------------------------------------------------------------------------------------------- #
+# flat parameter layout (one fp32 buffer = param group "fields"; names = reference state-dict keys)
+# --------------------------------------------------------------------------------------------- #
+@dataclass
+class FieldLayout:
+    num_classes: int
+    wavelengths: int
+    pred_specular: bool
+    log2_hashmap_size: int = 19
+    entries: Dict[str, Tuple[int, Tuple[int, ...]]] = field(default_factory=dict)
+    total: int = 0
+
+    def __post_init__(self):
+        Cn, B = self.num_classes, self.wavelengths
+        T = 1 << self.log2_hashmap_size
+        out_feat = Cn + 1 if self.pred_specular else Cn
+        shapes = [("mlp_base.encoder.hash_table", (NUM_LEVELS * T, FEATURES_PER_LEVEL))]
+
+        def mlp(prefix, dims):
+            for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+                shapes.append((f"{prefix}.layers.{i}.weight", (b, a)))
+                shapes.append((f"{prefix}.layers.{i}.bias", (b,)))
+
+        mlp("mlp_base.mlp", [NUM_LEVELS * FEATURES_PER_LEVEL, HIDDEN, 1 + GEO_FEAT_DIM])
+        mlp("mlp_head", [12 + GEO_FEAT_DIM, HIDDEN, HIDDEN, Cn])
+        mlp("feature_mlp", [12 + GEO_FEAT_DIM, HIDDEN, HIDDEN, out_feat])
+        mlp("mlp_directional", [16 + 12, 16, B])
+        shapes.append(("endmembers", (Cn, B)))
+        off = 0
+        for name, shp in shapes:
+            self.entries[name] = (off, shp)
+            off += (int(np.prod(shp)) + 3) & ~3  # 16-byte aligned segments (float4 Adam, float2 table rows)
+        self.total = off
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        off, shp = self.entries[name]
+        return flat[off : off + int(np.prod(shp))].view(shp)
+
+    def offset(self, name: str) -> int:
+        return self.entries[name][0]
+
+    # (C struct field, state-dict key)
+    C_FIELDS = (
+        ("base_w0", "mlp_base.mlp.layers.0.weight"), ("base_b0", "mlp_base.mlp.layers.0.bias"),
+        ("base_w1", "mlp_base.mlp.layers.1.weight"), ("base_b1", "mlp_base.mlp.layers.1.bias"),
+        ("head_w0", "mlp_head.layers.0.weight"), ("head_b0", "mlp_head.layers.0.bias"),
+        ("head_w1", "mlp_head.layers.1.weight"), ("head_b1", "mlp_head.layers.1.bias"),
+        ("head_w2", "mlp_head.layers.2.weight"), ("head_b2", "mlp_head.layers.2.bias"),
+        ("feat_w0", "feature_mlp.layers.0.weight"), ("feat_b0", "feature_mlp.layers.0.bias"),
+        ("feat_w1", "feature_mlp.layers.1.weight"), ("feat_b1", "feature_mlp.layers.1.bias"),
+        ("feat_w2", "feature_mlp.layers.2.weight"), ("feat_b2", "feature_mlp.layers.2.bias"),
+        ("dir_w0", "mlp_directional.layers.0.weight"), ("dir_b0", "mlp_directional.layers.0.bias"),
+        ("dir_w1", "mlp_directional.layers.1.weight"), ("dir_b1", "mlp_directional.layers.1.bias"),
+        ("endmembers", "endmembers"),
+    )
+
+    def c_struct(self, flat: torch.Tensor, cls):
+        s = cls()
+        base = flat.data_ptr()
+        for cname, key in self.C_FIELDS:
+            setattr(s, cname, base + 4 * self.entries[key][0])
+        return s
+
+
+@dataclass
+class FieldSpec:
+    """Static configuration the kernels need (everything that is not a tensor)."""
+
+    layout: FieldLayout
+    temperature: float
+    contraction: bool = True
+    aabb: Tuple[float, ...] = (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)
+    scalings: Optional[torch.Tensor] = None  # device [16] float32
+
+    def cfg(self, density_only: bool = False) -> _hip.FieldCfg:
+        return _hip.FieldCfg(self.layout.wavelengths, self.layout.num_classes, int(self.layout.pred_specular),
+                             int(density_only), float(self.temperature))
+
+
+# --------------------------------------------------------------------------------------------- #
+# raw operator calls
+# --------------------------------------------------------------------------------------------- #
+def positions_fwd(origins, directions, starts, ends, spec: FieldSpec, world_pos_in=None):
+    src = world_pos_in if world_pos_in is not None else origins
+    n = src.shape[0]
+    wpos = torch.empty((n, 3), device=src.device, dtype=torch.float32) if world_pos_in is None else world_pos_in
+    pos01 = torch.empty((n, 3), device=src.device, dtype=torch.float32)
+    sel = torch.empty((n,), device=src.device, dtype=torch.float32)
+    aabb = (C.c_float * 6)(*spec.aabb)
+    _hip.check(
+        _hip.lib().umhs_positions_fwd(ptr(origins), ptr(directions), ptr(starts), ptr(ends), ptr(world_pos_in), n,
+                                      int(spec.contraction), aabb, ptr(wpos) if world_pos_in is None else None, ptr(pos01),
+                                      ptr(sel), _hip.stream()),
+        "umhs_positions_fwd",
+    )
+    return wpos, pos01, sel
+
+
+def enc_strides(n: int, level_major: bool) -> Tuple[int, int]:
+    return (2, 2 * n) if level_major else (2 * NUM_LEVELS, 2)
+
+
+def hashgrid_fwd(pos01, table, scalings, log2_T: int, level_major: bool = True):
+    n = pos01.shape[0]
+    shape = (NUM_LEVELS, n, 2) if level_major else (n, NUM_LEVELS * 2)
+    enc = torch.empty(shape, device=pos01.device, dtype=torch.float32)
+    sn, sl = enc_strides(n, level_major)
+    _hip.check(_hip.lib().umhs_hashgrid_fwd(ptr(pos01), ptr(table), ptr(scalings), n, NUM_LEVELS, log2_T, ptr(enc), sn, sl,
+                                            _hip.stream()), "umhs_hashgrid_fwd")
+    return enc
+
+
+def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True):
+    n = pos01.shape[0]
+    sn, sl = enc_strides(n, level_major)
+    _hip.check(_hip.lib().umhs_hashgrid_bwd(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, NUM_LEVELS, log2_T,
+                                            ptr(d_table), _hip.stream()), "umhs_hashgrid_bwd")
+
+
+def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True):
+    n = sel.shape[0]
+    L = spec.layout
+    dev = sel.device
+    cfg = spec.cfg(density_only)
+    pp = L.c_struct(flat, _hip.FieldParams)
+    sn, sl = enc_strides(n, level_major)
+    new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    sigma, sigma_raw = new(n), new(n)
+    emb = new(n, GEO_FEAT_DIM) if (want_emb or density_only) else None
+    spectral = spectral2 = specular = abund = None
+    if not density_only:
+        spectral = new(n, L.wavelengths)
+        if want_aux:
+            abund = new(n, L.num_classes)
+            if L.pred_specular:
+                spectral2, specular = new(n, L.wavelengths), new(n, L.wavelengths)
+    _hip.check(_hip.lib().umhs_field_fwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), n,
+                                         ptr(sigma), ptr(sigma_raw), ptr(emb), ptr(spectral), ptr(spectral2), ptr(specular),
+                                         ptr(abund), _hip.stream()), "umhs_field_fwd")
+    return dict(sigma=sigma, sigma_raw=sigma_raw, emb=emb, spectral=spectral, spectral2=spectral2, specular=specular,
+                abundances=abund)
+
+
+_ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index or 0, 0)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, d_sigma, d_spectral, d_emb, d_flat):
+    """Writes d_enc (returned) and the MLP / endmember gradients straight into ``d_flat`` (flat layout)."""
+    n = sel.shape[0]
+    L = spec.layout
+    cfg = spec.cfg(False)
+    pp = L.c_struct(flat, _hip.FieldParams)
+    gp = L.c_struct(d_flat, _hip.FieldGrads)
+    sn, sl = enc_strides(n, level_major)
+    d_enc = torch.empty_like(enc)
+    nbytes = _hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n)
+    ws = _workspace(nbytes, sel.device)
+    _hip.check(_hip.lib().umhs_field_bwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), n,
+                                         ptr(d_sigma), ptr(d_spectral), ptr(d_emb), ptr(d_enc), C.byref(gp), ptr(ws),
+                                         ws.numel(), _hip.stream()), "umhs_field_bwd")
+    return d_enc
+
+
+def pack_info(ray_indices: torch.Tensor, num_rays: int) -> torch.Tensor:
+    out = torch.empty((num_rays, 2), device=ray_indices.device, dtype=torch.int64)
+    _hip.check(_hip.lib().umhs_pack_info(ptr(ray_indices), ray_indices.shape[0], num_rays, ptr(out), _hip.stream()),
+               "umhs_pack_info")
+    return out
+
+
+def composite_fwd(sigma, t0, t1, packed_info, values: Sequence[torch.Tensor]):
+    R, n, dev = packed_info.shape[0], sigma.shape[0], sigma.device
+    st = _hip.ValueStreams()
+    st.n_streams = len(values)
+    outs = []
+    for i, v in enumerate(values):
+        o = torch.empty((R, v.shape[-1]), device=dev, dtype=torch.float32)
+        st.k[i], st.values[i], st.out[i] = v.shape[-1], v.data_ptr(), o.data_ptr()
+        outs.append(o)
+    weights = torch.empty((n,), device=dev, dtype=torch.float32)
+    acc = torch.empty((R,), device=dev, dtype=torch.float32)
+    depth = torch.empty((R,), device=dev, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_composite_fwd(ptr(sigma), ptr(t0), ptr(t1), ptr(packed_info), R, n, C.byref(st), ptr(weights),
+                                             ptr(acc), ptr(depth), _hip.stream()), "umhs_composite_fwd")
+    return weights, acc, depth, outs
+
+
+def composite_bwd(sigma, t0, t1, packed_info, weights, values, d_outs, want_dvalues, d_acc, grad_scaling: bool):
+    R, n, dev = packed_info.shape[0], sigma.shape[0], sigma.device
+    g = _hip.ValueGrads()
+    d_values: List[Optional[torch.Tensor]] = []
+    k = 0
+    for v, do, want in zip(values, d_outs, want_dvalues):
+        if do is None:
+            d_values.append(None)
+            continue
+        dv = torch.empty_like(v) if want else None
+        g.k[k], g.values[k], g.d_out[k] = v.shape[-1], v.data_ptr(), do.data_ptr()
+        g.d_values[k] = dv.data_ptr() if dv is not None else None
+        d_values.append(dv)
+        k += 1
+    g.n_streams = k
+    d_sigma = torch.zeros((n,), device=dev, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_composite_bwd(ptr(sigma), ptr(t0), ptr(t1), ptr(packed_info), R, n, ptr(weights), C.byref(g),
+                                             ptr(d_acc), int(grad_scaling), ptr(d_sigma), _hip.stream()), "umhs_composite_bwd")
+    return d_sigma, d_values
+
+
+def spec2rgb_fwd(spec_t, M):
+    R, B = spec_t.shape
+    rgb = torch.empty((R, 3), device=spec_t.device, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_spec2rgb_fwd(ptr(spec_t), ptr(M), R, B, ptr(rgb), _hip.stream()), "umhs_spec2rgb_fwd")
+    return rgb
+
+
+def spec2rgb_bwd(spec_t, M, d_rgb):
+    R, B = spec_t.shape
+    d_spec = torch.empty_like(spec_t)
+    _hip.check(_hip.lib().umhs_spec2rgb_bwd(ptr(spec_t), ptr(M), ptr(d_rgb), R, B, ptr(d_spec), 0, _hip.stream()),
+               "umhs_spec2rgb_bwd")
+    return d_spec
+
+
+def adam_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps=1e-15, grad_scale=1.0, clamp_range=(0, 0)):
+    _hip.check(_hip.lib().umhs_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, step,
+                                         grad_scale, clamp_range[0], clamp_range[1], _hip.stream()), "umhs_adam_step")
+
+
+# --------------------------------------------------------------------------------------------- #
+# autograd glue
+# --------------------------------------------------------------------------------------------- #
+class FieldFn(torch.autograd.Function):
+    """UMHSField.forward (get_density + get_outputs, umhs_field.py:151-329) on packed samples.
+
+    inputs : flat params, origins [N,3], directions [N,3], starts [N,1], ends [N,1]
+    outputs: density [N,1], emb [N,15], spectral [N,B], spectral2 | None, specular | None, abundances [N,C]
+    """
+
+    @staticmethod
+    def forward(ctx, flat, origins, directions, starts, ends, spec: FieldSpec):
+        L = spec.layout
+        o, d = _hip.f32c(origins), _hip.f32c(directions)
+        s, e = _hip.f32c(starts).view(-1), _hip.f32c(ends).view(-1)
+        wpos, pos01, sel = positions_fwd(o, d, s, e, spec)
+        table = L.view(flat.detach(), "mlp_base.encoder.hash_table")
+        enc = hashgrid_fwd(pos01, table, spec.scalings, L.log2_hashmap_size, True)
+        out = field_fwd(spec, flat.detach(), enc, True, wpos, d, sel, want_emb=True)
+        ctx.spec = spec
+        ctx.save_for_backward(flat, pos01, sel, wpos, d, enc)
+        n = o.shape[0]
+        res = [out["sigma"].view(n, 1), out["emb"], out["spectral"], out["spectral2"], out["specular"], out["abundances"]]
+        ctx.mark_non_differentiable(*[t for t in res[3:] if t is not None])
+        ctx.sigma_raw = out["sigma_raw"]
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, d_sigma, d_emb, d_spectral, *_):
+        flat, pos01, sel, wpos, d, enc = ctx.saved_tensors
+        spec: FieldSpec = ctx.spec
+        L = spec.layout
+        n = sel.shape[0]
+        zeros = lambda *s: torch.zeros(s, device=sel.device, dtype=torch.float32)
+        d_sigma = _hip.f32c(d_sigma).view(-1) if d_sigma is not None else zeros(n)
+        d_spectral = _hip.f32c(d_spectral) if d_spectral is not None else zeros(n, L.wavelengths)
+        d_emb = _hip.f32c(d_emb) if d_emb is not None else None
+        d_flat = torch.zeros_like(flat)
+        d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, d_sigma, d_spectral, d_emb, d_flat)
+        hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, L.view(d_flat, "mlp_base.encoder.hash_table"), True)
+        return d_flat, None, None, None, None, None
+
+
+class DensityFn(torch.autograd.Function):
+    """density_fn / get_density forward only (no-grad users: occupancy grid, sampler; umhs_model.py:208,553)."""
+
+    @staticmethod
+    def forward(ctx, flat, positions, spec: FieldSpec):
+        L = spec.layout
+        p = _hip.f32c(positions).view(-1, 3)
+        _, pos01, sel = positions_fwd(None, None, None, None, spec, world_pos_in=p)
+        enc = hashgrid_fwd(pos01, L.view(flat.detach(), "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
+        out = field_fwd(spec, flat.detach(), enc, True, None, None, sel, density_only=True)
+        ctx.mark_non_differentiable(out["sigma"], out["emb"])
+        return out["sigma"].view(-1, 1), out["emb"]
+
+    @staticmethod
+    def backward(ctx, *_):
+        raise RuntimeError("density_fn is a no-grad path (umhs_model.py:229-237); use UMHSField.forward for gradients")
+
+
+class CompositeFn(torch.autograd.Function):
+    """nerfacc.render_weight_from_density + accumulate_along_rays for every composited stream at once
+    (umhs_model.py:245-304 -> umhs_renderer.py:28-30).  values: tuple of [N,k] tensors; returns
+    (weights [N,1], accumulation [R,1], depth_unclipped [R,1], *composited [R,k])."""
+
+    @staticmethod
+    def forward(ctx, sigma, starts, ends, packed_info, grad_scaling: bool, *values):
+        s = _hip.f32c(sigma).view(-1)
+        t0, t1 = _hip.f32c(starts).view(-1), _hip.f32c(ends).view(-1)
+        vals = [_hip.f32c(v).view(v.shape[-2], v.shape[-1]) for v in values]
+        weights, acc, depth, outs = composite_fwd(s, t0, t1, packed_info, vals)
+        ctx.save_for_backward(s, t0, t1, packed_info, weights, *vals)
+        ctx.grad_scaling = grad_scaling
+        ctx.needs = [v.requires_grad for v in values]
+        ctx.mark_non_differentiable(weights, depth)
+        return (weights.view(-1, 1), acc.view(-1, 1), depth.view(-1, 1), *outs)
+
+    @staticmethod
+    def backward(ctx, _dw, d_acc, _dd, *d_outs):
+        s, t0, t1, pinfo, weights, *vals = ctx.saved_tensors
+        d_outs = [(_hip.f32c(g) if g is not None else None) for g in d_outs]
+        d_acc = _hip.f32c(d_acc).view(-1) if d_acc is not None else None
+        d_sigma, d_values = composite_bwd(s, t0, t1, pinfo, weights, vals, d_outs, ctx.needs, d_acc, ctx.grad_scaling)
+        return (d_sigma.view(-1, 1), None, None, None, None, *d_values)
+
+
+class Spec2RgbFn(torch.autograd.Function):
+    """ColourSystem.forward (utils/spec_to_rgb.py:112-127)."""
+
+    @staticmethod
+    def forward(ctx, spec_t, M):
+        s, m = _hip.f32c(spec_t), _hip.f32c(M)
+        ctx.save_for_backward(s, m)
+        return spec2rgb_fwd(s, m)
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        s, m = ctx.saved_tensors
+        return spec2rgb_bwd(s, m, _hip.f32c(d_rgb)), None
