@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- train rays/sec of the UMHS hot path on N MI355X GPUs (one process per GPU over RCCL).
+
+A "step" is one full training iteration of the reference on a synthetic packed batch of the hotdog-shaped
+config C2 (B=31 bands, C=6 endmembers, temperature 0.4, specular on, rgb+spectral, 4096 rays x 64
+samples per GPU): field forward -> compositing of every stream -> spec->sRGB -> losses -> backward -> (RCCL
+all-reduce of the flat gradient when N>1) -> fused Adam with the endmember clamp.  Inputs are resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events on the
+launch stream; `cpu_baseline` is the oracle (CPU restatement of the reference's torch path) timed on this
+box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+C2 = dict(R=4096, S=64, B=31, C=6, temperature=0.4, pred_specular=True, method="rgb+spectral")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+ATOMIC_PEAK_GBS = 1300.0  # ibid. "Global float atomics": chip-wide ~1.3 TB/s of added bytes
+
+
+def synthetic_batch(R, S, B, seed, device):
+    """Same recipe as oracle.torch_ref.synthetic_batch, built with torch on the host then moved."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(R, 3, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True)
+    o = (torch.rand(R, 3, generator=g) * 2 - 1) * 0.5 + 2.5 * u
+    d = -o + torch.randn(R, 3, generator=g) * 0.1
+    d = d / d.norm(dim=-1, keepdim=True)
+    ray_indices = torch.arange(R).repeat_interleave(S)
+    step = float(np.sqrt(12.0) / 1000.0)
+    t_near = (o.norm(dim=-1) - 1.3).clamp(min=0.05) + torch.rand(R, generator=g) * step
+    k = torch.arange(R * S) % S
+    t0 = t_near[ray_indices] + k * (2.6 / S)
+    t1 = t0 + step * (1 + 0.004 * t0)
+    b = dict(origins=o[ray_indices].contiguous(), directions=d[ray_indices].contiguous(), starts=t0[:, None].contiguous(),
+             ends=t1[:, None].contiguous(), ray_indices=ray_indices, gt_spectral=torch.rand(R, B, generator=g))
+    return {k_: v.to(device) for k_, v in b.items()}
+
+
+def trained_like_init(field, seed):
+    """Untrained tables give constant outputs; use a 'trained-like' state: table U(+-0.5), endmembers in
+    [0,1], density bias raised so ~30 % of the samples have alpha > 0.01."""
+    g = torch.Generator().manual_seed(seed)
+    L = field.layout
+    with torch.no_grad():
+        flat = field.flat.data.cpu()
+        tab = L.view(flat, "mlp_base.encoder.hash_table")
+        tab.copy_((torch.rand(tab.shape, generator=g) * 2 - 1) * 0.5)
+        L.view(flat, "endmembers").copy_(torch.rand(L.entries["endmembers"][1], generator=g))
+        L.view(flat, "mlp_base.mlp.layers.1.bias")[0] += 1.5
+        field.flat.data.copy_(flat.to(field.flat.device))
+
+
+class KernelTimer:
+    """HIP events around each C-ABI call on the launch stream (torch's current stream is the stream every op uses)."""
+
+    def __init__(self, ops):
+        self.ops, self.records, self.orig = ops, {}, {}
+        self.enabled = False
+
+    def wrap(self, name):
+        fn = getattr(self.ops, name)
+        self.orig[name] = fn
+
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.records.setdefault(name, []).append((e0, e1))
+            return out
+
+        setattr(self.ops, name, timed)
+
+    def summary(self):
+        return {k: (float(np.mean([a.elapsed_time(b) for a, b in v])), len(v)) for k, v in self.records.items()}
+
+
+def cpu_baseline(cfg, seed, budget_s=15.0):
+    """Oracle train step (fwd + loss + bwd + Adam) on the host cores: the 'reference CPU path' stand-in."""
+    from oracle import torch_ref as T
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))  # a 1-GPU box owns a 16-core share of the host; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    R = 1024  # bounded sample: 1024 of the 4096 rays (x64 samples), same distributions
+    p = T.FieldParams(cfg["C"], cfg["B"], cfg["pred_specular"], cfg["method"], table_scale=0.5, seed=seed)
+    with torch.no_grad():
+        p.base_b[1][0] += 1.5
+    b = T.synthetic_batch(R, cfg["S"], cfg["B"], seed=seed)
+    M = T.colour_matrix(np.linspace(400, 700, cfg["B"]))
+    gt_rgb = T.colour_system(b["gt_spectral"], M)
+    params = [v for _, v in p.named_parameters()]
+    ms, vs = [torch.zeros_like(v) for v in params], [torch.zeros_like(v) for v in params]
+
+    def step(i):
+        out = T.model_outputs(p, b["origins"], b["directions"], b["starts"], b["ends"], b["ray_indices"], R, cfg["temperature"], M)
+        loss = sum(T.model_loss(out, b["gt_spectral"], gt_rgb, b["bg_random"], cfg["method"]).values())
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, params)]
+        with torch.no_grad():
+            T.adam_step(params, grads, ms, vs, i, 2e-2)
+            p.endmembers.clamp_(0, 1)
+
+    print(f"[bench] cpu_baseline: {cores} threads, {R} rays x {cfg['S']} samples ...", file=sys.stderr, flush=True)
+    step(1)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 8):
+        n += 1
+        step(n + 1)
+        print(f"[bench] cpu_baseline step {n}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=R / dt, unit="rays/s", cores=cores, kind="port",
+                sample=f"oracle/torch_ref.py fp32 train step (fwd+loss+bwd+Adam), {R} of {cfg['R']} rays x {cfg['S']} samples, {n} steps, {dt:.2f} s/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)  # RCCL
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from umhsnerf import ops
+    from umhsnerf._ns_compat import packed_ray_samples
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    cfg = C2
+    R, S, B, Cn = cfg["R"], cfg["S"], cfg["B"], cfg["C"]
+    N = R * S
+    bands = list(np.linspace(400, 700, B))
+    mc = UMHSConfig(method=cfg["method"], pred_specular=cfg["pred_specular"], temperature=cfg["temperature"], per_band_outputs=True)
+    pipe = UMHSPipeline(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=local, seed=42)
+    trained_like_init(pipe.model.field, seed=42)
+    if world > 1:
+        dist.broadcast(pipe.model.field.flat.data, src=0)
+    b = synthetic_batch(R, S, B, seed=42 + rank, device=device)  # every rank draws its own rays (weak scaling)
+    rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])
+    pinfo = ops.pack_info(b["ray_indices"], R)
+    with torch.no_grad():
+        gt_rgb = pipe.model.converter(b["gt_spectral"])
+    batch = {"image": gt_rgb, "hs_image": b["gt_spectral"]}
+
+    timer = KernelTimer(ops)
+    for name in ("positions_fwd", "hashgrid_fwd", "field_fwd", "composite_fwd", "spec2rgb_fwd", "spec2rgb_bwd", "composite_bwd",
+                 "field_bwd", "hashgrid_bwd", "adam_step"):
+        timer.wrap(name)
+
+    def step():
+        return pipe.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
+
+    for _ in range(args.warmup):
+        step()
+    timer.enabled = True
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outputs, loss_dict = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ksum = timer.summary()
+        ms_step = dt / args.steps * 1e3
+        psnr = float(pipe.model.psnr(outputs["spectral"].detach(), b["gt_spectral"]))
+        loss_dict = {k: v.detach() for k, v in loss_dict.items()}
+        print(f"[bench] gpu: {ms_step:.3f} ms/step, {R * world * args.steps / dt:.0f} rays/s", file=sys.stderr, flush=True)
+        # algorithmic bytes per launch (1024 B/sample of hash-grid gather resp. gradient scatter,
+        # + the level-major feature rows (128 B) and positions (12 B) each kernel streams)
+        alg = {
+            "hashgrid_bwd": N * (1024 + 128 + 12),
+            "hashgrid_fwd": N * (1024 + 128 + 12),
+            "adam_step": pipe.model.field.flat.numel() * 28,
+        }
+        kern = {k: round(v[0], 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][0])}
+        dom = next(iter(kern))
+        roof = None
+        if dom in alg:
+            ach = alg[dom] / (ksum[dom][0] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                        traffic=None, avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1],
+                        note=("float-atomic scatter: practical ceiling %.0f GB/s of added bytes (MI355X_MICROARCH.md)" % ATOMIC_PEAK_GBS)
+                        if dom == "hashgrid_bwd" else None)
+        else:  # MFMA-bound field kernels: fp32-input MFMA peak 157.3 TFLOP/s
+            flops = {"field_fwd": 33.9e3 * N, "field_bwd": (2 * 33.9e3 + 33.9e3) * N}.get(dom)
+            if flops:
+                ach = flops / (ksum[dom][0] * 1e-3) / 1e12
+                roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=157.3, unit="TFLOP/s", frac=round(ach / 157.3, 4),
+                            traffic=None, avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1])
+        line = {
+            "metric": "train rays/sec (hotdog-shaped 31-band, C2)", "value": round(R * world * args.steps / dt, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 hotdog 31-band rgb+spectral train step (fwd+loss+bwd+Adam)", "rays_per_gpu": R, "samples_per_ray": S,
+                       "bands": B, "endmembers": Cn, "global_rays": R * world, "hash_table": "16x2^19x2 f32", "parallelism": f"dp{world}"},
+            "spectral_psnr_db": round(psnr, 3), "loss": {k: round(float(v), 6) for k, v in loss_dict.items()},
+            "kernels_ms": kern, "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, seed=42)
+            line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

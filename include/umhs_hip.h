@@ -165,6 +165,15 @@ int umhs_composite_bwd(const float* sigma, const float* t_starts, const float* t
                        int64_t n_rays, int64_t n, const float* weights, const umhs_value_grads* grads,
                        const float* d_accumulation, int grad_scaling, float* d_sigma, umhs_stream_t stream);
 
+/* R12 stand-alone: accumulate with caller-provided weights [N] -- SpectralRenderer.forward(spectral, weights,  */
+/* ray_indices, num_rays) called on its own (umhs_renderer.py:15-30; dino / abundance renders,                  */
+/* umhs_model.py:299-317).  out[r,:] = sum_n w[n] v[n,:];  bwd: d_weights[n] = sum_k d_out[r,k] v[n,k] (rays     */
+/* with no samples leave their d_weights untouched: caller zero-fills), d_values[n,:] = w[n] d_out[r,:].         */
+int umhs_accumulate_fwd(const float* weights, const int64_t* packed_info, int64_t n_rays, int64_t n,
+                        const umhs_value_streams* streams, umhs_stream_t stream);
+int umhs_accumulate_bwd(const float* weights, const int64_t* packed_info, int64_t n_rays, int64_t n,
+                        const umhs_value_grads* grads, float* d_weights, umhs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* R14: spectrum -> sRGB.  Replaces ColourSystem.forward, utils/spec_to_rgb.py:103-127:         */
 /* rgb = clamp(gamma(spec @ M), 0, 1), M [B,3].  bwd writes d_spec [R,B] (accumulate != 0: +=). */

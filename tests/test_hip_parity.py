@@ -281,13 +281,14 @@ def test_field_against_reference_golden(golden_dir, case, C, B, spec):
     o, d, s, e = (torch.from_numpy(g[k]).to(DEV) for k in ("origins", "directions", "starts", "ends"))
     density, emb, spectral, spectral2, specular, abund = ops.FieldFn.apply(flat, o, d, s, e, fs)
     N = o.shape[0]
-    np.testing.assert_allclose(density.detach().cpu().numpy(), g["density"], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(emb.detach().cpu().numpy(), g["emb"], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(spectral.detach().cpu().numpy(), g["out_spectral"].reshape(N, B), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(abund.cpu().numpy(), g["out_abundances"].reshape(N, C), rtol=1e-4, atol=1e-6)
+    gt = lambda k, *shape: torch.from_numpy(g[k]).reshape(*shape)
+    assert_close("density", density, gt("density", N, 1), 2e-5)
+    assert_close("emb", emb, gt("emb", N, 15), 2e-5)
+    assert_close("spectral", spectral, gt("out_spectral", N, B), 2e-5)
+    assert_close("abundances", abund, gt("out_abundances", N, C), 2e-5)
     if spec:
-        np.testing.assert_allclose(spectral2.cpu().numpy(), g["out_spectral2"].reshape(N, B), rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(specular.cpu().numpy(), g["out_specular"].reshape(N, B), rtol=1e-4, atol=1e-6)
+        assert_close("spectral2", spectral2, gt("out_spectral2", N, B), 2e-5)
+        assert_close("specular", specular, gt("out_specular", N, B), 2e-5)
     loss = (spectral * torch.from_numpy(g["cot_spec"]).to(DEV).view(N, B)).sum() + (density * torch.from_numpy(g["cot_den"]).to(DEV)).sum()
     loss.backward()
     gflat = flat.grad

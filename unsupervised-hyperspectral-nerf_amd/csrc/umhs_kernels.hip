@@ -88,7 +88,12 @@ struct HashCorners {
 
 __device__ __forceinline__ HashCorners hash_corners(float px, float py, float pz, float s, uint32_t mask,
                                                     uint32_t base) {
+#pragma clang fp contract(off)
+  // round the scaled coordinate BEFORE subtracting its floor (as the reference's torch ops do): a fused
+  // fma(px, s, -floor) would use the unrounded product and shift the offset by up to half an ulp of ~2047.
+  // (__fmul_rn is plain '*' in HIP, so contraction is switched off here and the products are made opaque.)
   float sx = px * s, sy = py * s, sz = pz * s;
+  asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
   float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
   uint32_t xf = (uint32_t)(int)fx, yf = (uint32_t)(int)fy * HASH_P1, zf = (uint32_t)(int)fz * HASH_P2;
   uint32_t xc = (uint32_t)(int)ceilf(sx), yc = (uint32_t)(int)ceilf(sy) * HASH_P1,
@@ -438,6 +443,126 @@ extern "C" int umhs_composite_bwd(const float* sigma, const float* t_starts, con
   if (n_rays == 0 || n == 0) return UMHS_OK;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), sigma,
                      t_starts, t_ends, packed_info, n_rays, weights, gr, d_accumulation, grad_scaling, d_sigma);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// ---- accumulate with caller-provided weights (SpectralRenderer.forward called stand-alone) -----------------
+__global__ __launch_bounds__(256) void accumulate_fwd_kernel(const float* __restrict__ weights,
+                                                             const int64_t* __restrict__ pinfo, int64_t n_rays,
+                                                             CompStreams st) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (r >= n_rays) return;
+  const int64_t start = pinfo[2 * r];
+  const int cnt = (int)pinfo[2 * r + 1];
+  for (int s = 0; s < st.n; ++s) {
+    const int K = st.k[s];
+    for (int kc = 0; kc < K; kc += 64) {
+      const int k = kc + lane;
+      if (k >= K) continue;
+      const float* __restrict__ v = st.v[s] + start * (int64_t)K + k;
+      float p0 = 0.0f, p1 = 0.0f;
+      int j = 0;
+      for (; j + 1 < cnt; j += 2) {
+        p0 += weights[start + j] * v[(int64_t)j * K];
+        p1 += weights[start + j + 1] * v[(int64_t)(j + 1) * K];
+      }
+      if (j < cnt) p0 += weights[start + j] * v[(int64_t)j * K];
+      st.out[s][r * K + k] = p0 + p1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void accumulate_bwd_kernel(const float* __restrict__ weights,
+                                                             const int64_t* __restrict__ pinfo, int64_t n_rays,
+                                                             CompGrads gr, float* __restrict__ d_weights) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (r >= n_rays) return;
+  const int64_t start = pinfo[2 * r];
+  const int cnt = (int)pinfo[2 * r + 1];
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < cnt;
+    const int64_t nidx = start + i;
+    float w = valid ? weights[nidx] : 0.0f, dw = 0.0f;
+    if (valid) {
+      for (int s = 0; s < gr.n; ++s) {
+        const int K = gr.k[s];
+        const float* __restrict__ vrow = gr.v[s] + nidx * (int64_t)K;
+        const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
+        for (int k = 0; k < K; ++k) dw += drow[k] * vrow[k];
+      }
+      if (d_weights) d_weights[nidx] = dw;
+    }
+    const int nvalid = min(64, cnt - base);
+    for (int s = 0; s < gr.n; ++s) {
+      if (!gr.dv[s]) continue;
+      const int K = gr.k[s];
+      float* __restrict__ dv = gr.dv[s] + (start + base) * (int64_t)K;
+      const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
+      for (int kc = 0; kc < K; kc += 64) {
+        const int k = kc + lane;
+        const bool kv = k < K;
+        const float d = kv ? drow[k] : 0.0f;
+        for (int j = 0; j < nvalid; ++j) {
+          const float wj = __shfl(w, j, 64);
+          if (kv) dv[(int64_t)j * K + k] = wj * d;
+        }
+      }
+    }
+  }
+}
+
+static int fill_streams(const umhs_value_streams* streams, int64_t n, CompStreams* st) {
+  st->n = streams ? streams->n_streams : 0;
+  if (st->n < 0 || st->n > UMHS_MAX_STREAMS) return UMHS_ERR_ARG;
+  for (int s = 0; s < UMHS_MAX_STREAMS; ++s) {
+    st->k[s] = 0, st->v[s] = nullptr, st->out[s] = nullptr;
+    if (s < st->n) {
+      st->k[s] = streams->k[s], st->v[s] = streams->values[s], st->out[s] = streams->out[s];
+      if (st->k[s] < 1 || !st->out[s] || (n > 0 && !st->v[s])) return UMHS_ERR_ARG;
+    }
+  }
+  return UMHS_OK;
+}
+
+static int fill_grads(const umhs_value_grads* grads, int64_t n, CompGrads* gr) {
+  gr->n = grads ? grads->n_streams : 0;
+  if (gr->n < 0 || gr->n > UMHS_MAX_STREAMS) return UMHS_ERR_ARG;
+  for (int s = 0; s < UMHS_MAX_STREAMS; ++s) {
+    gr->k[s] = 0, gr->v[s] = nullptr, gr->dout[s] = nullptr, gr->dv[s] = nullptr;
+    if (s < gr->n) {
+      gr->k[s] = grads->k[s], gr->v[s] = grads->values[s], gr->dout[s] = grads->d_out[s], gr->dv[s] = grads->d_values[s];
+      if (gr->k[s] < 1 || !gr->dout[s] || (n > 0 && !gr->v[s])) return UMHS_ERR_ARG;
+    }
+  }
+  return UMHS_OK;
+}
+
+extern "C" int umhs_accumulate_fwd(const float* weights, const int64_t* packed_info, int64_t n_rays, int64_t n,
+                                   const umhs_value_streams* streams, umhs_stream_t stream) {
+  if (n_rays < 0 || n < 0 || !packed_info || (n > 0 && !weights)) return UMHS_ERR_ARG;
+  CompStreams st;
+  int rc = fill_streams(streams, n, &st);
+  if (rc) return rc;
+  if (n_rays == 0 || st.n == 0) return UMHS_OK;
+  hipLaunchKernelGGL(accumulate_fwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), weights,
+                     packed_info, n_rays, st);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+extern "C" int umhs_accumulate_bwd(const float* weights, const int64_t* packed_info, int64_t n_rays, int64_t n,
+                                   const umhs_value_grads* grads, float* d_weights, umhs_stream_t stream) {
+  if (n_rays < 0 || n < 0 || !packed_info || (n > 0 && !weights)) return UMHS_ERR_ARG;
+  CompGrads gr;
+  int rc = fill_grads(grads, n, &gr);
+  if (rc) return rc;
+  if (n_rays == 0 || n == 0) return UMHS_OK;
+  hipLaunchKernelGGL(accumulate_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), weights,
+                     packed_info, n_rays, gr, d_weights);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }

@@ -63,6 +63,8 @@ SIGNATURES = {
     "umhs_pack_info": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "umhs_composite_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.POINTER(ValueStreams), _vp, _vp, _vp, _vp]),
     "umhs_composite_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(ValueGrads), _vp, C.c_int, _vp, _vp]),
+    "umhs_accumulate_fwd": (C.c_int, [_vp, _vp, _i64, _i64, C.POINTER(ValueStreams), _vp]),
+    "umhs_accumulate_bwd": (C.c_int, [_vp, _vp, _i64, _i64, C.POINTER(ValueGrads), _vp, _vp]),
     "umhs_spec2rgb_fwd": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "umhs_spec2rgb_bwd": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, C.c_int, _vp]),
     "umhs_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _i64, _i64, _vp]),

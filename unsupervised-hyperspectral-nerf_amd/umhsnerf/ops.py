@@ -343,6 +343,7 @@ class CompositeFn(torch.autograd.Function):
         ctx.save_for_backward(s, t0, t1, packed_info, weights, *vals)
         ctx.grad_scaling = grad_scaling
         ctx.needs = [v.requires_grad for v in values]
+        ctx.vshapes = [v.shape for v in values]
         ctx.mark_non_differentiable(weights, depth)
         return (weights.view(-1, 1), acc.view(-1, 1), depth.view(-1, 1), *outs)
 
@@ -352,6 +353,7 @@ class CompositeFn(torch.autograd.Function):
         d_outs = [(_hip.f32c(g) if g is not None else None) for g in d_outs]
         d_acc = _hip.f32c(d_acc).view(-1) if d_acc is not None else None
         d_sigma, d_values = composite_bwd(s, t0, t1, pinfo, weights, vals, d_outs, ctx.needs, d_acc, ctx.grad_scaling)
+        d_values = [(g.view(shp) if g is not None else None) for g, shp in zip(d_values, ctx.vshapes)]
         return (d_sigma.view(-1, 1), None, None, None, None, *d_values)
 
 
@@ -368,3 +370,33 @@ class Spec2RgbFn(torch.autograd.Function):
     def backward(ctx, d_rgb):
         s, m = ctx.saved_tensors
         return spec2rgb_bwd(s, m, _hip.f32c(d_rgb)), None
+
+
+class AccumulateFn(torch.autograd.Function):
+    """nerfacc.accumulate_along_rays with caller-provided weights (SpectralRenderer.forward stand-alone,
+    umhs_renderer.py:28-30): out[r] = sum_n w[n] v[n].  Differentiable in both weights and values."""
+
+    @staticmethod
+    def forward(ctx, weights, values, packed_info):
+        w, v = _hip.f32c(weights).view(-1), _hip.f32c(values)
+        v = v.view(v.shape[-2], v.shape[-1])
+        R = packed_info.shape[0]
+        out = torch.empty((R, v.shape[1]), device=v.device, dtype=torch.float32)
+        st = _hip.ValueStreams()
+        st.n_streams, st.k[0], st.values[0], st.out[0] = 1, v.shape[1], v.data_ptr(), out.data_ptr()
+        _hip.check(_hip.lib().umhs_accumulate_fwd(ptr(w), ptr(packed_info), R, w.shape[0], C.byref(st), _hip.stream()),
+                   "umhs_accumulate_fwd")
+        ctx.save_for_backward(w, v, packed_info)
+        ctx.shapes = (weights.shape, values.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        w, v, pinfo = ctx.saved_tensors
+        d_out = _hip.f32c(d_out)
+        d_w, d_v = torch.zeros_like(w), torch.empty_like(v)
+        g = _hip.ValueGrads()
+        g.n_streams, g.k[0], g.values[0], g.d_out[0], g.d_values[0] = 1, v.shape[1], v.data_ptr(), d_out.data_ptr(), d_v.data_ptr()
+        _hip.check(_hip.lib().umhs_accumulate_bwd(ptr(w), ptr(pinfo), pinfo.shape[0], w.shape[0], C.byref(g), ptr(d_w),
+                                                  _hip.stream()), "umhs_accumulate_bwd")
+        return d_w.view(ctx.shapes[0]), d_v.view(ctx.shapes[1]), None

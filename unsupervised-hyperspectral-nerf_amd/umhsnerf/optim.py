@@ -1,0 +1,48 @@
+"""Optimizer for param group "fields": torch.optim.Adam semantics (AdamOptimizerConfig(lr=2e-2, eps=1e-15),
+umhs_config.py:59-64) executed by ONE fused HIP launch over the flat parameter buffer, with the
+``clamp_endmembers`` callback (umhs_model.py:568-572) folded into the same pass, and the data-parallel gradient
+reduction (the reference's DDP wrap, umhs_pipeline.py:110-113) as one RCCL all-reduce of the flat gradient."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def exp_decay_lr(step: int, lr_init: float = 2e-2, lr_final: float = 1e-5, max_steps: int = 30000) -> float:
+    """nerfstudio ExponentialDecayScheduler (no warm-up), umhs_config.py:63."""
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
+class UMHSAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 2e-2, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-15,
+                 clamp_range: Tuple[int, int] = (0, 0), lr_final: Optional[float] = None, max_steps: int = 30000):
+        defaults = dict(lr=lr, betas=betas, eps=eps, clamp_range=clamp_range, lr_init=lr, lr_final=lr_final, max_steps=max_steps)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("UMHSAdam works on the flat fp32 'fields' buffer")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                if world > 1 and not getattr(p, "_umhs_grad_reduced", False):
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)  # one 67 MB RCCL all-reduce over xGMI
+                lr = group["lr"]
+                if group["lr_final"] is not None:
+                    lr = exp_decay_lr(st["step"] - 1, group["lr_init"], group["lr_final"], group["max_steps"])
+                ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, group["betas"], group["eps"],
+                              grad_scale=1.0 / world, clamp_range=group["clamp_range"])

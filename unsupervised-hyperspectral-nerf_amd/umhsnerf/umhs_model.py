@@ -1,0 +1,271 @@
+"""UMHSModel -- mirror of the reference's ``umhsnerf/umhs_model.py`` (``UMHSConfig`` :61-119, ``UMHSModel`` :122-620)
+driving the HIP hot path: field -> packed transmittance/compositing over all bands -> spectrum->sRGB -> losses.
+
+Output keys, shapes, loss weights and callbacks follow the reference.  What differs by design:
+  * the four per-stream renderer calls of ``get_outputs`` (:270-304) are ONE compositing launch;
+  * ``scale_gradients_by_distance_squared`` (:241-242) is applied inside the compositing backward;
+  * the sampler is pluggable: nerfacc's CUDA occupancy marcher does not exist on ROCm, so until the HIP marcher
+    lands ``get_outputs`` uses ``PackedUniformSampler``; ``get_outputs_from_samples`` takes any
+    packed samples (this is what the benchmark and tests feed).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Literal, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from ._ns_compat import FieldHeadNames, RayBundle, RaySamples, packed_ray_samples
+from .optim import UMHSAdam
+from .umhs_field import UMHSField
+from .umhs_renderer import SpectralRenderer
+from .utils.clusterprobe import ClusterLookup
+from .utils.spec_to_rgb import ColourSystem
+
+CLASS_COLORS = torch.tensor([
+    [0.49, 0.29, 0.95], [0.29, 0.95, 0.30], [0.95, 0.29, 0.47], [0.29, 0.66, 0.95], [0.86, 0.95, 0.29],
+    [0.85, 0.29, 0.95], [0.29, 0.95, 0.66], [0.95, 0.46, 0.29], [0.29, 0.30, 0.95], [0.50, 0.95, 0.29],
+    [0.95, 0.29, 0.69], [0.29, 0.88, 0.95], [0.95, 0.82, 0.29], [0.63, 0.29, 0.95], [0.29, 0.95, 0.43],
+])  # umhs_model.py:146-162
+
+
+@dataclass
+class UMHSConfig:
+    """``UMHSConfig(InstantNGPModelConfig)``, umhs_model.py:61-119 (same names and defaults)."""
+
+    enable_collider: bool = False
+    collider_params: Optional[Dict[str, float]] = field(default_factory=lambda: {"near_plane": 2.0, "far_plane": 6.0})
+    grid_resolution: Union[int, List[int]] = 128
+    grid_levels: int = 4
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    alpha_thre: float = 0.01
+    cone_angle: float = 0.004
+    render_step_size: Optional[float] = None
+    near_plane: float = 0.05
+    far_plane: float = 1e3
+    use_gradient_scaling: bool = True
+    use_appearance_embedding: bool = True
+    background_color: Literal["random", "black", "white"] = "random"
+    disable_scene_contraction: bool = False
+    implementation: Literal["hip", "tcnn", "torch"] = "hip"
+    method: Literal["rgb", "spectral", "rgb+spectral"] = "rgb+spectral"
+    rgb_loss_weight: float = 1.0
+    spectral_loss_weight: float = 1.0  # unused by the reference's loss too (hard-coded 5, umhs_model.py:369)
+    temperature: float = 0.2
+    pred_dino: bool = False
+    pred_specular: bool = False
+    load_vca: bool = False
+    eval_num_rays_per_chunk: int = 512
+    samples_per_ray: int = 64  # PackedUniformSampler only
+    per_band_outputs: bool = True  # wv_i / residual_i / abundances_i views (umhs_model.py:273-304)
+
+    def setup(self, **kwargs) -> "UMHSModel":
+        return UMHSModel(self, **kwargs)
+
+
+class PackedUniformSampler(nn.Module):
+    """Stand-in for nerfstudio's VolumetricSampler (nerfacc occupancy marcher, umhs_model.py:206-209,229-237) until the
+    HIP marcher exists: S samples per ray with step render_step_size*(1+cone_angle*t), strided over the unit box."""
+
+    def __init__(self, samples_per_ray: int):
+        super().__init__()
+        self.S = samples_per_ray
+
+    @torch.no_grad()
+    def forward(self, ray_bundle: RayBundle, near_plane: float, far_plane: float, render_step_size: float,
+                alpha_thre: float = 0.0, cone_angle: float = 0.0) -> Tuple[RaySamples, Tensor]:
+        o, d = ray_bundle.origins, ray_bundle.directions
+        R, S = o.shape[0], self.S
+        t_near = (o.norm(dim=-1) - 1.3).clamp(min=near_plane)
+        if self.training:
+            t_near = t_near + torch.rand_like(t_near) * render_step_size
+        k = torch.arange(S, device=o.device, dtype=torch.float32)
+        t0 = (t_near[:, None] + k[None, :] * (2.6 / S)).reshape(-1)
+        t1 = t0 + render_step_size * (1 + cone_angle * t0)
+        ray_indices = torch.arange(R, device=o.device).repeat_interleave(S)
+        cam = ray_bundle.camera_indices[ray_indices] if ray_bundle.camera_indices is not None else None
+        return packed_ray_samples(o[ray_indices], d[ray_indices], t0, t1, cam), ray_indices
+
+
+class UMHSModel(nn.Module):
+    """UMHS model (``UMHSModel(NGPModel)``)."""
+
+    def __init__(self, config: UMHSConfig, scene_box=None, num_train_data: int = 1, metadata: Optional[Dict] = None,
+                 seed: Optional[int] = None, **kwargs):
+        super().__init__()
+        self.config = config
+        aabb = getattr(scene_box, "aabb", scene_box)
+        self.scene_aabb_t = torch.as_tensor(aabb if aabb is not None else [[-1, -1, -1], [1, 1, 1]], dtype=torch.float32).reshape(2, 3)
+        self.num_train_data = num_train_data
+        self.kwargs = dict(metadata or kwargs.get("metadata") or {})
+        if "wavelengths" not in self.kwargs or "num_classes" not in self.kwargs:
+            raise KeyError('metadata must carry "wavelengths" and "num_classes" (umhs_model.py:171-172,188-189)')
+        self._seed = seed
+        self.populate_modules()
+
+    def populate_modules(self):
+        c = self.config
+        wl = self.kwargs["wavelengths"]
+        self.step = 0
+        self.register_buffer("class_colors", CLASS_COLORS.clone())
+        if "spectral" in c.method:
+            self.renderer_spectral = SpectralRenderer()
+        self.converter = ColourSystem(bands=wl, cs="sRGB")
+        self.field = UMHSField(
+            aabb=self.scene_aabb_t, num_images=self.num_train_data, implementation=c.implementation,
+            log2_hashmap_size=c.log2_hashmap_size, max_res=c.max_res,
+            spatial_distortion=None if c.disable_scene_contraction else "linf",
+            appearance_embedding_dim=0,  # the reference's inverted flag yields 0 with the default config (:181)
+            method=c.method, wavelengths=len(wl) if "spectral" in c.method else 0, num_classes=self.kwargs["num_classes"],
+            temperature=c.temperature, converter=self.converter, pred_dino=c.pred_dino, pred_specular=c.pred_specular,
+            load_vca=c.load_vca, seed=self._seed,
+        )
+        self.scene_aabb = nn.Parameter(self.scene_aabb_t.flatten(), requires_grad=False)
+        if c.render_step_size is None:
+            c.render_step_size = float(((self.scene_aabb_t[1] - self.scene_aabb_t[0]) ** 2).sum().sqrt() / 1000)
+        self.sampler = PackedUniformSampler(c.samples_per_ray)
+        self.cluster_probe = ClusterLookup(len(wl), self.kwargs["num_classes"])
+        self.background_color = c.background_color
+
+    @property
+    def device(self):
+        return self.field.flat.device
+
+    def label_to_rgb(self, labels: Tensor) -> Tensor:
+        return self.class_colors[labels.long().squeeze(-1)]
+
+    # ---- optimisation surface --------------------------------------------------------------------
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        return {"fields": [self.field.flat]}
+
+    def make_optimizer(self, lr: float = 2e-2, eps: float = 1e-15, lr_final: Optional[float] = 1e-5, max_steps: int = 30000) -> UMHSAdam:
+        L = self.field.layout
+        off, shp = L.entries["endmembers"]
+        return UMHSAdam(self.get_param_groups()["fields"], lr=lr, eps=eps, clamp_range=(off, off + int(np.prod(shp))),
+                        lr_final=lr_final, max_steps=max_steps)
+
+    def clamp_endmembers(self, step: int = 0) -> None:
+        """AFTER_TRAIN_ITERATION callback of the reference (umhs_model.py:568-572); UMHSAdam already fuses it."""
+        with torch.no_grad():
+            self.field.endmembers[:] = self.field.endmembers.clamp(0, 1)
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List:
+        return [("after_train_iteration", self.clamp_endmembers)]
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        c = self.config
+        with torch.no_grad():
+            ray_samples, ray_indices = self.sampler(ray_bundle, c.near_plane, c.far_plane, c.render_step_size, c.alpha_thre, c.cone_angle)
+        return self.get_outputs_from_samples(ray_samples, ray_indices, len(ray_bundle))
+
+    def forward(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        return self.get_outputs(ray_bundle)
+
+    def get_outputs_from_samples(self, ray_samples: RaySamples, ray_indices: Tensor, num_rays: int,
+                                 packed_info: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """Body of ``get_outputs`` after the sampler, umhs_model.py:239-327."""
+        c = self.config
+        fo = self.field(ray_samples)
+        fr = ray_samples.frustums
+        if packed_info is None:
+            packed_info = ops.pack_info(ray_indices, num_rays)
+        values = [fo["spectral"]]
+        if c.pred_specular:
+            values += [fo["spectral2"].detach(), fo["specular"]]  # spectral2 carries no loss in the reference (:373-374)
+        values.append(fo["abundances"])
+        weights, accumulation, depth, *comp = ops.CompositeFn.apply(fo[FieldHeadNames.DENSITY], fr.starts, fr.ends, packed_info,
+                                                                     bool(c.use_gradient_scaling), *values)
+        steps_min, steps_max = torch.aminmax((fr.starts + fr.ends) / 2)
+        outputs: Dict[str, Tensor] = {"accumulation": accumulation, "depth": torch.clip(depth, steps_min, steps_max)}
+        spectral = comp[0]
+        outputs["spectral"] = spectral
+        if c.pred_specular:
+            outputs["spectral2"], outputs["specular"] = comp[1], comp[2]
+        if c.method == "spectral":
+            with torch.no_grad():
+                outputs["rgb"] = self.converter(spectral)
+        else:
+            outputs["rgb"] = self.converter(spectral)
+        outputs["num_samples_per_ray"] = packed_info[:, 1]
+        abund = comp[-1]
+        outputs["abundances"] = abund
+        if c.per_band_outputs:
+            for i in range(spectral.shape[-1]):
+                outputs[f"wv_{i}"] = spectral[..., i]
+            if c.pred_specular:
+                for i in range(spectral.shape[-1]):
+                    outputs[f"residual_{i}"] = comp[2][..., i]
+            for i in range(abund.shape[-1]):
+                outputs[f"abundances_{i}"] = abund[:, i]
+        _, cluster_probs = self.cluster_probe(spectral, alpha=0.2, clusters=self.field.endmembers)
+        outputs["seg_probs"] = cluster_probs
+        with torch.no_grad():
+            acc_if = (accumulation > 0.5).to(accumulation.dtype)
+            arg = cluster_probs.argmax(1)
+            outputs["seg_raw"] = arg * acc_if.squeeze(-1)
+            outputs["seg_pred"] = self.label_to_rgb(arg) * acc_if
+        outputs["weights"] = weights
+        return outputs
+
+    # ---- losses / metrics ----------------------------------------------------------------------------
+    def blend_background_for_loss_computation(self, pred_image, pred_accumulation, gt_image):
+        """nerfstudio RGBRenderer.blend_background_for_loss_computation as called at umhs_model.py:358-362."""
+        if self.background_color == "random":
+            bg = torch.rand_like(pred_image)
+            pred_image = pred_image + bg * (1.0 - pred_accumulation)
+        if gt_image.shape[-1] == 4:
+            bgc = bg if self.background_color == "random" else torch.full_like(pred_image, 1.0 if self.background_color == "white" else 0.0)
+            gt_image = gt_image[..., :3] * gt_image[..., 3:] + bgc * (1 - gt_image[..., 3:])
+        return pred_image, gt_image
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        """umhs_model.py:329-383: 5*MSE(spectral) + rgb_loss_weight*MSE(rgb blended with a random background)."""
+        loss_dict = {}
+        image = batch["image"].to(self.device)
+        pred_rgb, gt_rgb = self.blend_background_for_loss_computation(outputs["rgb"], outputs["accumulation"], image)
+        m = self.config.method
+        if m == "rgb":
+            loss_dict["rgb_loss"] = torch.nn.functional.mse_loss(pred_rgb, gt_rgb)
+        elif m == "spectral":
+            loss_dict["spectral_loss"] = torch.nn.functional.mse_loss(outputs["spectral"], batch["hs_image"].to(self.device))
+        else:
+            loss_dict["spectral_loss"] = 5 * torch.nn.functional.mse_loss(outputs["spectral"], batch["hs_image"].to(self.device))
+            loss_dict["rgb_loss"] = self.config.rgb_loss_weight * torch.nn.functional.mse_loss(pred_rgb, gt_rgb)
+        return loss_dict
+
+    @staticmethod
+    def psnr(pred: Tensor, gt: Tensor) -> Tensor:
+        return 10.0 * torch.log10(1.0 / torch.mean((pred - gt) ** 2))
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        """umhs_model.py:385-405.  Values stay device tensors (the reference's ``.item()`` calls would sync the stream)."""
+        md = {}
+        gt_rgb = batch["image"].to(self.device)[..., :3]
+        md["psnr"] = self.psnr(outputs["rgb"], gt_rgb)
+        md["rmse"] = torch.sqrt(torch.nn.functional.mse_loss(outputs["rgb"], gt_rgb))
+        if "spectral" in self.config.method:
+            gt = batch["hs_image"].to(self.device)
+            md["psnr_spectral"] = self.psnr(outputs["spectral"], gt)
+            md["rmse_spectral"] = torch.sqrt(torch.nn.functional.mse_loss(outputs["spectral"], gt))
+        md["num_samples_per_batch"] = outputs["num_samples_per_ray"].sum()
+        return md
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """umhs_model.py:593-620, chunked by eval_num_rays_per_chunk."""
+        o = camera_ray_bundle.origins
+        hw = o.shape[:-1]
+        flat = RayBundle(origins=o.reshape(-1, 3), directions=camera_ray_bundle.directions.reshape(-1, 3))
+        outs: Dict[str, List[Tensor]] = {}
+        n, ch = flat.origins.shape[0], self.config.eval_num_rays_per_chunk
+        for i in range(0, n, ch):
+            rb = RayBundle(origins=flat.origins[i:i + ch].to(self.device), directions=flat.directions[i:i + ch].to(self.device))
+            for k, v in self.forward(rb).items():
+                if isinstance(v, Tensor) and v.shape[:1] == (len(rb),):
+                    outs.setdefault(k, []).append(v.to(o.device))
+        return {k: torch.cat(v).view(*hw, -1) for k, v in outs.items()}

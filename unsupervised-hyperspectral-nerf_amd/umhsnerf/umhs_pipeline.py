@@ -1,0 +1,45 @@
+"""Pipeline glue (mirror of ``umhsnerf/umhs_pipeline.py``).  The reference forces ``world_size = 1``
+(``:86,108-109``), which silently disables its DDP wrap; here ray batches are sharded one rank per GPU and the flat
+"fields" gradient is all-reduced over RCCL/xGMI inside ``UMHSAdam.step``.
+
+Data managers / parsers / checkpoint I/O are nerfstudio's and out of scope for the hot path."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from ._ns_compat import RaySamples
+from .umhs_model import UMHSConfig, UMHSModel
+
+
+class UMHSPipeline(torch.nn.Module):
+    """Minimal pipeline: model + one train iteration on packed samples (what ``Trainer.train_iteration`` does around
+    ``pipeline.get_train_loss_dict``: forward, loss, backward, optimizer step)."""
+
+    def __init__(self, config: UMHSConfig, device, metadata: Dict, world_size: int = 1, local_rank: int = 0,
+                 seed: Optional[int] = 42, scene_box=None):
+        super().__init__()
+        self.world_size, self.local_rank = world_size, local_rank
+        self._model = UMHSModel(config, scene_box=scene_box, metadata=metadata, seed=seed).to(device)
+        if world_size > 1:  # identical parameters on every rank (DDP's initial broadcast)
+            dist.broadcast(self._model.field.flat.data, src=0)
+        self.optimizer = self._model.make_optimizer()
+
+    @property
+    def model(self) -> UMHSModel:
+        return self._model
+
+    def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None):
+        self.optimizer.zero_grad(set_to_none=True)
+        outputs = self._model.get_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
+        loss_dict = self._model.get_loss_dict(outputs, batch)
+        loss = sum(loss_dict.values())
+        loss.backward()
+        self.optimizer.step()
+        return outputs, loss_dict
+
+
+def make_nerfstudio_trainer_config(defaults):  # pragma: no cover - needs nerfstudio
+    raise NotImplementedError("nerfstudio TrainerConfig wiring is exercised only where nerfstudio is installed")
