@@ -66,12 +66,16 @@ int umhs_positions_fwd(const float* origins, const float* directions, const floa
 /*   stride_n=2L, stride_l=2  -> the reference's [N, L*F] layout;                               */
 /*   stride_n=2,  stride_l=2N -> level-major [L][N][2] (what the fused field kernels prefer).   */
 /* hashgrid_bwd ACCUMULATES into d_table (caller zeroes it): d_table[idx] += w_corner * d_enc.  */
+/* With a workspace (umhs_hashgrid_bwd_workspace_bytes; 0 = not available for this shape) the   */
+/* scatter is atomics-free (radix partition into LDS-sized slot buckets); with workspace ==     */
+/* NULL it falls back to global float atomics (no workspace, ~20x slower at N = 262k).          */
 /* ------------------------------------------------------------------------------------------ */
 int umhs_hashgrid_fwd(const float* pos01, const float* table, const float* scalings, int64_t n, int n_levels,
                       int log2_table_size, float* enc, int64_t stride_n, int64_t stride_l, umhs_stream_t stream);
+size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_table_size);
 int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
                       const float* scalings, int64_t n, int n_levels, int log2_table_size, float* d_table,
-                      umhs_stream_t stream);
+                      void* workspace, size_t workspace_bytes, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* R3-R9, R18: fused per-sample field.  Replaces mlp_base's MLP, NeRFEncoding, SHEncoding,      */

@@ -72,9 +72,10 @@ def test_positions_and_selector():
     assert_close("pos01_aabb", p2, q2 * m2[:, None], 1e-6)
 
 
+@pytest.mark.parametrize("method", ["partition", "atomic"])
 @pytest.mark.parametrize("level_major", [True, False])
 @pytest.mark.parametrize("log2_T", [19, 12])
-def test_hashgrid_fwd_bwd(level_major, log2_T):
+def test_hashgrid_fwd_bwd(level_major, log2_T, method):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
     N = 3000
@@ -92,8 +93,27 @@ def test_hashgrid_fwd_bwd(level_major, log2_T):
     (gref,) = torch.autograd.grad((ref * cot).sum(), table)
     d_enc = cot.view(N, 16, 2).permute(1, 0, 2).contiguous() if level_major else cot
     d_table = torch.zeros_like(table.detach()).to(DEV)
-    ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, level_major)
+    ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, level_major, method=method)
     assert_close("d_table", d_table, gref, 2e-5)
+    # accumulate semantics: a second call doubles the gradient
+    ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, level_major, method=method)
+    assert_close("d_table x2", d_table, 2 * gref, 2e-5)
+
+
+def test_hashgrid_bwd_skewed_all_samples_in_one_cell():
+    """Worst case for the bucket partition: every contribution of the coarse levels lands in 8 slots."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    N, log2_T = 5000, 19
+    x = 0.4 + torch.rand(N, 3, generator=g) * 1e-3
+    table = torch.zeros(16 << log2_T, 2, requires_grad=True)
+    sc = T.hash_scalings()
+    cot = torch.rand(N, 32, generator=g)
+    (gref,) = torch.autograd.grad((T.hash_encode(x, table, sc, log2_T) * cot).sum(), table)
+    d_enc = cot.view(N, 16, 2).permute(1, 0, 2).contiguous()
+    d_table = torch.zeros(16 << log2_T, 2, device=DEV)
+    ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, True, method="partition")
+    assert_close("d_table skew", d_table, gref, 2e-5)
 
 
 CASES = [

@@ -184,15 +184,195 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward v2 (default): atomics-free.  MI355X executes global float atomics at the memory side at
+// ~20 G requests/s whatever the schedule, so 8 corners x 16 levels x N scattered adds cost ~6 ms at
+// N = 262k.  Instead each level's 8N contributions are radix-partitioned by the high bits of their hash
+// slot into buckets of 2^13 slots (64 KiB of fp32 pairs = one LDS tile), every (level, bucket) tile is
+// accumulated in LDS by one workgroup and added to d_table with plain coalesced stores:
+//   count   : per (level, 1024-sample chunk) LDS histogram of bucket ids -> global counts
+//   scan    : exclusive scan of the (level, bucket) counts -> record offsets
+//   scatter : recompute the corners, reserve a contiguous run per (chunk, bucket), store {slot_low, w*g}
+//   reduce  : one workgroup per (level, bucket): stream its records, ds_add_f32 into the LDS tile, flush
+// Record order inside a bucket (hence fp32 summation order) is not deterministic -- as with atomics.
+// ---------------------------------------------------------------------------------------------
+#define HB_BUCKET_BITS 13
+#define HB_SPT 4  // samples per thread -> 1024 samples per workgroup
+
+struct HbArgs {
+  const float* pos01;
+  const float* d_enc;
+  int64_t sn, sl;
+  const float* scalings;
+  int64_t n;
+  int log2_T, bucket_bits, nb, level0;
+  uint32_t *counts, *offsets, *cursor;  // [nlev * nb]
+  uint16_t* rec_idx;                    // [8 * n * nlev]
+  float2* rec_val;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
+  __shared__ uint32_t hist[1 << (24 - HB_BUCKET_BITS) > 64 ? 64 : 64];
+  __shared__ uint32_t base[64];
+  const int tid = threadIdx.x, lev = blockIdx.y, l = a.level0 + lev;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  const float s = a.scalings[l];
+  const uint32_t mask = (1u << a.log2_T) - 1u;
+  uint32_t slot[HB_SPT][8];
+  float2 val[HB_SPT][8];
+  bool act[HB_SPT];
+#pragma unroll
+  for (int k = 0; k < HB_SPT; ++k) {
+    const int64_t i = (int64_t)blockIdx.x * (256 * HB_SPT) + k * 256 + tid;
+    act[k] = false;
+    if (i < a.n) {
+      const float* g = a.d_enc + i * a.sn + (int64_t)l * a.sl;
+      const float g0 = g[0], g1 = g[1];
+      if (g0 != 0.0f || g1 != 0.0f) {
+        act[k] = true;
+        HashCorners h = hash_corners(a.pos01[3 * i], a.pos01[3 * i + 1], a.pos01[3 * i + 2], s, mask, 0u);
+        const float ox = h.ox, oy = h.oy, oz = h.oz, rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
+        float w[8];
+        w[0] = ox * oy * oz, w[3] = rx * oy * oz, w[1] = ox * ry * oz, w[2] = rx * ry * oz;
+        w[4] = ox * oy * rz, w[7] = rx * oy * rz, w[5] = ox * ry * rz, w[6] = rx * ry * rz;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          slot[k][c] = h.idx[c];
+          val[k][c] = make_float2(w[c] * g0, w[c] * g1);
+          atomicAdd(&hist[h.idx[c] >> a.bucket_bits], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!SCATTER) {
+    if (tid < a.nb && hist[tid]) atomicAdd(&a.counts[lev * a.nb + tid], hist[tid]);
+    return;
+  }
+  if (tid < a.nb) {
+    const uint32_t c = hist[tid];
+    base[tid] = c ? atomicAdd(&a.cursor[lev * a.nb + tid], c) : 0u;
+    hist[tid] = 0;
+  }
+  __syncthreads();
+  const uint32_t lowmask = (1u << a.bucket_bits) - 1u;
+#pragma unroll
+  for (int k = 0; k < HB_SPT; ++k) {
+    if (act[k]) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t b = slot[k][c] >> a.bucket_bits;
+        const uint32_t pos = base[b] + atomicAdd(&hist[b], 1u);
+        a.rec_idx[pos] = (uint16_t)(slot[k][c] & lowmask);
+        a.rec_val[pos] = val[k][c];
+      }
+    }
+  }
+}
+
+__global__ void hg_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                               uint32_t* __restrict__ cursor, int m) {
+  // m <= 16 levels x 64 buckets: one wave does a chunked 64-lane scan
+  const int lane = threadIdx.x;
+  uint32_t carry = 0;
+  for (int base = 0; base < m; base += 64) {
+    const int i = base + lane;
+    uint32_t c = i < m ? counts[i] : 0u, incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (i < m) offsets[i] = cursor[i] = carry + incl - c;
+    carry += __shfl(incl, 63, 64);
+  }
+}
+
+__global__ __launch_bounds__(256) void hg_reduce_kernel(HbArgs a, float* __restrict__ d_table) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [2 << bucket_bits]
+  const int tid = threadIdx.x, b = blockIdx.x, lev = blockIdx.y, l = a.level0 + lev;
+  const int nfl = 2 << a.bucket_bits;
+  for (int i = tid * 4; i < nfl; i += 1024) *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const uint32_t start = a.offsets[lev * a.nb + b], cnt = a.counts[lev * a.nb + b];
+  const uint16_t* __restrict__ ri = a.rec_idx + start;
+  const float2* __restrict__ rv = a.rec_val + start;
+  uint32_t i = tid;
+  for (; i + 768 < cnt; i += 1024) {  // 4 records in flight per thread
+    const uint32_t i0 = ri[i], i1 = ri[i + 256], i2 = ri[i + 512], i3 = ri[i + 768];
+    const float2 v0 = rv[i], v1 = rv[i + 256], v2 = rv[i + 512], v3 = rv[i + 768];
+    atomicAdd(&tile[2 * i0], v0.x), atomicAdd(&tile[2 * i0 + 1], v0.y);
+    atomicAdd(&tile[2 * i1], v1.x), atomicAdd(&tile[2 * i1 + 1], v1.y);
+    atomicAdd(&tile[2 * i2], v2.x), atomicAdd(&tile[2 * i2 + 1], v2.y);
+    atomicAdd(&tile[2 * i3], v3.x), atomicAdd(&tile[2 * i3 + 1], v3.y);
+  }
+  for (; i < cnt; i += 256) {
+    const uint32_t i0 = ri[i];
+    const float2 v0 = rv[i];
+    atomicAdd(&tile[2 * i0], v0.x), atomicAdd(&tile[2 * i0 + 1], v0.y);
+  }
+  __syncthreads();
+  if (cnt == 0) return;  // nothing to add to this slab
+  float* dst = d_table + 2 * (((size_t)l << a.log2_T) + ((size_t)b << a.bucket_bits));
+  for (int j = tid * 4; j < nfl; j += 1024) {
+    float4 t = *reinterpret_cast<float4*>(tile + j);
+    float4 d = *reinterpret_cast<float4*>(dst + j);
+    d.x += t.x, d.y += t.y, d.z += t.z, d.w += t.w;
+    *reinterpret_cast<float4*>(dst + j) = d;
+  }
+}
+
+static inline int hb_bucket_bits(int log2_T) { return log2_T < HB_BUCKET_BITS ? log2_T : HB_BUCKET_BITS; }
+
+extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_T) {
+  if (n <= 0 || n_levels < 1 || log2_T < 2) return 0;
+  const int nb = 1 << (log2_T - hb_bucket_bits(log2_T));
+  if (nb > 64) return 0;  // log2_T > 19: only the atomic path is available
+  const size_t m = (size_t)n_levels * nb, cap = (size_t)8 * n * n_levels;
+  return 3 * m * 4 + 256 + cap * 2 + 256 + cap * 8 + 256;
+}
+
 extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
                                  const float* scalings, int64_t n, int n_levels, int log2_T, float* d_table,
-                                 umhs_stream_t stream) {
+                                 void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
   if (n < 0 || !pos01 || !d_enc || !scalings || !d_table) return UMHS_ERR_ARG;
-  if (n_levels < 1 || n_levels > 32 || log2_T < 1 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (n_levels < 1 || n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
   if (n == 0) return UMHS_OK;
-  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
-  hipLaunchKernelGGL(hashgrid_bwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01, d_enc, stride_n, stride_l,
-                     scalings, n, log2_T, d_table);
+  if (!workspace) {  // v1: memory-side float atomics (no workspace needed; fine for small N)
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
+    hipLaunchKernelGGL(hashgrid_bwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01, d_enc, stride_n, stride_l,
+                       scalings, n, log2_T, d_table);
+    UMHS_CHECK_LAUNCH();
+    return UMHS_OK;
+  }
+  const size_t need = umhs_hashgrid_bwd_workspace_bytes(n, n_levels, log2_T);
+  if (need == 0) return UMHS_ERR_UNSUPPORTED;
+  if (workspace_bytes < need || ((uintptr_t)d_table & 15)) return UMHS_ERR_WORKSPACE;
+  if ((size_t)8 * n * n_levels >= ((size_t)1 << 32)) return UMHS_ERR_UNSUPPORTED;
+  HbArgs a;
+  a.pos01 = pos01, a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.scalings = scalings, a.n = n;
+  a.log2_T = log2_T, a.bucket_bits = hb_bucket_bits(log2_T), a.nb = 1 << (log2_T - a.bucket_bits), a.level0 = 0;
+  const size_t m = (size_t)n_levels * a.nb, cap = (size_t)8 * n * n_levels;
+  uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  a.counts = reinterpret_cast<uint32_t*>(p), a.offsets = a.counts + m, a.cursor = a.offsets + m;
+  p = (p + 3 * m * 4 + 255) & ~(uintptr_t)255;
+  a.rec_idx = reinterpret_cast<uint16_t*>(p);
+  p = (p + cap * 2 + 255) & ~(uintptr_t)255;
+  a.rec_val = reinterpret_cast<float2*>(p);
+  if (hipMemsetAsync(a.counts, 0, m * 4, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
+  dim3 pgrid((unsigned)((n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
+  hipLaunchKernelGGL(hg_partition_kernel<false>, pgrid, dim3(256), 0, umhs_s(stream), a);
+  hipLaunchKernelGGL(hg_scan_kernel, dim3(1), dim3(64), 0, umhs_s(stream), (const uint32_t*)a.counts, a.offsets,
+                     a.cursor, (int)m);
+  hipLaunchKernelGGL(hg_partition_kernel<true>, pgrid, dim3(256), 0, umhs_s(stream), a);
+  const size_t lds = (size_t)(2 << a.bucket_bits) * 4;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(hg_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return UMHS_ERR_LAUNCH;
+  hipLaunchKernelGGL(hg_reduce_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(256), lds, umhs_s(stream), a,
+                     d_table);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }

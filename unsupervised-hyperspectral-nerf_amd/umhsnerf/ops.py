@@ -143,11 +143,17 @@ def hashgrid_fwd(pos01, table, scalings, log2_T: int, level_major: bool = True):
     return enc
 
 
-def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True):
+def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, method: str = "auto"):
+    """d_table += scatter(d_enc).  method: "partition" (atomics-free, needs a workspace), "atomic", or "auto"."""
     n = pos01.shape[0]
     sn, sl = enc_strides(n, level_major)
+    nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, NUM_LEVELS, log2_T) if method != "atomic" else 0
+    if method == "partition" and nbytes == 0:
+        raise RuntimeError("partitioned hash-grid backward unavailable for this shape")
+    ws = _workspace(nbytes, pos01.device, slot=1) if nbytes else None
     _hip.check(_hip.lib().umhs_hashgrid_bwd(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, NUM_LEVELS, log2_T,
-                                            ptr(d_table), _hip.stream()), "umhs_hashgrid_bwd")
+                                            ptr(d_table), ptr(ws), ws.numel() if ws is not None else 0, _hip.stream()),
+               "umhs_hashgrid_bwd")
 
 
 def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True):
@@ -177,8 +183,8 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
 _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (device.index or 0, 0)
+def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    key = (device.index or 0, slot)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
