@@ -84,6 +84,7 @@ extern "C" int umhs_positions_fwd(const float* origins, const float* directions,
 struct HashCorners {
   uint32_t idx[8];
   float ox, oy, oz;
+  uint32_t fx, fy, fz, eqx, eqy, eqz;  // floor coordinates and ceil == floor flags (cell identity)
 };
 
 __device__ __forceinline__ HashCorners hash_corners(float px, float py, float pz, float s, uint32_t mask,
@@ -99,6 +100,8 @@ __device__ __forceinline__ HashCorners hash_corners(float px, float py, float pz
   uint32_t xc = (uint32_t)(int)ceilf(sx), yc = (uint32_t)(int)ceilf(sy) * HASH_P1,
            zc = (uint32_t)(int)ceilf(sz) * HASH_P2;
   HashCorners h;
+  h.fx = xf, h.fy = (uint32_t)(int)fy, h.fz = (uint32_t)(int)fz;
+  h.eqx = xc == xf, h.eqy = yc == yf, h.eqz = zc == zf;
   h.ox = sx - fx, h.oy = sy - fy, h.oz = sz - fz;
   // corner order of nerfstudio HashEncoding.pytorch_fwd: 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
   h.idx[0] = ((xc ^ yc ^ zc) & mask) + base;
@@ -185,16 +188,21 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward v2 (default): atomics-free.  MI355X executes global float atomics at the memory side at
+// Backward v2 (default): no global atomics.  MI355X executes global float atomics at the memory side at
 // ~20 G requests/s whatever the schedule, so 8 corners x 16 levels x N scattered adds cost ~6 ms at
-// N = 262k.  Instead each level's 8N contributions are radix-partitioned by the high bits of their hash
-// slot into buckets of 2^13 slots (64 KiB of fp32 pairs = one LDS tile), every (level, bucket) tile is
-// accumulated in LDS by one workgroup and added to d_table with plain coalesced stores:
+// N = 262k.  Instead each level's contributions are radix-partitioned by the high bits of their hash
+// slot into buckets of 2^13 slots, every (level, bucket) tile is accumulated in LDS by one workgroup
+// and added to d_table with plain coalesced stores:
 //   count   : per (level, 1024-sample chunk) LDS histogram of bucket ids -> global counts
 //   scan    : exclusive scan of the (level, bucket) counts -> record offsets
 //   scatter : recompute the corners, reserve a contiguous run per (chunk, bucket), store {slot_low, w*g}
-//   reduce  : one workgroup per (level, bucket): stream its records, ds_add_f32 into the LDS tile, flush
-// Record order inside a bucket (hence fp32 summation order) is not deterministic -- as with atomics.
+//   reduce  : one workgroup per (level, bucket): stream its records into an LDS tile, flush
+// Two MI355X-specific choices (tools/mb_lds_atomics.hip, measured): LDS float atomics cost 3.1 cycles per
+// lane-op per CU but 64-bit INTEGER LDS atomics 1.35, so the tile is int64 fixed point (scale from the level's
+// max |value| and the bucket's record count: >= 46 bits below the level maximum) -- which also makes every
+// sum exact and order-independent, i.e. bitwise reproducible, unlike the reference's index_put_/atomics.
+// And consecutive samples of a ray mostly share a grid cell on the coarse/mid levels, so lanes with the
+// same cell are merged by a wave segmented scan before a record is emitted (2-30x fewer records there).
 // ---------------------------------------------------------------------------------------------
 #define HB_BUCKET_BITS 13
 #define HB_SPT 4  // samples per thread -> 1024 samples per workgroup
@@ -205,46 +213,89 @@ struct HbArgs {
   int64_t sn, sl;
   const float* scalings;
   int64_t n;
-  int log2_T, bucket_bits, nb, level0;
+  int log2_T, bucket_bits, nb, level0, nlev;
   uint32_t *counts, *offsets, *cursor;  // [nlev * nb]
+  uint32_t* lmax;                       // [nlev] bits of the level's max |record value|
   uint16_t* rec_idx;                    // [8 * n * nlev]
   float2* rec_val;
 };
 
+__device__ __forceinline__ void seg_scan_step(float& v, bool take, int d) {
+  const float pv = __shfl_up(v, d, 64);
+  if (take) v += pv;
+}
+
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
-  __shared__ uint32_t hist[1 << (24 - HB_BUCKET_BITS) > 64 ? 64 : 64];
+  __shared__ uint32_t hist[64];
   __shared__ uint32_t base[64];
-  const int tid = threadIdx.x, lev = blockIdx.y, l = a.level0 + lev;
+  __shared__ uint32_t wgmax;
+  const int tid = threadIdx.x, lane = tid & 63, lev = blockIdx.y, l = a.level0 + lev;
   if (tid < 64) hist[tid] = 0;
+  if (tid == 0) wgmax = 0;
   __syncthreads();
   const float s = a.scalings[l];
   const uint32_t mask = (1u << a.log2_T) - 1u;
   uint32_t slot[HB_SPT][8];
   float2 val[HB_SPT][8];
-  bool act[HB_SPT];
+  bool emit[HB_SPT];
+  float vmax = 0.0f;
 #pragma unroll
   for (int k = 0; k < HB_SPT; ++k) {
     const int64_t i = (int64_t)blockIdx.x * (256 * HB_SPT) + k * 256 + tid;
-    act[k] = false;
+    bool act = false;
+    float g0 = 0.0f, g1 = 0.0f;
+    uint32_t kx = 0xffffffffu, ky = 0, kz = 0, kf = 0x80000000u | (uint32_t)lane;  // unique per lane when inactive
+    float w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[c] = 0.0f, slot[k][c] = 0;
     if (i < a.n) {
       const float* g = a.d_enc + i * a.sn + (int64_t)l * a.sl;
-      const float g0 = g[0], g1 = g[1];
+      g0 = g[0], g1 = g[1];
       if (g0 != 0.0f || g1 != 0.0f) {
-        act[k] = true;
-        HashCorners h = hash_corners(a.pos01[3 * i], a.pos01[3 * i + 1], a.pos01[3 * i + 2], s, mask, 0u);
+        act = true;
+        const float px = a.pos01[3 * i], py = a.pos01[3 * i + 1], pz = a.pos01[3 * i + 2];
+        HashCorners h = hash_corners(px, py, pz, s, mask, 0u);
         const float ox = h.ox, oy = h.oy, oz = h.oz, rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
-        float w[8];
         w[0] = ox * oy * oz, w[3] = rx * oy * oz, w[1] = ox * ry * oz, w[2] = rx * ry * oz;
         w[4] = ox * oy * rz, w[7] = rx * oy * rz, w[5] = ox * ry * rz, w[6] = rx * ry * rz;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          slot[k][c] = h.idx[c];
-          val[k][c] = make_float2(w[c] * g0, w[c] * g1);
-          atomicAdd(&hist[h.idx[c] >> a.bucket_bits], 1u);
-        }
+        for (int c = 0; c < 8; ++c) slot[k][c] = h.idx[c];
+        // cell identity: floor coordinates + "coordinate is an exact integer" flags (ceil == floor)
+        kx = h.fx, ky = h.fy, kz = h.fz, kf = h.eqx | (h.eqy << 1) | (h.eqz << 2);
       }
     }
+    // all four shuffles are executed by every lane (no short-circuit: a shuffle under divergent control flow
+    // would read the registers of inactive lanes)
+    const uint32_t px_ = __shfl_up(kx, 1, 64), py_ = __shfl_up(ky, 1, 64), pz_ = __shfl_up(kz, 1, 64), pf_ = __shfl_up(kf, 1, 64);
+    const bool head = (lane == 0) | (px_ != kx) | (py_ != ky) | (pz_ != kz) | (pf_ != kf);
+    const int nhead = __shfl_down((int)head, 1, 64);
+    emit[k] = act && (lane == 63 || nhead);  // tail lane of a run of equal cells emits the run's sum
+    if (SCATTER) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) val[k][c] = make_float2(w[c] * g0, w[c] * g1);
+      bool f = head;  // segmented inclusive scan over the wave: (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv)
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const bool take = lane >= d && !f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) seg_scan_step(val[k][c].x, take, d), seg_scan_step(val[k][c].y, take, d);
+        const int pf = __shfl_up((int)f, d, 64);
+        if (lane >= d) f = f || pf;
+      }
+    }
+    if (emit[k]) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        atomicAdd(&hist[slot[k][c] >> a.bucket_bits], 1u);
+        if (SCATTER) vmax = fmaxf(vmax, fmaxf(fabsf(val[k][c].x), fabsf(val[k][c].y)));
+      }
+    }
+  }
+  if (SCATTER) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+    if (lane == 0 && vmax > 0.0f) atomicMax(&wgmax, __float_as_uint(vmax));
   }
   __syncthreads();
   if (!SCATTER) {
@@ -256,11 +307,12 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
     base[tid] = c ? atomicAdd(&a.cursor[lev * a.nb + tid], c) : 0u;
     hist[tid] = 0;
   }
+  if (tid == 0 && wgmax) atomicMax(&a.lmax[lev], wgmax);
   __syncthreads();
   const uint32_t lowmask = (1u << a.bucket_bits) - 1u;
 #pragma unroll
   for (int k = 0; k < HB_SPT; ++k) {
-    if (act[k]) {
+    if (emit[k]) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint32_t b = slot[k][c] >> a.bucket_bits;
@@ -290,36 +342,43 @@ __global__ void hg_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __
   }
 }
 
-__global__ __launch_bounds__(256) void hg_reduce_kernel(HbArgs a, float* __restrict__ d_table) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [2 << bucket_bits]
+__global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __restrict__ d_table) {
+  extern __shared__ __attribute__((aligned(16))) long long tile[];  // [2 << bucket_bits] int64 fixed point
   const int tid = threadIdx.x, b = blockIdx.x, lev = blockIdx.y, l = a.level0 + lev;
-  const int nfl = 2 << a.bucket_bits;
-  for (int i = tid * 4; i < nfl; i += 1024) *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
   const uint32_t start = a.offsets[lev * a.nb + b], cnt = a.counts[lev * a.nb + b];
+  if (cnt == 0) return;  // nothing to add to this slab (uniform over the workgroup)
+  const int nsl = 2 << a.bucket_bits;
+  for (int i = tid; i < nsl; i += 1024) tile[i] = 0;
+  // fixed-point scale 2^k:  |v| <= vmax < 2^e, at most cnt < 2^hb addends  =>  |sum| * 2^k < 2^62
+  int e;
+  (void)frexpf(__uint_as_float(a.lmax[lev]), &e);
+  const int hb = 33 - __clz(cnt);  // cnt < 2^(32-clz) ; one spare bit
+  const int k = 62 - hb - e;
+  __syncthreads();
   const uint16_t* __restrict__ ri = a.rec_idx + start;
   const float2* __restrict__ rv = a.rec_val + start;
+  typedef unsigned long long u64;
+  u64* ut = reinterpret_cast<u64*>(tile);
   uint32_t i = tid;
-  for (; i + 768 < cnt; i += 1024) {  // 4 records in flight per thread
-    const uint32_t i0 = ri[i], i1 = ri[i + 256], i2 = ri[i + 512], i3 = ri[i + 768];
-    const float2 v0 = rv[i], v1 = rv[i + 256], v2 = rv[i + 512], v3 = rv[i + 768];
-    atomicAdd(&tile[2 * i0], v0.x), atomicAdd(&tile[2 * i0 + 1], v0.y);
-    atomicAdd(&tile[2 * i1], v1.x), atomicAdd(&tile[2 * i1 + 1], v1.y);
-    atomicAdd(&tile[2 * i2], v2.x), atomicAdd(&tile[2 * i2 + 1], v2.y);
-    atomicAdd(&tile[2 * i3], v3.x), atomicAdd(&tile[2 * i3 + 1], v3.y);
+  for (; i + 3072 < cnt; i += 4096) {  // 4 records in flight per thread
+    const uint32_t i0 = ri[i], i1 = ri[i + 1024], i2 = ri[i + 2048], i3 = ri[i + 3072];
+    const float2 v0 = rv[i], v1 = rv[i + 1024], v2 = rv[i + 2048], v3 = rv[i + 3072];
+    atomicAdd(&ut[2 * i0], (u64)__float2ll_rn(ldexpf(v0.x, k))), atomicAdd(&ut[2 * i0 + 1], (u64)__float2ll_rn(ldexpf(v0.y, k)));
+    atomicAdd(&ut[2 * i1], (u64)__float2ll_rn(ldexpf(v1.x, k))), atomicAdd(&ut[2 * i1 + 1], (u64)__float2ll_rn(ldexpf(v1.y, k)));
+    atomicAdd(&ut[2 * i2], (u64)__float2ll_rn(ldexpf(v2.x, k))), atomicAdd(&ut[2 * i2 + 1], (u64)__float2ll_rn(ldexpf(v2.y, k)));
+    atomicAdd(&ut[2 * i3], (u64)__float2ll_rn(ldexpf(v3.x, k))), atomicAdd(&ut[2 * i3 + 1], (u64)__float2ll_rn(ldexpf(v3.y, k)));
   }
-  for (; i < cnt; i += 256) {
+  for (; i < cnt; i += 1024) {
     const uint32_t i0 = ri[i];
     const float2 v0 = rv[i];
-    atomicAdd(&tile[2 * i0], v0.x), atomicAdd(&tile[2 * i0 + 1], v0.y);
+    atomicAdd(&ut[2 * i0], (u64)__float2ll_rn(ldexpf(v0.x, k))), atomicAdd(&ut[2 * i0 + 1], (u64)__float2ll_rn(ldexpf(v0.y, k)));
   }
   __syncthreads();
-  if (cnt == 0) return;  // nothing to add to this slab
   float* dst = d_table + 2 * (((size_t)l << a.log2_T) + ((size_t)b << a.bucket_bits));
-  for (int j = tid * 4; j < nfl; j += 1024) {
-    float4 t = *reinterpret_cast<float4*>(tile + j);
+  for (int j = tid * 4; j < nsl; j += 4096) {
     float4 d = *reinterpret_cast<float4*>(dst + j);
-    d.x += t.x, d.y += t.y, d.z += t.z, d.w += t.w;
+    d.x += (float)ldexp((double)tile[j], -k), d.y += (float)ldexp((double)tile[j + 1], -k);
+    d.z += (float)ldexp((double)tile[j + 2], -k), d.w += (float)ldexp((double)tile[j + 3], -k);
     *reinterpret_cast<float4*>(dst + j) = d;
   }
 }
@@ -331,7 +390,7 @@ extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int
   const int nb = 1 << (log2_T - hb_bucket_bits(log2_T));
   if (nb > 64) return 0;  // log2_T > 19: only the atomic path is available
   const size_t m = (size_t)n_levels * nb, cap = (size_t)8 * n * n_levels;
-  return 3 * m * 4 + 256 + cap * 2 + 256 + cap * 8 + 256;
+  return (3 * m + 64) * 4 + 256 + cap * 2 + 256 + cap * 8 + 256;
 }
 
 extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
@@ -354,24 +413,25 @@ extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t
   HbArgs a;
   a.pos01 = pos01, a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.scalings = scalings, a.n = n;
   a.log2_T = log2_T, a.bucket_bits = hb_bucket_bits(log2_T), a.nb = 1 << (log2_T - a.bucket_bits), a.level0 = 0;
+  a.nlev = n_levels;
   const size_t m = (size_t)n_levels * a.nb, cap = (size_t)8 * n * n_levels;
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
-  a.counts = reinterpret_cast<uint32_t*>(p), a.offsets = a.counts + m, a.cursor = a.offsets + m;
-  p = (p + 3 * m * 4 + 255) & ~(uintptr_t)255;
+  a.counts = reinterpret_cast<uint32_t*>(p), a.lmax = a.counts + m, a.offsets = a.lmax + 64, a.cursor = a.offsets + m;
+  p = (p + (3 * m + 64) * 4 + 255) & ~(uintptr_t)255;
   a.rec_idx = reinterpret_cast<uint16_t*>(p);
   p = (p + cap * 2 + 255) & ~(uintptr_t)255;
   a.rec_val = reinterpret_cast<float2*>(p);
-  if (hipMemsetAsync(a.counts, 0, m * 4, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
+  if (hipMemsetAsync(a.counts, 0, (m + 64) * 4, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;  // counts + lmax
   dim3 pgrid((unsigned)((n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<false>, pgrid, dim3(256), 0, umhs_s(stream), a);
   hipLaunchKernelGGL(hg_scan_kernel, dim3(1), dim3(64), 0, umhs_s(stream), (const uint32_t*)a.counts, a.offsets,
                      a.cursor, (int)m);
   hipLaunchKernelGGL(hg_partition_kernel<true>, pgrid, dim3(256), 0, umhs_s(stream), a);
-  const size_t lds = (size_t)(2 << a.bucket_bits) * 4;
+  const size_t lds = (size_t)(2 << a.bucket_bits) * 8;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(hg_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return UMHS_ERR_LAUNCH;
-  hipLaunchKernelGGL(hg_reduce_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(256), lds, umhs_s(stream), a,
+  hipLaunchKernelGGL(hg_reduce_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(1024), lds, umhs_s(stream), a,
                      d_table);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
