@@ -1,0 +1,79 @@
+"""N>1 path on CPU: two gloo ranks exercise the ray sharding and the flat-gradient all-reduce that bench.py / UMHSAdam
+use over RCCL.  Equivalence checked: averaging per-rank gradients of per-rank ray shards == gradient of the global batch
+(equal shard sizes), and both ranks end with identical parameters after the same Adam step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import torch_ref as T
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from umhsnerf import parallel
+
+        torch.set_num_threads(2)
+        R, S, B, C = 16, 8, 5, 3
+        p = T.FieldParams(C, B, True, log2_hashmap_size=10, table_scale=0.5, seed=3)
+        flat = torch.cat([v.detach().reshape(-1) for v in p.parameters()])
+        parallel.broadcast_params(flat, 0)
+        batch = T.synthetic_batch(R, S, B, seed=5)
+        M = T.colour_matrix(np.linspace(400, 700, B))
+        b0, b1 = parallel.shard_rays(R, rank, world)
+        sel = (batch["ray_indices"] >= b0) & (batch["ray_indices"] < b1)
+        out_ = T.model_outputs(p, batch["origins"][sel], batch["directions"][sel], batch["starts"][sel], batch["ends"][sel],
+                               batch["ray_indices"][sel] - b0, b1 - b0, 0.4, M)
+        loss = 5 * torch.nn.functional.mse_loss(out_["spectral"], batch["gt_spectral"][b0:b1])
+        params = list(p.parameters())
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        g = torch.cat([(gi if gi is not None else torch.zeros_like(v)).reshape(-1) for gi, v in zip(grads, params)])
+        scale = parallel.allreduce_flat_grad(g)
+        assert scale == 1.0 / world
+        g = g * scale
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        T.adam_step([flat], [g], [m], [v], 1, 2e-2)
+        if rank == 0:
+            # single-process gradient of the GLOBAL batch (mean over all rays) must equal the averaged shard gradients
+            og = T.model_outputs(p, batch["origins"], batch["directions"], batch["starts"], batch["ends"], batch["ray_indices"], R, 0.4, M)
+            lg = 5 * torch.nn.functional.mse_loss(og["spectral"], batch["gt_spectral"])
+            gg = torch.autograd.grad(lg, params, allow_unused=True)
+            gg = torch.cat([(gi if gi is not None else torch.zeros_like(v_)).reshape(-1) for gi, v_ in zip(gg, params)])
+            np.testing.assert_allclose(g.numpy(), gg.numpy(), rtol=1e-4, atol=1e-7)
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert torch.equal(gathered[0], gathered[1])  # replicas stay bit-identical
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce_matches_global_batch():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}
+
+
+def test_shard_rays_partitions_exactly():
+    from umhsnerf.parallel import rank_seed, shard_rays
+
+    for R, W in [(4096, 8), (65536, 8), (10, 3), (7, 8)]:
+        sl = [shard_rays(R, r, W) for r in range(W)]
+        assert sl[0][0] == 0 and sl[-1][1] == R and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        assert max(e - b for b, e in sl) - min(e - b for b, e in sl) <= 1
+    assert rank_seed(42, 3) == 45

@@ -8,9 +8,9 @@ import math
 from typing import Optional, Tuple
 
 import torch
-import torch.distributed as dist
 
 from . import ops
+from .parallel import allreduce_flat_grad
 
 
 def exp_decay_lr(step: int, lr_init: float = 2e-2, lr_final: float = 1e-5, max_steps: int = 30000) -> float:
@@ -27,7 +27,6 @@ class UMHSAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -39,10 +38,9 @@ class UMHSAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
                 st["step"] += 1
-                if world > 1 and not getattr(p, "_umhs_grad_reduced", False):
-                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)  # one 67 MB RCCL all-reduce over xGMI
+                grad_scale = allreduce_flat_grad(p.grad)  # one 67 MB RCCL all-reduce over xGMI (no-op at world 1)
                 lr = group["lr"]
                 if group["lr_final"] is not None:
                     lr = exp_decay_lr(st["step"] - 1, group["lr_init"], group["lr_final"], group["max_steps"])
                 ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, group["betas"], group["eps"],
-                              grad_scale=1.0 / world, clamp_range=group["clamp_range"])
+                              grad_scale=grad_scale, clamp_range=group["clamp_range"])
