@@ -121,16 +121,17 @@ int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
                    int64_t n, float* sigma, float* sigma_raw, float* emb, float* spectral, float* spectral2,
                    float* specular, float* abundances, umhs_stream_t stream);
 
-/* Backward (recomputes the forward per tile; nothing but enc is saved).  d_sigma [N] and        */
-/* d_spectral [N,B] are the gradients w.r.t. the forward's sigma / spectral outputs; d_emb_ext    */
-/* [N,15] (optional) is an extra gradient on emb.  Writes d_enc (same strides as enc) and the     */
-/* parameter gradients (OVERWRITTEN, not accumulated).  workspace: umhs_field_bwd_workspace_bytes.*/
+/* Backward.  Recomputes the activations per tile; the only saved forward tensors are enc, sigma_raw [N] and    */
+/* emb [N,15] (both outputs of umhs_field_fwd).  d_sigma [N] and d_spectral [N,B] are the gradients w.r.t. the   */
+/* forward's sigma / spectral outputs; d_emb_ext [N,15] (optional) is an extra gradient on emb.  Writes d_enc     */
+/* (same strides as enc) and the parameter gradients (OVERWRITTEN, not accumulated).                             */
+/* workspace: umhs_field_bwd_workspace_bytes.                                                                    */
 size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int64_t n);
 int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                    int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
-                   int64_t n, const float* d_sigma, const float* d_spectral, const float* d_emb_ext,
-                   float* d_enc, const umhs_field_grads* grads, void* workspace, size_t workspace_bytes,
-                   umhs_stream_t stream);
+                   const float* sigma_raw, const float* emb, int64_t n, const float* d_sigma,
+                   const float* d_spectral, const float* d_emb_ext, float* d_enc, const umhs_field_grads* grads,
+                   void* workspace, size_t workspace_bytes, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* R11: packed transmittance/weights.  Replaces nerfacc.pack_info + render_weight_from_density, */

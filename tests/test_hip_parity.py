@@ -238,6 +238,7 @@ def test_field_bwd(C, B, spec, temp):
     d_flat = torch.zeros_like(flat)
     e = enc.detach().view(N, 16, 2).permute(1, 0, 2).contiguous()
     d_enc = ops.field_bwd(fs, flat, e.to(DEV), True, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV),
+                          sraw.detach().view(-1).contiguous().to(DEV), emb.detach().contiguous().to(DEV),
                           cot_d.view(-1).to(DEV), cot_s.to(DEV), cot_e.to(DEV), d_flat)
     assert_close("d_enc", d_enc.permute(1, 0, 2).reshape(N, 32), d_enc_ref, 5e-5)
     key = {"base_w": "mlp_base.mlp", "head_w": "mlp_head", "feat_w": "feature_mlp", "dir_w": "mlp_directional",

@@ -141,6 +141,8 @@ struct FieldIO {
   // backward
   const float *d_sigma, *d_spectral, *d_emb;
   float* d_enc;
+  const float *emb_in, *sigma_raw_in;  // saved forward outputs (heads / base backward)
+  float* d_bo;                         // [N,16] gradient w.r.t. the base MLP's outputs (heads -> base)
 };
 
 // NeRF positional encoding slots of quarter q (3 per lane) and SH slots (4 per lane)
@@ -343,7 +345,12 @@ __global__ __launch_bounds__(256, 2) void field_fwd_kernel(FieldIO io, PackDesc 
 }
 
 // =============================================================================================
-// Backward: transposed pack images (A operands of the dX chain), built once per call in global memory
+// Backward.  Two kernels so that each fits 2 waves per SIMD (8-wave workgroups, <= 256 VGPRs):
+//   heads: feature_mlp / mlp_head / mlp_directional / mixing.  Reads the forward's saved emb, recomputes the head
+//          activations per 16-sample column tile, runs the dX chain and the dW products, emits d_bo [N,16]
+//          (gradient w.r.t. the base MLP's 16 outputs).
+//   base : mlp_base.  Recomputes its hidden layer from the hash features, consumes d_bo + d_sigma, emits d_enc.
+// Transposed pack images (A operands of the dX chain) are built once per call in global memory (L2-resident).
 // =============================================================================================
 enum TLayerId { T_B1 = 0, T_B0, T_H2, T_H1, T_H0, T_F2, T_F1, T_F0, T_D1, T_MX, NTLAYERS };
 struct TDesc {
@@ -387,46 +394,62 @@ __device__ __forceinline__ void stage_hid(float* st, int FS, int row, int q, con
     *reinterpret_cast<v4f*>(st + row * FS + 16 * t + 4 * q) = v4f{x[4 * t], x[4 * t + 1], x[4 * t + 2], x[4 * t + 3]};
 }
 
-// dW tile pairs of one layer, quarter-split over the 4 waves: pair p = idx*4 + wave, (to,ti) = (p/TI, p%TI)
-//   D[out=16to+4q+r][in=16ti+j] += sum_samples Z[sample][out] * X[sample][in]
-template <int NACC>
+// dW tile pairs of one layer, split over the WAVES waves of the workgroup.  TI divides WAVES, so every pair of a
+// wave shares its X tile (ti = wave % TI, read once per k-step); its Z tiles are to = wave/TI + idx*(WAVES/TI).
+//   D[out=16to+4q+r][in=16ti+j] += sum_samples Z[sample][out] * X[sample][in]        (16*WAVES staged samples)
+template <int NACC, int WAVES>
 __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restrict__ stZ, int FSz,
                                          const float* __restrict__ stX, int FSx, int TO, int TI, int wave, int lane) {
   const int j = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
+  const int ti = wave % TI, to0 = wave / TI, tstep = WAVES / TI;
+  if (to0 >= TO) return;
+  const float* __restrict__ px = stX + q * FSx + 16 * ti + j;
+  const float* __restrict__ pz = stZ + q * FSz + 16 * to0 + j;
+#pragma unroll 8
+  for (int ks = 0; ks < 4 * WAVES; ++ks) {
+    const float b = px[4 * ks * FSx];
 #pragma unroll
     for (int idx = 0; idx < NACC; ++idx) {
-      const int p = idx * 4 + wave;
-      if (p < TO * TI) {
-        const int to = p / TI, ti = p - to * TI;
-        const float a = stZ[(4 * ks + q) * FSz + 16 * to + j];
-        const float b = stX[(4 * ks + q) * FSx + 16 * ti + j];
-        acc[idx] = MFMA(a, b, acc[idx]);
-      }
+      if (to0 + idx * tstep < TO) acc[idx] = MFMA(pz[4 * ks * FSz + 16 * idx * tstep], b, acc[idx]);
     }
   }
 }
 
-__device__ __forceinline__ float col_sum64(const float* __restrict__ st, int FS, int col) {
+// partial column sum of a staged tile: thread -> (column, row group); the slab reduce adds the row groups
+template <int WAVES>
+__device__ __forceinline__ float col_sum_part(const float* __restrict__ st, int FS, int cols, int tid) {
+  constexpr int S = 16 * WAVES, NTH = 64 * WAVES;
+  const int RG = NTH / cols, rg = tid / cols, col = tid - rg * cols;
+  if (rg >= RG) return 0.0f;
+  const int rpg = (S + RG - 1) / RG, r0 = rg * rpg, r1 = min(S, r0 + rpg);
   float s = 0.0f;
-#pragma unroll 8
-  for (int r = 0; r < 64; ++r) s += st[r * FS + col];
+  for (int r = r0; r < r1; ++r) s += st[r * FS + col];
   return s;
+}
+
+// epilogue: fold a per-thread partial bias sum (thread = row group x column) over the row groups in LDS and write
+// the `cols` column totals of layer l to the workgroup's slab
+template <int WAVES>
+__device__ __forceinline__ void flush_db(float v, float* red, float* slab_db, int cols, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  if (tid < cols) {
+    const int RG = (64 * WAVES) / cols;
+    float s = 0.0f;
+    for (int rg = 0; rg < RG; ++rg) s += red[rg * cols + tid];
+    slab_db[tid] = s;
+  }
+  __syncthreads();
 }
 
 // slab layout (floats) of one workgroup's partial parameter gradients
 struct SlabLayout {
-  int off[NLAYERS];   // dW tiles of layer l: [wave 4][nacc][64 lanes][4]
+  int off[NLAYERS];   // dW tiles of layer l: [wave WAVES][nacc][64 lanes][4]
   int nacc[NLAYERS];
   int TO[NLAYERS], TI[NLAYERS];
-  int off_db[NLAYERS];
-  int total;
-};
-
-template <int MT4>
-struct DwAcc {
-  v4f B0[2], B1[1], H0[2], H1[4], H2[1], F0[2], F1[4], F2[1], D0[1], D1[MT4], MX[MT4];
+  int off_db[NLAYERS];  // [64*WAVES] per-thread partial bias sums (thread = row group x column)
+  int cols[NLAYERS];    // padded output width 16*OT (0: layer absent)
+  int waves, total_w, total;
 };
 
 template <int N>
@@ -440,44 +463,38 @@ __device__ __forceinline__ void store_acc(const v4f (&a)[N], float* slab, int of
   for (int i = 0; i < N; ++i) *reinterpret_cast<v4f*>(slab + off + ((wave * N + i) * 64 + lane) * 4) = a[i];
 }
 
-template <bool SPEC, int MT4>
-__global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc pd, TPackDesc td,
-                                                           const float* __restrict__ wT, SlabLayout sl,
-                                                           float* __restrict__ slabs, int stage_off, int FSd) {
+// ---------------------------------------------------------------------------------------------
+// heads
+// ---------------------------------------------------------------------------------------------
+template <bool SPEC, int NA, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(FieldIO io, PackDesc pd, TPackDesc td,
+                                                                               const float* __restrict__ wT, SlabLayout sl,
+                                                                               float* __restrict__ slabs, int stage_off,
+                                                                               int FSd) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   build_fwd_image(lds, pd);
-  float* const st = lds + stage_off;  // staging region
-  constexpr int NT = 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-  const int row = wave * 16 + j;  // sample row of this lane inside the workgroup's 64-sample tile
-  const int tid = threadIdx.x;
-  DwAcc<MT4> A;
-  zero_acc(A.B0), zero_acc(A.B1), zero_acc(A.H0), zero_acc(A.H1), zero_acc(A.H2), zero_acc(A.F0), zero_acc(A.F1);
-  zero_acc(A.F2), zero_acc(A.D0), zero_acc(A.D1), zero_acc(A.MX);
-  float db[NLAYERS];
-#pragma unroll
-  for (int l = 0; l < NLAYERS; ++l) db[l] = 0.0f;
+  float* const st = lds + stage_off;
+  constexpr int NT = 1, S = 16 * WAVES, NH0 = 8 / WAVES, NH1 = 16 / WAVES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int row = wave * 16 + j;
+  v4f aH0[NH0], aH1[NH1], aH2[1], aF0[NH0], aF1[NH1], aF2[1], aD0[1], aD1[NA], aMX[NA];
+  zero_acc(aH0), zero_acc(aH1), zero_acc(aH2), zero_acc(aF0), zero_acc(aF1), zero_acc(aF2), zero_acc(aD0);
+  zero_acc(aD1), zero_acc(aMX);
+  float dbH0 = 0.f, dbH1 = 0.f, dbH2 = 0.f, dbF0 = 0.f, dbF1 = 0.f, dbF2 = 0.f, dbD0 = 0.f, dbD1 = 0.f;
   __syncthreads();
-  const int64_t ntiles = (io.n + 63) / 64;
+  const int64_t ntiles = (io.n + S - 1) / S;
   const int C = io.C, B = io.B, TB = io.TB;
+  float* const stZ = st;            // [S][<=80]
+  float* const stX = st + S * 80;   // [S][<=80]
+  float* const stZd = st;           // [S][FSd]   dZ of mlp_directional's output layer
+  float* const stXh = st + S * FSd; // [S][16]    hidden of mlp_directional
+  float* const stXm = stXh + S * 16;  // [S][16]  mixing coefficients m
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t n0 = tile * 64;
+    const int64_t n0 = tile * S;
     int64_t n = n0 + row;
     const bool ok = n < io.n;
     if (!ok) n = io.n - 1;
-    // =================== forward recompute ======================================================
-    float encf[NT][8];
-#pragma unroll
-    for (int lv = 0; lv < 4; ++lv) {
-      const float2 v = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
-      encf[0][2 * lv] = v.x, encf[0][2 * lv + 1] = v.y;
-    }
-    v4f t4[NT][4];
-    float h[NT][16];
-    gemm_pack<4, 8, NT, true>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
-    relu_to<4, NT>(h, t4);
-    v4f bo4[NT][1];
-    gemm_pack<1, 16, NT, true>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+    // =================== forward recompute of the heads (base-MLP output comes from the forward pass) ========
     float in27[NT][7], dir28[NT][7];
     {
       float pe[3];
@@ -485,7 +502,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
 #pragma unroll
       for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) in27[0][3 + r] = bo4[0][0][r];
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r - 1;
+        in27[0][3 + r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) has zero weight
+      }
       if (SPEC) {
         float sh[4];
         sh_slots(sh, io.dirs[3 * n], io.dirs[3 * n + 1], io.dirs[3 * n + 2], q);
@@ -496,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
       }
     }
     float a1h[NT][16], a2h[NT][16], a1f[NT][16], a2f[NT][16];
-    v4f hd4[NT][1], fl4[NT][1];
+    v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
     gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
     relu_to<4, NT>(a1h, t4);
     gemm_pack<4, 16, NT, true>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
@@ -516,9 +536,6 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
       relu_to<1, NT>(hdir, d4);
     }
     // =================== phase A: band tiles (mixing + specular tail) ============================
-    float* const stZd = st;                  // [64][FSd]   dZ of mlp_directional's output layer
-    float* const stXh = st + 64 * FSd;       // [64][16]    hidden of mlp_directional
-    float* const stXm = stXh + 64 * 16;      // [64][16]    mixing coefficients m
     v4f dm4[NT][1], dhd4[NT][1];
     dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
@@ -551,20 +568,22 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
     ds1 = xq_sum(ds1);
     __syncthreads();
     if (SPEC) {
-      dw_accum<MT4>(A.D1, stZd, FSd, stXh, 16, TB, 1, wave, lane);
-      if (tid < 16 * TB) db[L_D1] += col_sum64(stZd, FSd, tid);
+      dw_accum<NA, WAVES>(aD1, stZd, FSd, stXh, 16, TB, 1, wave, lane);
+      dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
     }
-    {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: rows are samples)
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
+    {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: its rows are samples)
+      const float* __restrict__ pm = stXm + q * 16 + j;
+#pragma unroll 8
+      for (int ks = 0; ks < 4 * WAVES; ++ks) {
         const int64_t ns = n0 + 4 * ks + q;
+        const float bm = pm[4 * ks * 16];
 #pragma unroll
-        for (int idx = 0; idx < MT4; ++idx) {
-          const int to = idx * 4 + wave;
+        for (int idx = 0; idx < NA; ++idx) {
+          const int to = wave + idx * WAVES;
           if (to < TB) {
             const int b = 16 * to + j;
             const float a = (ns < io.n && b < B) ? io.d_spectral[ns * B + b] : 0.0f;
-            A.MX[idx] = MFMA(a, stXm[(4 * ks + q) * 16 + j], A.MX[idx]);
+            aMX[idx] = MFMA(a, bm, aMX[idx]);
           }
         }
       }
@@ -591,8 +610,6 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
         if (c >= C) dhs[0][r] = 0.0f;
       }
     }
-    float* const stZ = st;             // [64][<=80]
-    float* const stX = st + 64 * 80;   // [64][<=80]
     if (SPEC) {  // mlp_directional hidden layer: dZ = d_hd * [hd > 0]; X = dir28 (staging order = reference order)
       float dz[4];
 #pragma unroll
@@ -604,20 +621,21 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
       for (int s = 0; s < 3; ++s) stX[row * 48 + 16 + 3 * q + s] = dir28[0][4 + s];
       if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       __syncthreads();
-      dw_accum<1>(A.D0, stZ, 16, stX, 48, 1, 2, wave, lane);
-      if (tid < 16) db[L_D0] += col_sum64(stZ, 16, tid);
+      dw_accum<1, WAVES>(aD0, stZ, 16, stX, 48, 1, 2, wave, lane);
+      dbD0 += col_sum_part<WAVES>(stZ, 16, 16, tid);
     }
     v4f dbo4[NT][1];
     dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     // one 27->64->64->out MLP (head or feature): dW for its three layers, dX down to the base-MLP slots
     auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f(&acc2)[1],
-                        v4f(&acc1)[4], v4f(&acc0)[2], int l2, int l1, int l0, int t2, int t1, int t0) __attribute__((always_inline)) {
+                        v4f(&acc1)[NH1], v4f(&acc0)[NH0], float& db2, float& db1, float& db0, int t2, int t1,
+                        int t0) __attribute__((always_inline)) {
       __syncthreads();
       *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
       stage_hid<4>(stX, 80, row, q, a2[0]);
       __syncthreads();
-      dw_accum<1>(acc2, stZ, 16, stX, 80, 1, 4, wave, lane);
-      if (tid < 16) db[l2] += col_sum64(stZ, 16, tid);
+      dw_accum<1, WAVES>(acc2, stZ, 16, stX, 80, 1, 4, wave, lane);
+      db2 += col_sum_part<WAVES>(stZ, 16, 16, tid);
       v4f g4[NT][4];
       gemm_pack<4, 4, NT, true>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
       float dz1[NT][16];
@@ -627,8 +645,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
       stage_hid<4>(stZ, 80, row, q, dz1[0]);
       stage_hid<4>(stX, 80, row, q, a1[0]);
       __syncthreads();
-      dw_accum<4>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
-      if (tid < 64) db[l1] += col_sum64(stZ, 80, tid);
+      dw_accum<NH1, WAVES>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
+      db1 += col_sum_part<WAVES>(stZ, 80, 64, tid);
       gemm_pack<4, 16, NT, true>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
       float dz0[NT][16];
 #pragma unroll
@@ -641,31 +659,88 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
       *reinterpret_cast<v4f*>(stX + row * 48 + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
       if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       __syncthreads();
-      dw_accum<2>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
-      if (tid < 64) db[l0] += col_sum64(stZ, 80, tid);
+      dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
+      db0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
       gemm_pack<1, 16, NT, false>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
     };
-    mlp3_bwd(dhs, a2h, a1h, A.H2, A.H1, A.H0, L_H2, L_H1, L_H0, T_H2, T_H1, T_H0);
-    mlp3_bwd(dfl, a2f, a1f, A.F2, A.F1, A.F0, L_F2, L_F1, L_F0, T_F2, T_F1, T_F0);
-    // =================== base MLP ====================================================================
-    float dzb1[NT][4];
+    mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
+    mlp3_bwd(dfl, a2f, a1f, aF2, aF1, aF0, dbF2, dbF1, dbF0, T_F2, T_F1, T_F0);
+    if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
+  }
+  float* const slab = slabs + (size_t)blockIdx.x * sl.total;
+  store_acc(aH0, slab, sl.off[L_H0], wave, lane), store_acc(aH1, slab, sl.off[L_H1], wave, lane);
+  store_acc(aH2, slab, sl.off[L_H2], wave, lane), store_acc(aF0, slab, sl.off[L_F0], wave, lane);
+  store_acc(aF1, slab, sl.off[L_F1], wave, lane), store_acc(aF2, slab, sl.off[L_F2], wave, lane);
+  store_acc(aD0, slab, sl.off[L_D0], wave, lane), store_acc(aD1, slab, sl.off[L_D1], wave, lane);
+  store_acc(aMX, slab, sl.off[L_MX], wave, lane);
+  __syncthreads();  // staging region is free: reuse it for the bias fold
+  flush_db<WAVES>(dbH0, st, slab + sl.off_db[L_H0], sl.cols[L_H0], tid);
+  flush_db<WAVES>(dbH1, st, slab + sl.off_db[L_H1], sl.cols[L_H1], tid);
+  flush_db<WAVES>(dbH2, st, slab + sl.off_db[L_H2], sl.cols[L_H2], tid);
+  flush_db<WAVES>(dbF0, st, slab + sl.off_db[L_F0], sl.cols[L_F0], tid);
+  flush_db<WAVES>(dbF1, st, slab + sl.off_db[L_F1], sl.cols[L_F1], tid);
+  flush_db<WAVES>(dbF2, st, slab + sl.off_db[L_F2], sl.cols[L_F2], tid);
+  if (SPEC) {
+    flush_db<WAVES>(dbD0, st, slab + sl.off_db[L_D0], sl.cols[L_D0], tid);
+    flush_db<WAVES>(dbD1, st, slab + sl.off_db[L_D1], sl.cols[L_D1], tid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// base
+// ---------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(FieldIO io, PackDesc pd, TPackDesc td,
+                                                                              const float* __restrict__ wT, SlabLayout sl,
+                                                                              float* __restrict__ slabs, int stage_off) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  build_fwd_image(lds, pd);
+  float* const st = lds + stage_off;
+  constexpr int NT = 1, S = 16 * WAVES, NB0 = 8 / WAVES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int row = wave * 16 + j;
+  v4f aB0[NB0], aB1[1];
+  zero_acc(aB0), zero_acc(aB1);
+  float dbB0 = 0.f, dbB1 = 0.f;
+  __syncthreads();
+  float* const stZ = st;
+  float* const stX = st + S * 80;
+  const int64_t ntiles = (io.n + S - 1) / S;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t n = tile * S + row;
+    const bool ok = n < io.n;
+    if (!ok) n = io.n - 1;
+    float encf[NT][8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float g = dbo4[0][0][r];
-      const int e = 4 * q + r - 1;
-      if (io.d_emb && ok && e >= 0) g += io.d_emb[n * 15 + e];
-      dzb1[0][r] = g;
+    for (int lv = 0; lv < 4; ++lv) {
+      const float2 v = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
+      encf[0][2 * lv] = v.x, encf[0][2 * lv + 1] = v.y;
     }
-    if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
-      const float raw = bo4[0][0][0];
-      dzb1[0][0] = ok ? io.d_sigma[n] * io.sel[n] * expf(fminf(fmaxf(raw, -15.0f), 15.0f)) : 0.0f;
+    v4f t4[NT][4];
+    float h[NT][16];
+    gemm_pack<4, 8, NT, true>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+    relu_to<4, NT>(h, t4);
+    float dzb1[NT][4];
+    {
+      const v4f g = ok ? *reinterpret_cast<const v4f*>(io.d_bo + n * 16 + 4 * q) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float gr = g[r];
+        const int e = 4 * q + r - 1;
+        if (io.d_emb && ok && e >= 0) gr += io.d_emb[n * 15 + e];
+        dzb1[0][r] = gr;
+      }
+      if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
+        const float raw = io.sigma_raw_in[n];
+        dzb1[0][0] = ok ? io.d_sigma[n] * io.sel[n] * expf(fminf(fmaxf(raw, -15.0f), 15.0f)) : 0.0f;
+      }
     }
     __syncthreads();
     *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzb1[0][0], dzb1[0][1], dzb1[0][2], dzb1[0][3]};
     stage_hid<4>(stX, 80, row, q, h[0]);
     __syncthreads();
-    dw_accum<1>(A.B1, stZ, 16, stX, 80, 1, 4, wave, lane);
-    if (tid < 16) db[L_B1] += col_sum64(stZ, 16, tid);
+    dw_accum<1, WAVES>(aB1, stZ, 16, stX, 80, 1, 4, wave, lane);
+    dbB1 += col_sum_part<WAVES>(stZ, 16, 16, tid);
     v4f g4[NT][4];
     gemm_pack<4, 4, NT, true>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
     float dzb0[NT][16];
@@ -676,8 +751,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
     *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q) = v4f{encf[0][0], encf[0][1], encf[0][2], encf[0][3]};
     *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q + 4) = v4f{encf[0][4], encf[0][5], encf[0][6], encf[0][7]};
     __syncthreads();
-    dw_accum<2>(A.B0, stZ, 80, stX, 48, 4, 2, wave, lane);
-    if (tid < 64) db[L_B0] += col_sum64(stZ, 80, tid);
+    dw_accum<NB0, WAVES>(aB0, stZ, 80, stX, 48, 4, 2, wave, lane);
+    dbB0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
     v4f de4[NT][2];
     gemm_pack<2, 16, NT, true>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
     if (ok && io.d_enc) {
@@ -691,17 +766,11 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldIO io, PackDesc 
         }
     }
   }
-  // =================== partial slabs ==================================================================
   float* const slab = slabs + (size_t)blockIdx.x * sl.total;
-  store_acc(A.B0, slab, sl.off[L_B0], wave, lane), store_acc(A.B1, slab, sl.off[L_B1], wave, lane);
-  store_acc(A.H0, slab, sl.off[L_H0], wave, lane), store_acc(A.H1, slab, sl.off[L_H1], wave, lane);
-  store_acc(A.H2, slab, sl.off[L_H2], wave, lane), store_acc(A.F0, slab, sl.off[L_F0], wave, lane);
-  store_acc(A.F1, slab, sl.off[L_F1], wave, lane), store_acc(A.F2, slab, sl.off[L_F2], wave, lane);
-  store_acc(A.D0, slab, sl.off[L_D0], wave, lane), store_acc(A.D1, slab, sl.off[L_D1], wave, lane);
-  store_acc(A.MX, slab, sl.off[L_MX], wave, lane);
-#pragma unroll
-  for (int l = 0; l < NLAYERS; ++l)
-    if (l != L_MX && tid < 16 * pd.L[l].OT) slab[sl.off_db[l] + tid] = db[l];
+  store_acc(aB0, slab, sl.off[L_B0], wave, lane), store_acc(aB1, slab, sl.off[L_B1], wave, lane);
+  __syncthreads();
+  flush_db<WAVES>(dbB0, st, slab + sl.off_db[L_B0], sl.cols[L_B0], tid);
+  flush_db<WAVES>(dbB1, st, slab + sl.off_db[L_B1], sl.cols[L_B1], tid);
 }
 
 // ---- sum the per-workgroup slabs and scatter into the reference-layout gradient tensors ------------
@@ -717,22 +786,30 @@ __device__ __forceinline__ int stage_col_to_in(int kind, int col) {
 }
 
 __global__ __launch_bounds__(256) void field_reduce_kernel(const float* __restrict__ slabs, int nslabs, SlabLayout sl,
-                                                           PackDesc pd, GradPtrs gp) {
+                                                           PackDesc pd, GradPtrs gp, int n_bias_items) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= sl.total) return;
+  if (idx >= sl.total_w + n_bias_items) return;
+  if (idx >= sl.total_w) {  // bias item: (layer, output) -> sum over workgroups and row groups
+    int o = idx - sl.total_w, l = 0;
+    while (l < NLAYERS && o >= sl.cols[l]) o -= sl.cols[l], ++l;
+    if (l >= NLAYERS || l == L_MX) return;
+    float s = 0.0f;
+    for (int w = 0; w < nslabs; ++w) s += slabs[(size_t)w * sl.total + sl.off_db[l] + o];
+    if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
+    return;
+  }
   float s = 0.0f;
   for (int w = 0; w < nslabs; ++w) s += slabs[(size_t)w * sl.total + idx];
-  // which entry is this?
   for (int l = 0; l < NLAYERS; ++l) {
     const LayerDesc& L = pd.L[l];
-    const int nw = 4 * sl.nacc[l] * 256;
+    const int nw = sl.waves * sl.nacc[l] * 256;
     if (idx >= sl.off[l] && idx < sl.off[l] + nw) {
       const int rel = idx - sl.off[l];
       const int r = rel & 3, ln = (rel >> 2) & 63, blk = rel >> 8;
       const int wave = blk / sl.nacc[l], i = blk % sl.nacc[l];
-      const int p = i * 4 + wave;
-      if (p >= sl.TO[l] * sl.TI[l]) return;
-      const int to = p / sl.TI[l], ti = p % sl.TI[l];
+      const int TI = sl.TI[l];
+      const int to = wave / TI + i * (sl.waves / TI), ti = wave % TI;
+      if (to >= sl.TO[l]) return;
       const int out = 16 * to + 4 * (ln >> 4) + r, col = 16 * ti + (ln & 15);
       if (l == L_MX) {  // slab holds dE^T[b][c]
         if (out < L.OUT && col < L.IN && gp.W[l]) gp.W[l][(size_t)col * L.OUT + out] = s;
@@ -740,11 +817,6 @@ __global__ __launch_bounds__(256) void field_reduce_kernel(const float* __restri
       }
       const int in = stage_col_to_in(L.kind, col);
       if (out < L.OUT && in >= 0 && in < L.IN && gp.W[l]) gp.W[l][(size_t)out * L.IN + in] = s;
-      return;
-    }
-    if (l != L_MX && idx >= sl.off_db[l] && idx < sl.off_db[l] + 16 * L.OT) {
-      const int o = idx - sl.off_db[l];
-      if (o < L.OUT && gp.b[l]) gp.b[l][o] = s;
       return;
     }
   }
@@ -755,7 +827,8 @@ __global__ __launch_bounds__(256) void field_reduce_kernel(const float* __restri
 // =============================================================================================
 static int round16(int x) { return (x + 15) & ~15; }
 
-static int build_pack_desc(const umhs_field_cfg* cfg, const umhs_field_params* p, PackDesc* pd, int* TB_out) {
+static int build_pack_desc(const umhs_field_cfg* cfg, const umhs_field_params* p, PackDesc* pd, int* TB_out, int part = 0) {
+  // part 0: every layer, 1: mlp_base only, 2: heads only (backward kernels)
   const int B = cfg->n_bands, C = cfg->n_classes, spec = cfg->pred_specular != 0, dens = cfg->density_only != 0;
   const int TB = dens ? 0 : (B + 15) / 16;
   *TB_out = TB;
@@ -776,6 +849,8 @@ static int build_pack_desc(const umhs_field_cfg* cfg, const umhs_field_params* p
   set(L_D0, p->dir_w0, p->dir_b0, IN_DIR28, 7, 1 * d, 16, 28);
   set(L_D1, p->dir_w1, p->dir_b1, IN_HID16, 4, TB * d, B, 16);
   set(L_MX, p->endmembers, nullptr, IN_MIX, 4, TB * h, B, C);  // "W" = E [C][B]: OUT = B, IN = C
+  for (int l = 0; l < NLAYERS; ++l)
+    if ((part == 1 && l > L_B1) || (part == 2 && l <= L_B1)) pd->L[l].OT = 0;
   int off = 0;
   for (int l = 0; l < NLAYERS; ++l) {
     pd->L[l].off_w = off;
@@ -852,9 +927,42 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   return UMHS_OK;
 }
 
-static void build_bwd_layouts(const umhs_field_cfg* cfg, const umhs_field_params* p, const PackDesc& pd, int TB,
-                              TPackDesc* td, SlabLayout* sl, int* MT4, int* FSd, int* stage_floats) {
+struct BwdPlan {
+  int TB, waves, NA, FSd, S;
+  PackDesc pd_heads, pd_base;
+  TPackDesc td;
+  SlabLayout sl;
+  int n_bias_items;
+  int stage_off_h, stage_off_b;
+  size_t lds_h, lds_b;
+};
+
+static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p, BwdPlan* pl) {
   const int B = cfg->n_bands, C = cfg->n_classes, spec = cfg->pred_specular != 0;
+  int TB;
+  int rc = build_pack_desc(cfg, p, &pl->pd_heads, &TB, 2);
+  if (rc) return rc;
+  rc = build_pack_desc(cfg, p, &pl->pd_base, &TB, 1);
+  if (rc) return rc;
+  pl->TB = TB;
+  pl->FSd = (TB & 1) ? 16 * TB : 16 * TB + 16;
+  auto stage_floats = [&](int S) {
+    const int tail = S * pl->FSd + 2 * S * 16;
+    return tail > 2 * S * 80 ? tail : 2 * S * 80;
+  };
+  pl->stage_off_h = (pl->pd_heads.total + 3) & ~3;
+  pl->stage_off_b = (pl->pd_base.total + 3) & ~3;
+  pl->waves = 8;
+  if ((size_t)(pl->stage_off_h + stage_floats(128)) * 4 > 160 * 1024 || TB > 8) pl->waves = 4;
+  pl->S = 16 * pl->waves;
+  pl->lds_h = (size_t)(pl->stage_off_h + stage_floats(pl->S)) * 4;
+  pl->lds_b = (size_t)(pl->stage_off_b + 2 * pl->S * 80) * 4;
+  if (pl->lds_h > 160 * 1024) return UMHS_ERR_UNSUPPORTED;
+  pl->NA = (TB + pl->waves - 1) / pl->waves;
+  if (pl->waves == 8 ? pl->NA != 1 : (pl->NA < 1 || pl->NA > 4)) return UMHS_ERR_UNSUPPORTED;
+  if (pl->waves == 4 && pl->NA == 1) pl->NA = 2;  // only NA in {2,3,4} is instantiated for 4-wave workgroups
+
+  TPackDesc* td = &pl->td;
   auto sett = [&](int l, const float* W, int OUT, int IN, int KS, int OT, int rowmap) {
     td->L[l].W = W, td->L[l].OUT = OUT, td->L[l].IN = IN, td->L[l].KS = KS, td->L[l].OT = OT, td->L[l].rowmap = rowmap;
   };
@@ -874,98 +982,118 @@ static void build_bwd_layouts(const umhs_field_cfg* cfg, const umhs_field_params
     off += td->L[l].OT * ((td->L[l].KS + 3) / 4) * 256;
   }
   td->total = off;
-  *MT4 = (TB + 3) / 4;
+
+  SlabLayout* sl = &pl->sl;
+  const int W = pl->waves;
   const int TOs[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1, 1, TB, TB};
   const int TIs[NLAYERS] = {2, 4, 2, 4, 4, 2, 4, 4, 2, 1, 1};
-  const int naccs[NLAYERS] = {2, 1, 2, 4, 1, 2, 4, 1, 1, *MT4, *MT4};
+  const int naccs[NLAYERS] = {8 / W, 1, 8 / W, 16 / W, 1, 8 / W, 16 / W, 1, 1, pl->NA, pl->NA};
+  const int OTs[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1, spec ? 1 : 0, spec ? TB : 0, 0};
   off = 0;
   for (int l = 0; l < NLAYERS; ++l) {
     sl->TO[l] = TOs[l], sl->TI[l] = TIs[l], sl->nacc[l] = naccs[l], sl->off[l] = off;
-    off += 4 * naccs[l] * 256;
+    off += W * naccs[l] * 256;
   }
+  sl->total_w = off;
+  pl->n_bias_items = 0;
   for (int l = 0; l < NLAYERS; ++l) {
     sl->off_db[l] = off;
-    if (l != L_MX) off += 16 * pd.L[l].OT;
+    sl->cols[l] = 16 * OTs[l];
+    pl->n_bias_items += sl->cols[l];
+    if (l != L_MX) off += 64 * W;
   }
+  sl->waves = W;
   sl->total = (off + 3) & ~3;
-  *FSd = (TB & 1) ? 16 * TB : 16 * TB + 16;
-  const int tail = 64 * (*FSd) + 2 * 64 * 16;
-  *stage_floats = tail > 2 * 64 * 80 ? tail : 2 * 64 * 80;
+  return UMHS_OK;
 }
 
-static unsigned bwd_grid(int64_t n) {
-  const int64_t ntiles = (n + 63) / 64;
+static unsigned bwd_grid(int64_t n, int S) {
+  const int64_t ntiles = (n + S - 1) / S;
   return (unsigned)(ntiles < 256 ? ntiles : 256);
+}
+
+static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
+  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 16) * 4 + 512;
 }
 
 extern "C" size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int64_t n) {
   if (check_cfg(cfg) || cfg->density_only || n <= 0) return 0;
   umhs_field_params dummy = {};
-  PackDesc pd;
-  int TB;
   const float one = 0.0f;
   const float** pp = reinterpret_cast<const float**>(&dummy);
   for (size_t i = 0; i < sizeof(dummy) / sizeof(float*); ++i) pp[i] = &one;  // layout only, never dereferenced
-  if (build_pack_desc(cfg, &dummy, &pd, &TB)) return 0;
-  TPackDesc td;
-  SlabLayout sl;
-  int MT4, FSd, stage;
-  build_bwd_layouts(cfg, &dummy, pd, TB, &td, &sl, &MT4, &FSd, &stage);
-  return ((size_t)td.total + (size_t)bwd_grid(n) * sl.total) * 4 + 256;
+  BwdPlan pl;
+  if (build_bwd_plan(cfg, &dummy, &pl)) return 0;
+  return bwd_workspace_need(pl, n);
 }
 
 extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
                               int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
-                              const float* selector, int64_t n, const float* d_sigma, const float* d_spectral,
-                              const float* d_emb_ext, float* d_enc, const umhs_field_grads* grads, void* workspace,
-                              size_t workspace_bytes, umhs_stream_t stream) {
+                              const float* selector, const float* sigma_raw, const float* emb, int64_t n,
+                              const float* d_sigma, const float* d_spectral, const float* d_emb_ext, float* d_enc,
+                              const umhs_field_grads* grads, void* workspace, size_t workspace_bytes,
+                              umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
-  if (!params || !enc || !selector || !world_pos || !d_sigma || !d_spectral || !grads || n < 0) return UMHS_ERR_ARG;
+  if (!params || !enc || !selector || !world_pos || !sigma_raw || !emb || !d_sigma || !d_spectral || !grads || n < 0)
+    return UMHS_ERR_ARG;
   const bool spec = cfg->pred_specular != 0;
   if (spec && !directions) return UMHS_ERR_ARG;
   if ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7) || ((uintptr_t)d_enc & 7)) return UMHS_ERR_ARG;
   if (n == 0) return UMHS_OK;
-  PackDesc pd;
-  int TB;
-  rc = build_pack_desc(cfg, params, &pd, &TB);
+  BwdPlan pl;
+  rc = build_bwd_plan(cfg, params, &pl);
   if (rc) return rc;
-  TPackDesc td;
-  SlabLayout sl;
-  int MT4, FSd, stage_floats;
-  build_bwd_layouts(cfg, params, pd, TB, &td, &sl, &MT4, &FSd, &stage_floats);
-  if (MT4 > 3) return UMHS_ERR_UNSUPPORTED;  // n_bands <= 192 in the backward
-  const unsigned grid = bwd_grid(n);
-  const size_t need = ((size_t)td.total + (size_t)grid * sl.total) * 4 + 256;
-  if (!workspace || workspace_bytes < need) return UMHS_ERR_WORKSPACE;
+  const unsigned grid = bwd_grid(n, pl.S);
+  if (!workspace || workspace_bytes < bwd_workspace_need(pl, n)) return UMHS_ERR_WORKSPACE;
   float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  float* slabs = wT + td.total;
-  hipLaunchKernelGGL(field_pack_T_kernel, dim3((td.total + 255) / 256), dim3(256), 0, umhs_s(stream), td, wT);
+  float* slabs = wT + ((pl.td.total + 63) & ~63);
+  float* d_bo = slabs + (((size_t)grid * pl.sl.total + 63) & ~(size_t)63);
+  hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
   UMHS_CHECK_LAUNCH();
   FieldIO io = {};
   io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
-  io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
+  io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = pl.TB, io.temperature = cfg->temperature;
   io.d_sigma = d_sigma, io.d_spectral = d_spectral, io.d_emb = d_emb_ext, io.d_enc = d_enc;
-  const int stage_off = (pd.total + 3) & ~3;
-  const size_t lds_bytes = (size_t)(stage_off + stage_floats) * 4;
-#define LAUNCH_BWD(S, M)                                                                                      \
-  do {                                                                                                        \
-    rc = set_lds(field_bwd_kernel<S, M>, lds_bytes);                                                          \
-    if (rc) return rc;                                                                                        \
-    hipLaunchKernelGGL((field_bwd_kernel<S, M>), dim3(grid), dim3(256), lds_bytes, umhs_s(stream), io, pd, td, \
-                       (const float*)wT, sl, slabs, stage_off, FSd);                                          \
+  io.emb_in = emb, io.sigma_raw_in = sigma_raw, io.d_bo = d_bo;
+#define LAUNCH_HEADS(S_, NA_, W_)                                                                                  \
+  do {                                                                                                             \
+    rc = set_lds(field_bwd_heads_kernel<S_, NA_, W_>, pl.lds_h);                                                   \
+    if (rc) return rc;                                                                                             \
+    hipLaunchKernelGGL((field_bwd_heads_kernel<S_, NA_, W_>), dim3(grid), dim3(64 * W_), pl.lds_h, umhs_s(stream), \
+                       io, pl.pd_heads, pl.td, (const float*)wT, pl.sl, slabs, pl.stage_off_h, pl.FSd);            \
   } while (0)
-  if (spec) {
-    if (MT4 == 1) LAUNCH_BWD(true, 1);
-    else if (MT4 == 2) LAUNCH_BWD(true, 2);
-    else LAUNCH_BWD(true, 3);
+#define LAUNCH_HEADS_S(NA_, W_)          \
+  do {                                   \
+    if (spec)                            \
+      LAUNCH_HEADS(true, NA_, W_);       \
+    else                                 \
+      LAUNCH_HEADS(false, NA_, W_);      \
+  } while (0)
+  if (pl.waves == 8) {
+    LAUNCH_HEADS_S(1, 8);
+  } else if (pl.NA == 2) {
+    LAUNCH_HEADS_S(2, 4);
+  } else if (pl.NA == 3) {
+    LAUNCH_HEADS_S(3, 4);
   } else {
-    if (MT4 == 1) LAUNCH_BWD(false, 1);
-    else if (MT4 == 2) LAUNCH_BWD(false, 2);
-    else LAUNCH_BWD(false, 3);
+    LAUNCH_HEADS_S(4, 4);
   }
-#undef LAUNCH_BWD
+#undef LAUNCH_HEADS_S
+#undef LAUNCH_HEADS
+  UMHS_CHECK_LAUNCH();
+  if (pl.waves == 8) {
+    rc = set_lds(field_bwd_base_kernel<8>, pl.lds_b);
+    if (rc) return rc;
+    hipLaunchKernelGGL((field_bwd_base_kernel<8>), dim3(grid), dim3(512), pl.lds_b, umhs_s(stream), io, pl.pd_base, pl.td,
+                       (const float*)wT, pl.sl, slabs, pl.stage_off_b);
+  } else {
+    rc = set_lds(field_bwd_base_kernel<4>, pl.lds_b);
+    if (rc) return rc;
+    hipLaunchKernelGGL((field_bwd_base_kernel<4>), dim3(grid), dim3(256), pl.lds_b, umhs_s(stream), io, pl.pd_base, pl.td,
+                       (const float*)wT, pl.sl, slabs, pl.stage_off_b);
+  }
   UMHS_CHECK_LAUNCH();
   GradPtrs gp;
   float* const gw[NLAYERS] = {grads->base_w0, grads->base_w1, grads->head_w0, grads->head_w1, grads->head_w2,
@@ -975,8 +1103,13 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
                               grads->feat_b0, grads->feat_b1, grads->feat_b2, grads->dir_b0,  grads->dir_b1,
                               nullptr};
   for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
-  hipLaunchKernelGGL(field_reduce_kernel, dim3((sl.total + 255) / 256), dim3(256), 0, umhs_s(stream),
-                     (const float*)slabs, (int)grid, sl, pd, gp);
+  PackDesc pd_all;
+  int TB2;
+  rc = build_pack_desc(cfg, params, &pd_all, &TB2, 0);
+  if (rc) return rc;
+  const int items = pl.sl.total_w + pl.n_bias_items;
+  hipLaunchKernelGGL(field_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, umhs_s(stream), (const float*)slabs,
+                     (int)grid, pl.sl, pd_all, gp, pl.n_bias_items);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }

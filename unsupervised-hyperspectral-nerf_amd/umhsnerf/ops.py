@@ -192,7 +192,7 @@ def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
     return ws
 
 
-def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, d_sigma, d_spectral, d_emb, d_flat):
+def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat):
     """Writes d_enc (returned) and the MLP / endmember gradients straight into ``d_flat`` (flat layout)."""
     n = sel.shape[0]
     L = spec.layout
@@ -203,7 +203,8 @@ def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, d_sigma,
     d_enc = torch.empty_like(enc)
     nbytes = _hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n)
     ws = _workspace(nbytes, sel.device)
-    _hip.check(_hip.lib().umhs_field_bwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), n,
+    _hip.check(_hip.lib().umhs_field_bwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel),
+                                         ptr(sigma_raw), ptr(emb), n,
                                          ptr(d_sigma), ptr(d_spectral), ptr(d_emb), ptr(d_enc), C.byref(gp), ptr(ws),
                                          ws.numel(), _hip.stream()), "umhs_field_bwd")
     return d_enc
@@ -294,16 +295,15 @@ class FieldFn(torch.autograd.Function):
         enc = hashgrid_fwd(pos01, table, spec.scalings, L.log2_hashmap_size, True)
         out = field_fwd(spec, flat.detach(), enc, True, wpos, d, sel, want_emb=True)
         ctx.spec = spec
-        ctx.save_for_backward(flat, pos01, sel, wpos, d, enc)
+        ctx.save_for_backward(flat, pos01, sel, wpos, d, enc, out["sigma_raw"], out["emb"])
         n = o.shape[0]
         res = [out["sigma"].view(n, 1), out["emb"], out["spectral"], out["spectral2"], out["specular"], out["abundances"]]
         ctx.mark_non_differentiable(*[t for t in res[3:] if t is not None])
-        ctx.sigma_raw = out["sigma_raw"]
         return tuple(res)
 
     @staticmethod
     def backward(ctx, d_sigma, d_emb, d_spectral, *_):
-        flat, pos01, sel, wpos, d, enc = ctx.saved_tensors
+        flat, pos01, sel, wpos, d, enc, sigma_raw, emb = ctx.saved_tensors
         spec: FieldSpec = ctx.spec
         L = spec.layout
         n = sel.shape[0]
@@ -312,7 +312,7 @@ class FieldFn(torch.autograd.Function):
         d_spectral = _hip.f32c(d_spectral) if d_spectral is not None else zeros(n, L.wavelengths)
         d_emb = _hip.f32c(d_emb) if d_emb is not None else None
         d_flat = torch.zeros_like(flat)
-        d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, d_sigma, d_spectral, d_emb, d_flat)
+        d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat)
         hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, L.view(d_flat, "mlp_base.encoder.hash_table"), True)
         return d_flat, None, None, None, None, None
 
