@@ -116,10 +116,14 @@ typedef struct umhs_field_grads {
 /*   sigma [N] = trunc_exp(raw)*selector (:327-328); sigma_raw [N]; emb [N,15];                 */
 /*   spectral [N,B] (= spec + s1*specular when pred_specular, else spec), spectral2 [N,B] (spec),*/
 /*   specular [N,B] (s1*specular), abundances [N,C].                                            */
+/* workspace (optional, umhs_field_fwd_workspace_bytes): room for the packed weight image built once per call;   */
+/* with workspace == NULL every workgroup gathers the image itself (~60 us slower per launch).                   */
+size_t umhs_field_fwd_workspace_bytes(const umhs_field_cfg* cfg);
 int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                    int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
                    int64_t n, float* sigma, float* sigma_raw, float* emb, float* spectral, float* spectral2,
-                   float* specular, float* abundances, umhs_stream_t stream);
+                   float* specular, float* abundances, void* workspace, size_t workspace_bytes,
+                   umhs_stream_t stream);
 
 /* Backward.  Recomputes the activations per tile; the only saved forward tensors are enc, sigma_raw [N] and    */
 /* emb [N,15] (both outputs of umhs_field_fwd).  d_sigma [N] and d_spectral [N,B] are the gradients w.r.t. the   */

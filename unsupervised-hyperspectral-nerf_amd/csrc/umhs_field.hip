@@ -78,6 +78,30 @@ __device__ __forceinline__ void build_fwd_image(float* lds, const PackDesc& pd) 
   }
 }
 
+// The same image built ONCE per call into global memory (each workgroup then copies it with float4 loads instead
+// of re-gathering ~19k weights through the index maps: that gather cost ~60 us per launch when done per workgroup).
+__global__ __launch_bounds__(256) void field_pack_fwd_kernel(PackDesc pd, float* __restrict__ dst) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < pd.total_w; idx += gridDim.x * 256) dst[idx] = fwd_pack_value(pd, idx);
+  if (blockIdx.x == 0) {
+    for (int li = 0; li < NLAYERS; ++li) {
+      const LayerDesc& L = pd.L[li];
+      if (li == L_MX) continue;
+      for (int o = threadIdx.x; o < 16 * L.OT; o += 256) dst[L.off_b + o] = (L.b && o < L.OUT) ? L.b[o] : 0.0f;
+    }
+  }
+}
+
+// LDS image = image[first .. total): copy when a prebuilt image is given, else gather-build in place
+__device__ __forceinline__ void load_fwd_image(float* lds, const PackDesc& pd, const float* __restrict__ image, int first) {
+  if (image) {
+    const int n4 = (pd.total - first + 3) >> 2;  // first and the image buffer are 16-byte aligned
+    for (int i = threadIdx.x; i < n4; i += blockDim.x)
+      reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(image + first)[i];
+  } else {
+    build_fwd_image(lds - first, pd);
+  }
+}
+
 // acc[ct][t] (+)= W-pack(t, :) x B-operand regs b[ct][:]   (A from LDS or global, 16 B per lane per 4 k-steps)
 template <int OT, int KS, int NT, bool INIT>
 __device__ __forceinline__ void gemm_pack(v4f (&acc)[NT][OT], const float (&b)[NT][KS], const float* __restrict__ w,
@@ -223,9 +247,9 @@ __device__ __forceinline__ void head_epilogue(HeadState<NT>& hs, const v4f (&hd4
 // Forward
 // =============================================================================================
 template <bool SPEC, bool DENSITY_ONLY>
-__global__ __launch_bounds__(256, 2) void field_fwd_kernel(FieldIO io, PackDesc pd) {
+__global__ __launch_bounds__(256, 2) void field_fwd_kernel(FieldIO io, PackDesc pd, const float* __restrict__ image) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  build_fwd_image(lds, pd);
+  load_fwd_image(lds, pd, image, 0);
   __syncthreads();
   constexpr int NT = 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
@@ -470,10 +494,12 @@ template <bool SPEC, int NA, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(FieldIO io, PackDesc pd, TPackDesc td,
                                                                                const float* __restrict__ wT, SlabLayout sl,
                                                                                float* __restrict__ slabs, int stage_off,
-                                                                               int FSd) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  build_fwd_image(lds, pd);
-  float* const st = lds + stage_off;
+                                                                               int FSd, const float* __restrict__ image,
+                                                                               int first) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  load_fwd_image(lds_raw, pd, image, first);  // pd carries ALL layers' offsets; only [first, total) is resident
+  float* const lds = lds_raw - first;
+  float* const st = lds_raw + stage_off;
   constexpr int NT = 1, S = 16 * WAVES, NH0 = 8 / WAVES, NH1 = 16 / WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int row = wave * 16 + j;
@@ -798,8 +824,14 @@ __global__ __launch_bounds__(256) void field_reduce_kernel(const float* __restri
     if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
     return;
   }
-  float s = 0.0f;
-  for (int w = 0; w < nslabs; ++w) s += slabs[(size_t)w * sl.total + idx];
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int w = 0;
+  for (; w + 3 < nslabs; w += 4) {  // 4 independent loads in flight per thread
+    s0 += slabs[(size_t)w * sl.total + idx], s1 += slabs[(size_t)(w + 1) * sl.total + idx];
+    s2 += slabs[(size_t)(w + 2) * sl.total + idx], s3 += slabs[(size_t)(w + 3) * sl.total + idx];
+  }
+  for (; w < nslabs; ++w) s0 += slabs[(size_t)w * sl.total + idx];
+  const float s = (s0 + s1) + (s2 + s3);
   for (int l = 0; l < NLAYERS; ++l) {
     const LayerDesc& L = pd.L[l];
     const int nw = sl.waves * sl.nacc[l] * 256;
@@ -885,11 +917,23 @@ static int set_lds(K kernel, size_t bytes) {
   return UMHS_OK;
 }
 
+extern "C" size_t umhs_field_fwd_workspace_bytes(const umhs_field_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  umhs_field_params dummy = {};
+  const float one = 0.0f;
+  const float** pp = reinterpret_cast<const float**>(&dummy);
+  for (size_t i = 0; i < sizeof(dummy) / sizeof(float*); ++i) pp[i] = &one;  // layout only, never dereferenced
+  PackDesc pd;
+  int TB;
+  if (build_pack_desc(cfg, &dummy, &pd, &TB)) return 0;
+  return (size_t)pd.total * 4 + 512;
+}
+
 extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
                               int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
                               const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
                               float* spectral, float* spectral2, float* specular, float* abundances,
-                              umhs_stream_t stream) {
+                              void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!params || !enc || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
@@ -906,15 +950,24 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances;
-  const size_t lds_bytes = (size_t)pd.total * 4;
+  const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
   const int64_t ntiles = (n + 127) / 128;
+  const float* image = nullptr;
+  if (workspace) {  // optional: prebuilt pack image (without it every workgroup gathers the image itself)
+    if (workspace_bytes < (size_t)pd.total * 4 + 512) return UMHS_ERR_WORKSPACE;
+    float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
+    UMHS_CHECK_LAUNCH();
+    image = img;
+  }
   const int blocks_per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
 #define LAUNCH_FWD(S, D)                                                                                       \
   do {                                                                                                         \
     rc = set_lds(field_fwd_kernel<S, D>, lds_bytes);                                                           \
     if (rc) return rc;                                                                                         \
-    hipLaunchKernelGGL((field_fwd_kernel<S, D>), dim3(grid), dim3(256), lds_bytes, umhs_s(stream), io, pd);     \
+    hipLaunchKernelGGL((field_fwd_kernel<S, D>), dim3(grid), dim3(256), lds_bytes, umhs_s(stream), io, pd,      \
+                       image);                                                                                  \
   } while (0)
   if (dens)
     LAUNCH_FWD(false, true);
@@ -928,8 +981,8 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
 }
 
 struct BwdPlan {
-  int TB, waves, NA, FSd, S;
-  PackDesc pd_heads, pd_base;
+  int TB, waves, NA, FSd, S, first;
+  PackDesc pd_all, pd_base;
   TPackDesc td;
   SlabLayout sl;
   int n_bias_items;
@@ -940,8 +993,9 @@ struct BwdPlan {
 static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p, BwdPlan* pl) {
   const int B = cfg->n_bands, C = cfg->n_classes, spec = cfg->pred_specular != 0;
   int TB;
-  int rc = build_pack_desc(cfg, p, &pl->pd_heads, &TB, 2);
+  int rc = build_pack_desc(cfg, p, &pl->pd_all, &TB, 0);
   if (rc) return rc;
+  pl->first = pl->pd_all.L[L_H0].off_w;  // the heads kernel keeps image[first, total) resident
   rc = build_pack_desc(cfg, p, &pl->pd_base, &TB, 1);
   if (rc) return rc;
   pl->TB = TB;
@@ -950,7 +1004,7 @@ static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p,
     const int tail = S * pl->FSd + 2 * S * 16;
     return tail > 2 * S * 80 ? tail : 2 * S * 80;
   };
-  pl->stage_off_h = (pl->pd_heads.total + 3) & ~3;
+  pl->stage_off_h = (pl->pd_all.total - pl->first + 3) & ~3;
   pl->stage_off_b = (pl->pd_base.total + 3) & ~3;
   pl->waves = 8;
   if ((size_t)(pl->stage_off_h + stage_floats(128)) * 4 > 160 * 1024 || TB > 8) pl->waves = 4;
@@ -1013,7 +1067,7 @@ static unsigned bwd_grid(int64_t n, int S) {
 }
 
 static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
-  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 16) * 4 + 512;
+  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 16 + pl.pd_all.total) * 4 + 1024;
 }
 
 extern "C" size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int64_t n) {
@@ -1050,7 +1104,10 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   float* slabs = wT + ((pl.td.total + 63) & ~63);
   float* d_bo = slabs + (((size_t)grid * pl.sl.total + 63) & ~(size_t)63);
+  float* img = d_bo + (((size_t)n * 16 + 63) & ~(size_t)63);
   hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
+  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all,
+                     img);
   UMHS_CHECK_LAUNCH();
   FieldIO io = {};
   io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
@@ -1062,7 +1119,8 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
     rc = set_lds(field_bwd_heads_kernel<S_, NA_, W_>, pl.lds_h);                                                   \
     if (rc) return rc;                                                                                             \
     hipLaunchKernelGGL((field_bwd_heads_kernel<S_, NA_, W_>), dim3(grid), dim3(64 * W_), pl.lds_h, umhs_s(stream), \
-                       io, pl.pd_heads, pl.td, (const float*)wT, pl.sl, slabs, pl.stage_off_h, pl.FSd);            \
+                       io, pl.pd_all, pl.td, (const float*)wT, pl.sl, slabs, pl.stage_off_h, pl.FSd,               \
+                       (const float*)img, pl.first);                                                               \
   } while (0)
 #define LAUNCH_HEADS_S(NA_, W_)          \
   do {                                   \
@@ -1103,10 +1161,7 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
                               grads->feat_b0, grads->feat_b1, grads->feat_b2, grads->dir_b0,  grads->dir_b1,
                               nullptr};
   for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
-  PackDesc pd_all;
-  int TB2;
-  rc = build_pack_desc(cfg, params, &pd_all, &TB2, 0);
-  if (rc) return rc;
+  const PackDesc& pd_all = pl.pd_all;
   const int items = pl.sl.total_w + pl.n_bias_items;
   hipLaunchKernelGGL(field_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, umhs_s(stream), (const float*)slabs,
                      (int)grid, pl.sl, pd_all, gp, pl.n_bias_items);

@@ -173,9 +173,10 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
             abund = new(n, L.num_classes)
             if L.pred_specular:
                 spectral2, specular = new(n, L.wavelengths), new(n, L.wavelengths)
+    ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_fwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), n,
                                          ptr(sigma), ptr(sigma_raw), ptr(emb), ptr(spectral), ptr(spectral2), ptr(specular),
-                                         ptr(abund), _hip.stream()), "umhs_field_fwd")
+                                         ptr(abund), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_fwd")
     return dict(sigma=sigma, sigma_raw=sigma_raw, emb=emb, spectral=spectral, spectral2=spectral2, specular=specular,
                 abundances=abund)
 
