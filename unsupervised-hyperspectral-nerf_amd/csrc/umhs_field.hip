@@ -16,11 +16,18 @@
 // i.e. over lanes) by staging [sample][feature] tiles of dZ and X in LDS and re-reading them
 // transposed as MFMA operands; each wave keeps a quarter of every layer's dW tiles in registers for
 // the whole launch, partial slabs are summed by a small reduce kernel.
+#include <cstdlib>
+
 #include "umhs_common.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#ifdef UMHS_ABL_NO_SYNC  // timing-only ablation build (tools/ablate_field.sh); never defined in the shipped library
+#define BSYNC()
+#else
+#define BSYNC() __syncthreads()
+#endif
 
 enum InKind { IN_ENC = 0, IN_HID64 = 1, IN_HID16 = 2, IN_27 = 3, IN_DIR28 = 4, IN_MIX = 5 };
 enum LayerId { L_B0 = 0, L_B1, L_H0, L_H1, L_H2, L_F0, L_F1, L_F2, L_D0, L_D1, L_MX, NLAYERS };
@@ -132,6 +139,10 @@ __device__ __forceinline__ void gemm_pack(v4f (&acc)[NT][OT], const float (&b)[N
   }
 }
 
+// relu as ONE integer max on the bit pattern (negative floats are negative ints; +NaN stays NaN like torch.relu);
+// fmaxf() on an MFMA result costs two instructions because hipcc first canonicalises a possible sNaN
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 template <int OT, int NT>
 __device__ __forceinline__ void relu_to(float (&x)[NT][OT * 4], const v4f (&acc)[NT][OT]) {
 #pragma unroll
@@ -139,10 +150,14 @@ __device__ __forceinline__ void relu_to(float (&x)[NT][OT * 4], const v4f (&acc)
 #pragma unroll
     for (int t = 0; t < OT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[ct][4 * t + r] = fmaxf(acc[ct][t][r], 0.0f);
+      for (int r = 0; r < 4; ++r) x[ct][4 * t + r] = relu1(acc[ct][t][r]);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp via v_exp_f32 (2^x) and reciprocal via v_rcp_f32: ~1e-7..1e-6 relative error for the |x| <~ 30 seen here, an
+// order of magnitude inside the parity budget, and ~10x fewer instructions than the IEEE sequences between MFMAs
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return frcp(1.0f + fexp(-x)); }
 __device__ __forceinline__ float xq_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -211,26 +226,27 @@ template <int NT, bool SPEC>
 __device__ __forceinline__ void head_epilogue(HeadState<NT>& hs, const v4f (&hd4)[NT][1], const v4f (&fl4)[NT][1], int C,
                                               float temperature, int lane) {
   const int q = lane >> 4;
+  const float inv_t = 1.0f / temperature;
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
     float z[4], zmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      z[r] = fl4[ct][0][r] / temperature;
+      z[r] = fl4[ct][0][r] * inv_t;
       if (4 * q + r < C) zmax = fmaxf(zmax, z[r]);
     }
     zmax = xq_max(zmax);
     float e[4], sum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      e[r] = (4 * q + r < C) ? expf(z[r] - zmax) : 0.0f;
+      e[r] = (4 * q + r < C) ? fexp(z[r] - zmax) : 0.0f;
       sum += e[r];
     }
-    sum = xq_sum(sum);
+    sum = frcp(xq_sum(sum));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool v = 4 * q + r < C;
-      hs.ab[ct][r] = e[r] / sum;
+      hs.ab[ct][r] = e[r] * sum;
       hs.sg[ct][r] = v ? sigmoidf_(hd4[ct][0][r]) : 0.0f;
       hs.m[ct][r] = hs.sg[ct][r] * hs.ab[ct][r];
     }
@@ -246,20 +262,21 @@ __device__ __forceinline__ void head_epilogue(HeadState<NT>& hs, const v4f (&hd4
 // =============================================================================================
 // Forward
 // =============================================================================================
-template <bool SPEC, bool DENSITY_ONLY>
-__global__ __launch_bounds__(256, 2) void field_fwd_kernel(FieldIO io, PackDesc pd, const float* __restrict__ image) {
+template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(FieldIO io, PackDesc pd,
+                                                                               const float* __restrict__ image) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   load_fwd_image(lds, pd, image, 0);
   __syncthreads();
-  constexpr int NT = 2;
+  constexpr int TILE = 16 * NT * WAVES;  // samples per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-  const int64_t ntiles = (io.n + 127) / 128;
+  const int64_t ntiles = (io.n + TILE - 1) / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t nn[NT];
     bool ok[NT];
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
-      int64_t n = tile * 128 + wave * 32 + ct * 16 + j;
+      int64_t n = tile * TILE + wave * (16 * NT) + ct * 16 + j;
       ok[ct] = n < io.n;
       nn[ct] = ok[ct] ? n : io.n - 1;
     }
@@ -424,6 +441,9 @@ __device__ __forceinline__ void stage_hid(float* st, int FS, int row, int q, con
 template <int NACC, int WAVES>
 __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restrict__ stZ, int FSz,
                                          const float* __restrict__ stX, int FSx, int TO, int TI, int wave, int lane) {
+#ifdef UMHS_ABL_NO_DW
+  return;
+#endif
   const int j = lane & 15, q = lane >> 4;
   const int ti = wave % TI, to0 = wave / TI, tstep = WAVES / TI;
   if (to0 >= TO) return;
@@ -442,6 +462,9 @@ __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restri
 // partial column sum of a staged tile: thread -> (column, row group); the slab reduce adds the row groups
 template <int WAVES>
 __device__ __forceinline__ float col_sum_part(const float* __restrict__ st, int FS, int cols, int tid) {
+#ifdef UMHS_ABL_NO_DW
+  return 0.0f;
+#endif
   constexpr int S = 16 * WAVES, NTH = 64 * WAVES;
   const int RG = NTH / cols, rg = tid / cols, col = tid - rg * cols;
   if (rg >= RG) return 0.0f;
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
   zero_acc(aH0), zero_acc(aH1), zero_acc(aH2), zero_acc(aF0), zero_acc(aF1), zero_acc(aF2), zero_acc(aD0);
   zero_acc(aD1), zero_acc(aMX);
   float dbH0 = 0.f, dbH1 = 0.f, dbH2 = 0.f, dbF0 = 0.f, dbF1 = 0.f, dbF2 = 0.f, dbD0 = 0.f, dbD1 = 0.f;
-  __syncthreads();
+  BSYNC();
   const int64_t ntiles = (io.n + S - 1) / S;
   const int C = io.C, B = io.B, TB = io.TB;
   float* const stZ = st;            // [S][<=80]
@@ -566,7 +589,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
     dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     float ds1 = 0.0f;
-    __syncthreads();  // previous tile's staging reads are done
+    BSYNC();  // previous tile's staging reads are done
     for (int t = 0; t < TB; ++t) {
       float dsp[NT][4];
 #pragma unroll
@@ -592,7 +615,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
     if (SPEC) *reinterpret_cast<v4f*>(stXh + row * 16 + 4 * q) = v4f{hdir[0][0], hdir[0][1], hdir[0][2], hdir[0][3]};
     *reinterpret_cast<v4f*>(stXm + row * 16 + 4 * q) = v4f{hs.m[0][0], hs.m[0][1], hs.m[0][2], hs.m[0][3]};
     ds1 = xq_sum(ds1);
-    __syncthreads();
+    BSYNC();
     if (SPEC) {
       dw_accum<NA, WAVES>(aD1, stZd, FSd, stXh, 16, TB, 1, wave, lane);
       dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
@@ -617,6 +640,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
     // =================== phase B: heads ===========================================================
     float dhs[NT][4], dfl[NT][4];
     {
+      const float inv_t = 1.0f / io.temperature;
       float da[4], dot = 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -630,7 +654,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = 4 * q + r;
-        float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) / io.temperature : 0.0f;
+        float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) * inv_t : 0.0f;
         if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
         dfl[0][r] = g;
         if (c >= C) dhs[0][r] = 0.0f;
@@ -640,13 +664,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       float dz[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
-      __syncthreads();
+      BSYNC();
       *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dz[0], dz[1], dz[2], dz[3]};
       *reinterpret_cast<v4f*>(stX + row * 48 + 4 * q) = v4f{dir28[0][0], dir28[0][1], dir28[0][2], dir28[0][3]};
 #pragma unroll
       for (int s = 0; s < 3; ++s) stX[row * 48 + 16 + 3 * q + s] = dir28[0][4 + s];
       if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      __syncthreads();
+      BSYNC();
       dw_accum<1, WAVES>(aD0, stZ, 16, stX, 48, 1, 2, wave, lane);
       dbD0 += col_sum_part<WAVES>(stZ, 16, 16, tid);
     }
@@ -656,10 +680,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
     auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f(&acc2)[1],
                         v4f(&acc1)[NH1], v4f(&acc0)[NH0], float& db2, float& db1, float& db0, int t2, int t1,
                         int t0) __attribute__((always_inline)) {
-      __syncthreads();
+      BSYNC();
       *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
       stage_hid<4>(stX, 80, row, q, a2[0]);
-      __syncthreads();
+      BSYNC();
       dw_accum<1, WAVES>(acc2, stZ, 16, stX, 80, 1, 4, wave, lane);
       db2 += col_sum_part<WAVES>(stZ, 16, 16, tid);
       v4f g4[NT][4];
@@ -667,24 +691,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       float dz1[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-      __syncthreads();
+      BSYNC();
       stage_hid<4>(stZ, 80, row, q, dz1[0]);
       stage_hid<4>(stX, 80, row, q, a1[0]);
-      __syncthreads();
+      BSYNC();
       dw_accum<NH1, WAVES>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
       db1 += col_sum_part<WAVES>(stZ, 80, 64, tid);
       gemm_pack<4, 16, NT, true>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
       float dz0[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-      __syncthreads();
+      BSYNC();
       stage_hid<4>(stZ, 80, row, q, dz0[0]);
       // X = [pe(12) | base-MLP output slots(16)] : 28 columns, 28..31 zero
 #pragma unroll
       for (int s = 0; s < 3; ++s) stX[row * 48 + 3 * q + s] = in27[0][s];
       *reinterpret_cast<v4f*>(stX + row * 48 + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
       if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      __syncthreads();
+      BSYNC();
       dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
       db0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
       gemm_pack<1, 16, NT, false>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
@@ -699,7 +723,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
   store_acc(aF1, slab, sl.off[L_F1], wave, lane), store_acc(aF2, slab, sl.off[L_F2], wave, lane);
   store_acc(aD0, slab, sl.off[L_D0], wave, lane), store_acc(aD1, slab, sl.off[L_D1], wave, lane);
   store_acc(aMX, slab, sl.off[L_MX], wave, lane);
-  __syncthreads();  // staging region is free: reuse it for the bias fold
+  BSYNC();  // staging region is free: reuse it for the bias fold
   flush_db<WAVES>(dbH0, st, slab + sl.off_db[L_H0], sl.cols[L_H0], tid);
   flush_db<WAVES>(dbH1, st, slab + sl.off_db[L_H1], sl.cols[L_H1], tid);
   flush_db<WAVES>(dbH2, st, slab + sl.off_db[L_H2], sl.cols[L_H2], tid);
@@ -728,7 +752,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
   v4f aB0[NB0], aB1[1];
   zero_acc(aB0), zero_acc(aB1);
   float dbB0 = 0.f, dbB1 = 0.f;
-  __syncthreads();
+  BSYNC();
   float* const stZ = st;
   float* const stX = st + S * 80;
   const int64_t ntiles = (io.n + S - 1) / S;
@@ -761,10 +785,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
         dzb1[0][0] = ok ? io.d_sigma[n] * io.sel[n] * expf(fminf(fmaxf(raw, -15.0f), 15.0f)) : 0.0f;
       }
     }
-    __syncthreads();
+    BSYNC();
     *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzb1[0][0], dzb1[0][1], dzb1[0][2], dzb1[0][3]};
     stage_hid<4>(stX, 80, row, q, h[0]);
-    __syncthreads();
+    BSYNC();
     dw_accum<1, WAVES>(aB1, stZ, 16, stX, 80, 1, 4, wave, lane);
     dbB1 += col_sum_part<WAVES>(stZ, 16, 16, tid);
     v4f g4[NT][4];
@@ -772,11 +796,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     float dzb0[NT][16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-    __syncthreads();
+    BSYNC();
     stage_hid<4>(stZ, 80, row, q, dzb0[0]);
     *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q) = v4f{encf[0][0], encf[0][1], encf[0][2], encf[0][3]};
     *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q + 4) = v4f{encf[0][4], encf[0][5], encf[0][6], encf[0][7]};
-    __syncthreads();
+    BSYNC();
     dw_accum<NB0, WAVES>(aB0, stZ, 80, stX, 48, 4, 2, wave, lane);
     dbB0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
     v4f de4[NT][2];
@@ -794,7 +818,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
   }
   float* const slab = slabs + (size_t)blockIdx.x * sl.total;
   store_acc(aB0, slab, sl.off[L_B0], wave, lane), store_acc(aB1, slab, sl.off[L_B1], wave, lane);
-  __syncthreads();
+  BSYNC();
   flush_db<WAVES>(dbB0, st, slab + sl.off_db[L_B0], sl.cols[L_B0], tid);
   flush_db<WAVES>(dbB1, st, slab + sl.off_db[L_B1], sl.cols[L_B1], tid);
 }
@@ -951,7 +975,9 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances;
   const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
-  const int64_t ntiles = (n + 127) / 128;
+  static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;  // tuning knob
+  const int tile_samples = 128;  // every variant processes 128 samples per workgroup iteration
+  const int64_t ntiles = (n + tile_samples - 1) / tile_samples;
   const float* image = nullptr;
   if (workspace) {  // optional: prebuilt pack image (without it every workgroup gathers the image itself)
     if (workspace_bytes < (size_t)pd.total * 4 + 512) return UMHS_ERR_WORKSPACE;
@@ -962,19 +988,22 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   }
   const int blocks_per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
-#define LAUNCH_FWD(S, D)                                                                                       \
-  do {                                                                                                         \
-    rc = set_lds(field_fwd_kernel<S, D>, lds_bytes);                                                           \
-    if (rc) return rc;                                                                                         \
-    hipLaunchKernelGGL((field_fwd_kernel<S, D>), dim3(grid), dim3(256), lds_bytes, umhs_s(stream), io, pd,      \
-                       image);                                                                                  \
+#define LAUNCH_FWD(S, D, NT_, W_)                                                                               \
+  do {                                                                                                          \
+    rc = set_lds(field_fwd_kernel<S, D, NT_, W_>, lds_bytes);                                                   \
+    if (rc) return rc;                                                                                          \
+    hipLaunchKernelGGL((field_fwd_kernel<S, D, NT_, W_>), dim3(grid), dim3(64 * W_), lds_bytes, umhs_s(stream), \
+                       io, pd, image);                                                                          \
   } while (0)
   if (dens)
-    LAUNCH_FWD(false, true);
-  else if (spec)
-    LAUNCH_FWD(true, false);
-  else
-    LAUNCH_FWD(false, false);
+    LAUNCH_FWD(false, true, 2, 4);
+  else if (spec) {
+    if (fwd_variant == 1)
+      LAUNCH_FWD(true, false, 1, 8);
+    else
+      LAUNCH_FWD(true, false, 2, 4);
+  } else
+    LAUNCH_FWD(false, false, 2, 4);
 #undef LAUNCH_FWD
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
