@@ -192,6 +192,30 @@ int umhs_spec2rgb_bwd(const float* spec, const float* M, const float* d_rgb, int
                       float* d_spec, int accumulate, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* R13/R15/R16 fused per-ray epilogue + losses (the ~85 tiny torch kernels of umhs_model.py:254-313,358-370).     */
+/* umhs_tmid_minmax: min / max over all samples of (t0+t1)/2 -- DepthRenderer's clip bounds (global over the      */
+/*   batch); minmax2 = 2 device words in an order-preserving encoding consumed by umhs_ray_epilogue_fwd only.     */
+/* umhs_ray_epilogue_fwd: rgb = ColourSystem(spectral) (spec_to_rgb.py:112-127); depth_clipped; seg_probs =       */
+/*   softmax(alpha * cos(spectral, endmembers)) (clusterprobe.py:17-38, alpha = 0.2 at umhs_model.py:307);        */
+/*   seg_raw = argmax * [acc > 0.5]; seg_pred = class_colors[argmax] * [acc > 0.5] (:308-313).  Any output NULL   */
+/*   = skipped.  n_classes <= 16.  Gradient flows through rgb only (umhs_spec2rgb_bwd).                           */
+/* umhs_loss_fwd: losses2[0] = w_spectral * MSE(spectral, gt_spectral); losses2[1] = w_rgb * MSE(rgb +           */
+/*   background*(1-acc), gt_rgb) (rgb == NULL: skipped).  umhs_loss_bwd: their gradients scaled by the upstream    */
+/*   gradients grad_losses2 (device [2], NULL = 1).                                                               */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_tmid_minmax(const float* t_starts, const float* t_ends, int64_t n, float* minmax2, umhs_stream_t stream);
+int umhs_ray_epilogue_fwd(const float* spectral, const float* M, const float* endmembers, const float* accumulation,
+                          const float* depth, const float* tmid_minmax2, const float* class_colors, int64_t n_rays,
+                          int n_bands, int n_classes, float alpha, float* rgb, float* depth_clipped, float* seg_probs,
+                          float* seg_raw, float* seg_pred, umhs_stream_t stream);
+int umhs_loss_fwd(const float* spectral, const float* gt_spectral, const float* rgb, const float* accumulation,
+                  const float* background, const float* gt_rgb, int64_t n_rays, int n_bands, float w_spectral, float w_rgb,
+                  float* losses2, umhs_stream_t stream);
+int umhs_loss_bwd(const float* spectral, const float* gt_spectral, const float* rgb, const float* accumulation,
+                  const float* background, const float* gt_rgb, int64_t n_rays, int n_bands, float w_spectral, float w_rgb,
+                  const float* grad_losses2, float* d_spectral, float* d_rgb, float* d_accumulation, umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Optimizer: torch.optim.Adam step for param group "fields" (AdamOptimizerConfig(lr=2e-2,      */
 /* eps=1e-15), umhs_config.py:59-64) over one flat fp32 buffer, with the clamp_endmembers        */
 /* callback (umhs_model.py:568-572) fused for elements [clamp_begin, clamp_end).  grad_scale     */

@@ -416,3 +416,87 @@ def test_end_to_end_loss_and_grads(C, B, spec, temp, ragged):
     assert_close("grad head_b0", layout.view(g, "mlp_head.layers.0.bias"), grads["head_b.0"], 2e-4)
     if spec:
         assert_close("grad dir_w1", layout.view(g, "mlp_directional.layers.1.weight"), grads["dir_w.1"], 2e-4)
+
+
+def test_ray_epilogue_and_fused_loss():
+    """R13-R16 fused kernels against the oracle's separate functions (colour system, cluster lookup, depth clip, losses)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    R, B, Cn, N = 300, 31, 6, 5000
+    M = T.colour_matrix(np.linspace(400, 700, B))
+    spec = torch.rand(R, B, generator=g)
+    spec[:5] *= 0.003
+    E = torch.rand(Cn, B, generator=g)
+    acc = torch.rand(R, 1, generator=g)
+    depth = torch.rand(R, 1, generator=g) * 3
+    t0 = torch.rand(N, 1, generator=g) * 2 + 0.5
+    t1 = t0 + 0.01
+    colors = torch.rand(15, 3, generator=g)
+    mm = ops.tmid_minmax(t0.to(DEV), t1.to(DEV))
+    sd = spec.to(DEV).requires_grad_()
+    rgb, dclip, probs, raw, pred = ops.RayEpilogueFn.apply(sd, M.to(DEV), E.to(DEV), acc.to(DEV), depth.to(DEV), mm, colors.to(DEV), 0.2)
+    steps = (t0 + t1) / 2
+    assert_close("rgb", rgb, T.colour_system(spec, M), 1e-5)
+    assert_close("depth clip", dclip, torch.clip(depth, steps.min(), steps.max()), 1e-6)
+    ip, pr = T.cluster_lookup(spec, 0.2, E)
+    assert_close("seg_probs", probs, pr, 1e-5)
+    on = (acc > 0.5).float()
+    assert torch.equal(raw.cpu(), pr.argmax(1) * on.squeeze(-1))
+    assert_close("seg_pred", pred, colors[pr.argmax(1)] * on, 1e-6)
+    # fused losses + gradients (incl. non-unit upstream gradients)
+    gt_s, gt_rgb, bg = torch.rand(R, B, generator=g), torch.rand(R, 3, generator=g), torch.rand(R, 3, generator=g)
+    sr = spec.clone().requires_grad_()
+    ar = acc.clone().requires_grad_()
+    rr = T.colour_system(sr, M)
+    l_s = 5 * torch.nn.functional.mse_loss(sr, gt_s)
+    l_r = 0.7 * torch.nn.functional.mse_loss(rr + bg * (1 - ar), gt_rgb)
+    gs_ref, ga_ref = torch.autograd.grad(2.0 * l_s + 3.0 * l_r, [sr, ar])
+    ad = acc.to(DEV).requires_grad_()
+    ls, lr = ops.LossFn.apply(sd, gt_s.to(DEV), rgb, ad, bg.to(DEV), gt_rgb.to(DEV), 5.0, 0.7)
+    assert abs(float(ls) - float(l_s)) < 1e-5 * float(l_s) and abs(float(lr) - float(l_r)) < 1e-5 * float(l_r)
+    (2.0 * ls + 3.0 * lr).backward()
+    assert_close("d_spectral (loss + rgb chain)", sd.grad, gs_ref, 2e-5)
+    assert_close("d_acc", ad.grad, ga_ref, 2e-5)
+    l1, _ = ops.LossFn.apply(sd.detach(), gt_s.to(DEV), None, None, None, None, 1.0, 0.0)
+    assert abs(float(l1) - float(torch.nn.functional.mse_loss(spec, gt_s))) < 1e-6
+
+
+def test_model_train_iteration_matches_oracle_step():
+    """Plugin-surface path (UMHSPipeline.train_iteration): outputs, losses and the parameters after one fused-Adam step."""
+    import numpy as np
+    from umhsnerf._ns_compat import packed_ray_samples
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    ops = _ops()
+    R, S, B, Cn, temp = 40, 20, 31, 6, 0.4
+    bands = list(np.linspace(400, 700, B))
+    cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=temp, log2_hashmap_size=14, background_color="black")
+    pipe = UMHSPipeline(cfg, torch.device(DEV), metadata={"wavelengths": bands, "num_classes": Cn}, seed=3)
+    p = T.FieldParams(Cn, B, True, log2_hashmap_size=14, table_scale=0.5, seed=9)
+    with torch.no_grad():
+        p.base_b[1][0] += 1.0
+    pipe.model.field.load_state_dict(p.reference_state_dict())
+    b = T.synthetic_batch(R, S, B, seed=12)
+    M = T.colour_matrix(bands)
+    gt_rgb = T.colour_system(b["gt_spectral"], M)
+    out = T.model_outputs(p, b["origins"], b["directions"], b["starts"], b["ends"], b["ray_indices"], R, temp, M)
+    loss = T.model_loss(out, b["gt_spectral"], gt_rgb, torch.zeros(R, 3), "rgb+spectral")
+    params = [v for _, v in p.named_parameters()]
+    grads = torch.autograd.grad(sum(loss.values()), params, allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, params)]
+    d = dev(b)
+    rs = packed_ray_samples(d["origins"], d["directions"], d["starts"], d["ends"])
+    outputs, loss_dict = pipe.train_iteration(rs, d["ray_indices"], R, {"image": gt_rgb.to(DEV), "hs_image": d["gt_spectral"]})
+    for k in ("spectral", "spectral2", "specular", "abundances", "rgb", "accumulation", "depth", "seg_probs"):
+        assert_close(f"outputs[{k}]", outputs[k], out[k] if k != "depth" else out["depth"], 1e-4)
+    assert set(f"wv_{i}" for i in range(B)) <= set(outputs) and "residual_0" in outputs and "abundances_5" in outputs
+    for k in loss:
+        assert abs(float(loss_dict[k]) - float(loss[k])) <= 1e-4 * abs(float(loss[k])), k
+    with torch.no_grad():
+        ms, vs = [torch.zeros_like(v) for v in params], [torch.zeros_like(v) for v in params]
+        T.adam_step(params, grads, ms, vs, 1, T.exp_decay_lr(0))
+        p.endmembers.clamp_(0, 1)
+    sd_new = pipe.model.field.state_dict()
+    for k, v in p.reference_state_dict().items():
+        assert_close(f"param after step: {k}", sd_new[k], v, 1e-4)

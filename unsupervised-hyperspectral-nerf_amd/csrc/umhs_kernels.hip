@@ -883,6 +883,192 @@ extern "C" int umhs_spec2rgb_bwd(const float* spec, const float* M, const float*
 }
 
 // =============================================================================================
+// R14-R16 fused per-ray epilogue and loss.  The reference runs ~85 tiny torch kernels per step for these
+// (depth clip with a global min/max, ColourSystem, ClusterLookup + argmax + label colours, random-background
+// blend, two MSE losses and their autograd); here they are one forward kernel each and the loss kernel also
+// writes the gradients of both losses (the upstream gradient of a loss is a scalar, applied by the caller).
+// =============================================================================================
+__device__ __forceinline__ uint32_t f2ord(float f) {  // order-preserving float -> uint (for atomicMin/Max)
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+// min/max of the sample mid-points t_mid = (t0+t1)/2 over the whole batch (DepthRenderer's clip bounds)
+__global__ __launch_bounds__(256) void tmid_minmax_kernel(const float* __restrict__ t0, const float* __restrict__ t1, int64_t n,
+                                                          uint32_t* __restrict__ mm) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float m = (t0[i] + t1[i]) / 2.0f;
+    lo = fminf(lo, m), hi = fmaxf(hi, m);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) lo = fminf(lo, __shfl_xor(lo, d, 64)), hi = fmaxf(hi, __shfl_xor(hi, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMin(&mm[0], f2ord(lo)), atomicMax(&mm[1], f2ord(hi));
+}
+
+extern "C" int umhs_tmid_minmax(const float* t_starts, const float* t_ends, int64_t n, float* minmax2, umhs_stream_t stream) {
+  if (n < 0 || !minmax2 || (n > 0 && (!t_starts || !t_ends))) return UMHS_ERR_ARG;
+  const uint32_t init[2] = {0xffffffffu, 0u};
+  if (hipMemcpyAsync(minmax2, init, 8, hipMemcpyHostToDevice, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
+  if (n == 0) return UMHS_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(tmid_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, umhs_s(stream), t_starts, t_ends, n,
+                     reinterpret_cast<uint32_t*>(minmax2));
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// one thread per ray: rgb = ColourSystem(spectral); depth clip; ClusterLookup(alpha) against the endmembers;
+// seg_raw = argmax * [acc > 0.5]; seg_pred = class colour * [acc > 0.5]
+__global__ __launch_bounds__(256) void ray_epilogue_kernel(const float* __restrict__ spec, const float* __restrict__ M,
+                                                           const float* __restrict__ E, const float* __restrict__ acc,
+                                                           const float* __restrict__ depth_in, const uint32_t* __restrict__ mm,
+                                                           const float* __restrict__ colors, int64_t n_rays, int B, int C,
+                                                           float alpha, float* __restrict__ rgb, float* __restrict__ depth_out,
+                                                           float* __restrict__ seg_probs, float* __restrict__ seg_raw,
+                                                           float* __restrict__ seg_pred) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rays) return;
+  const float* row = spec + r * B;
+  float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, ss = 0.0f;
+  float ip[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) ip[c] = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float s = row[b];
+    x0 += s * M[3 * b], x1 += s * M[3 * b + 1], x2 += s * M[3 * b + 2];
+    ss += s * s;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < C) ip[c] += s * E[c * B + b];
+  }
+  if (rgb) {
+    rgb[3 * r] = fminf(fmaxf(srgb_gamma(x0), 0.0f), 1.0f);
+    rgb[3 * r + 1] = fminf(fmaxf(srgb_gamma(x1), 0.0f), 1.0f);
+    rgb[3 * r + 2] = fminf(fmaxf(srgb_gamma(x2), 0.0f), 1.0f);
+  }
+  if (depth_out) depth_out[r] = fminf(fmaxf(depth_in[r], ord2f(mm[0])), ord2f(mm[1]));
+  if (seg_probs) {
+    // F.normalize: x / max(||x||, 1e-12) for the ray spectrum and for every endmember row (utils/clusterprobe.py:20-25)
+    const float inv_x = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    float mx = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < C) {
+        float ee = 0.0f;
+        for (int b = 0; b < B; ++b) ee += E[c * B + b] * E[c * B + b];
+        ip[c] = ip[c] * inv_x / fmaxf(sqrtf(ee), 1e-12f);
+        if (ip[c] > mx) mx = ip[c], arg = c;
+      }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < C) ip[c] = expf(alpha * (ip[c] - mx)), sum += ip[c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < C) seg_probs[r * C + c] = ip[c] / sum;
+    const float on = acc[r] > 0.5f ? 1.0f : 0.0f;
+    if (seg_raw) seg_raw[r] = (float)arg * on;
+    if (seg_pred) {
+      seg_pred[3 * r] = colors[3 * arg] * on, seg_pred[3 * r + 1] = colors[3 * arg + 1] * on;
+      seg_pred[3 * r + 2] = colors[3 * arg + 2] * on;
+    }
+  }
+}
+
+extern "C" int umhs_ray_epilogue_fwd(const float* spectral, const float* M, const float* endmembers, const float* accumulation,
+                                     const float* depth, const float* tmid_minmax2, const float* class_colors, int64_t n_rays,
+                                     int n_bands, int n_classes, float alpha, float* rgb, float* depth_clipped, float* seg_probs,
+                                     float* seg_raw, float* seg_pred, umhs_stream_t stream) {
+  if (n_rays < 0 || n_bands < 1 || !spectral || !M) return UMHS_ERR_ARG;
+  if (seg_probs && (!endmembers || !accumulation || n_classes < 1)) return UMHS_ERR_ARG;
+  if (seg_pred && !class_colors) return UMHS_ERR_ARG;
+  if (depth_clipped && (!depth || !tmid_minmax2)) return UMHS_ERR_ARG;
+  if (n_classes > 16) return UMHS_ERR_UNSUPPORTED;
+  if (n_rays == 0) return UMHS_OK;
+  hipLaunchKernelGGL(ray_epilogue_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, umhs_s(stream), spectral, M,
+                     endmembers, accumulation, depth, reinterpret_cast<const uint32_t*>(tmid_minmax2), class_colors, n_rays,
+                     n_bands, n_classes, alpha, rgb, depth_clipped, seg_probs, seg_raw, seg_pred);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// losses[0] = w_spec * mean((spec - gt_spec)^2)             (umhs_model.py:366-369)
+// losses[1] = w_rgb  * mean((rgb + bg*(1-acc) - gt_rgb)^2)  (umhs_model.py:358-370, random background blend)
+// Forward call: losses != NULL, d_* == NULL.  Backward call: d_* != NULL, g_up = upstream gradients of the two
+// losses (device [2], NULL = 1): writes d_spec [R,B], d_rgb [R,3], d_acc [R].  One wave per ray.
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ spec, const float* __restrict__ gt_spec,
+                                                   const float* __restrict__ rgb, const float* __restrict__ acc,
+                                                   const float* __restrict__ bg, const float* __restrict__ gt_rgb,
+                                                   int64_t n_rays, int B, float w_spec, float w_rgb,
+                                                   const float* __restrict__ g_up, float* __restrict__ losses,
+                                                   float* __restrict__ d_spec, float* __restrict__ d_rgb,
+                                                   float* __restrict__ d_acc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool live = r < n_rays;
+  float ls = 0.0f, lr = 0.0f, ga = 0.0f;
+  const float gs = g_up ? g_up[0] : 1.0f, gr = g_up ? g_up[1] : 1.0f;
+  if (live) {
+    const float cs = gs * w_spec * 2.0f / ((float)n_rays * (float)B);
+    for (int b = lane; b < B; b += 64) {
+      const float d = spec[r * B + b] - gt_spec[r * B + b];
+      ls += d * d;
+      if (d_spec) d_spec[r * B + b] = cs * d;
+    }
+    if (rgb && lane < 3) {
+      const float beta = bg ? bg[3 * r + lane] : 0.0f;
+      const float d = rgb[3 * r + lane] + beta * (1.0f - acc[r]) - gt_rgb[3 * r + lane];
+      lr = d * d;
+      const float g = gr * w_rgb * 2.0f / ((float)n_rays * 3.0f) * d;
+      if (d_rgb) d_rgb[3 * r + lane] = g;
+      ga = -g * beta;  // d/d acc of beta*(1-acc)
+    }
+  }
+  ga = wave_reduce_sum(ga);
+  if (live && rgb && d_acc && lane == 0) d_acc[r] = ga;
+  if (!losses) return;
+  ls = wave_reduce_sum(ls), lr = wave_reduce_sum(lr);
+  __shared__ float part[2][4];
+  if (lane == 0) part[0][threadIdx.x >> 6] = ls, part[1][threadIdx.x >> 6] = lr;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&losses[0], (part[0][0] + part[0][1] + part[0][2] + part[0][3]) * (w_spec / ((float)n_rays * (float)B)));
+    if (rgb) atomicAdd(&losses[1], (part[1][0] + part[1][1] + part[1][2] + part[1][3]) * (w_rgb / ((float)n_rays * 3.0f)));
+  }
+}
+
+extern "C" int umhs_loss_fwd(const float* spectral, const float* gt_spectral, const float* rgb, const float* accumulation,
+                             const float* background, const float* gt_rgb, int64_t n_rays, int n_bands, float w_spectral,
+                             float w_rgb, float* losses2, umhs_stream_t stream) {
+  if (n_rays < 1 || n_bands < 1 || !spectral || !gt_spectral || !losses2) return UMHS_ERR_ARG;
+  if (rgb && (!accumulation || !gt_rgb)) return UMHS_ERR_ARG;
+  if (hipMemsetAsync(losses2, 0, 8, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
+  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), spectral, gt_spectral,
+                     rgb, accumulation, background, gt_rgb, n_rays, n_bands, w_spectral, w_rgb, (const float*)nullptr,
+                     losses2, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+extern "C" int umhs_loss_bwd(const float* spectral, const float* gt_spectral, const float* rgb, const float* accumulation,
+                             const float* background, const float* gt_rgb, int64_t n_rays, int n_bands, float w_spectral,
+                             float w_rgb, const float* grad_losses2, float* d_spectral, float* d_rgb, float* d_accumulation,
+                             umhs_stream_t stream) {
+  if (n_rays < 1 || n_bands < 1 || !spectral || !gt_spectral || !d_spectral) return UMHS_ERR_ARG;
+  if (rgb && (!accumulation || !gt_rgb || !d_rgb || !d_accumulation)) return UMHS_ERR_ARG;
+  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), spectral, gt_spectral,
+                     rgb, accumulation, background, gt_rgb, n_rays, n_bands, w_spectral, w_rgb, grad_losses2,
+                     (float*)nullptr, d_spectral, d_rgb, d_accumulation);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
 // Fused Adam over the flat "fields" parameter buffer (28 B/param of pure HBM streaming, float4 lanes)
 // =============================================================================================
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,

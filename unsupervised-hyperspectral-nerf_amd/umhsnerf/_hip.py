@@ -69,6 +69,10 @@ SIGNATURES = {
     "umhs_accumulate_bwd": (C.c_int, [_vp, _vp, _i64, _i64, C.POINTER(ValueGrads), _vp, _vp]),
     "umhs_spec2rgb_fwd": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "umhs_spec2rgb_bwd": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, C.c_int, _vp]),
+    "umhs_tmid_minmax": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "umhs_ray_epilogue_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "umhs_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp]),
+    "umhs_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "umhs_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _i64, _i64, _vp]),
 }
 

@@ -407,3 +407,73 @@ class AccumulateFn(torch.autograd.Function):
         _hip.check(_hip.lib().umhs_accumulate_bwd(ptr(w), ptr(pinfo), pinfo.shape[0], w.shape[0], C.byref(g), ptr(d_w),
                                                   _hip.stream()), "umhs_accumulate_bwd")
         return d_w.view(ctx.shapes[0]), d_v.view(ctx.shapes[1]), None
+
+
+def tmid_minmax(starts, ends) -> torch.Tensor:
+    """Encoded (min, max) of the sample mid-points over the batch; consumed by RayEpilogueFn only."""
+    t0, t1 = _hip.f32c(starts).view(-1), _hip.f32c(ends).view(-1)
+    mm = torch.empty(2, device=t0.device, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_tmid_minmax(ptr(t0), ptr(t1), t0.shape[0], ptr(mm), _hip.stream()), "umhs_tmid_minmax")
+    return mm
+
+
+class RayEpilogueFn(torch.autograd.Function):
+    """One launch for the per-ray tail of UMHSModel.get_outputs (umhs_model.py:254-313): ColourSystem, depth clip,
+    ClusterLookup(alpha) + argmax + class colours.  Returns (rgb, depth, seg_probs, seg_raw, seg_pred); gradient flows
+    through rgb only (no loss of the reference uses the segmentation outputs)."""
+
+    @staticmethod
+    def forward(ctx, spectral, M, endmembers, accumulation, depth, tminmax, colors, alpha: float):
+        s, m = _hip.f32c(spectral), _hip.f32c(M)
+        E = _hip.f32c(endmembers)
+        R, B = s.shape
+        Cn = E.shape[0]
+        new = lambda *shp: torch.empty(shp, device=s.device, dtype=torch.float32)
+        rgb, dclip, probs, raw, pred = new(R, 3), new(R, 1), new(R, Cn), new(R), new(R, 3)
+        _hip.check(_hip.lib().umhs_ray_epilogue_fwd(ptr(s), ptr(m), ptr(E), ptr(_hip.f32c(accumulation).view(-1)),
+                                                    ptr(_hip.f32c(depth).view(-1)), ptr(tminmax), ptr(_hip.f32c(colors)), R, B, Cn,
+                                                    float(alpha), ptr(rgb), ptr(dclip), ptr(probs), ptr(raw), ptr(pred),
+                                                    _hip.stream()), "umhs_ray_epilogue_fwd")
+        ctx.save_for_backward(s, m)
+        ctx.mark_non_differentiable(dclip, probs, raw, pred)
+        return rgb, dclip, probs, raw, pred
+
+    @staticmethod
+    def backward(ctx, d_rgb, *_):
+        s, m = ctx.saved_tensors
+        d_spec = spec2rgb_bwd(s, m, _hip.f32c(d_rgb)) if d_rgb is not None else None
+        return d_spec, None, None, None, None, None, None, None
+
+
+class LossFn(torch.autograd.Function):
+    """(w_spec * MSE(spectral, gt), w_rgb * MSE(rgb + bg*(1-acc), gt_rgb)) in one launch; backward in one launch
+    (umhs_model.py:358-370).  rgb/acc/bg/gt_rgb may be None (method == "spectral")."""
+
+    @staticmethod
+    def forward(ctx, spectral, gt_spectral, rgb, accumulation, background, gt_rgb, w_spec: float, w_rgb: float):
+        c = lambda t: _hip.f32c(t) if t is not None else None
+        s, g, r, bg, gr = c(spectral), c(gt_spectral), c(rgb), c(background), c(gt_rgb)
+        a = c(accumulation).view(-1) if accumulation is not None else None
+        R, B = s.shape
+        losses = torch.empty(2, device=s.device, dtype=torch.float32)
+        _hip.check(_hip.lib().umhs_loss_fwd(ptr(s), ptr(g), ptr(r), ptr(a), ptr(bg), ptr(gr), R, B, float(w_spec), float(w_rgb),
+                                            ptr(losses), _hip.stream()), "umhs_loss_fwd")
+        ctx.save_for_backward(*[t for t in (s, g, r, a, bg, gr) if t is not None])
+        ctx.has = [t is not None for t in (s, g, r, a, bg, gr)]
+        ctx.w = (float(w_spec), float(w_rgb))
+        ctx.acc_shape = accumulation.shape if accumulation is not None else None
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_spec, g_rgb):
+        it = iter(ctx.saved_tensors)
+        s, g, r, a, bg, gr = [(next(it) if h else None) for h in ctx.has]
+        R, B = s.shape
+        zero = lambda: torch.zeros((), device=s.device, dtype=torch.float32)
+        gl = torch.stack([g_spec if g_spec is not None else zero(), g_rgb if g_rgb is not None else zero()]).to(torch.float32)
+        d_spec = torch.empty_like(s)
+        d_rgb = torch.empty_like(r) if r is not None else None
+        d_acc = torch.empty_like(a) if r is not None else None
+        _hip.check(_hip.lib().umhs_loss_bwd(ptr(s), ptr(g), ptr(r), ptr(a), ptr(bg), ptr(gr), R, B, ctx.w[0], ctx.w[1], ptr(gl),
+                                            ptr(d_spec), ptr(d_rgb), ptr(d_acc), _hip.stream()), "umhs_loss_bwd")
+        return d_spec, None, d_rgb, (d_acc.view(ctx.acc_shape) if d_acc is not None else None), None, None, None, None

@@ -180,17 +180,16 @@ class UMHSModel(nn.Module):
         values.append(fo["abundances"])
         weights, accumulation, depth, *comp = ops.CompositeFn.apply(fo[FieldHeadNames.DENSITY], fr.starts, fr.ends, packed_info,
                                                                      bool(c.use_gradient_scaling), *values)
-        steps_min, steps_max = torch.aminmax((fr.starts + fr.ends) / 2)
-        outputs: Dict[str, Tensor] = {"accumulation": accumulation, "depth": torch.clip(depth, steps_min, steps_max)}
+        mm = ops.tmid_minmax(fr.starts, fr.ends)  # DepthRenderer clips to the batch-wide [min, max] of t_mid
         spectral = comp[0]
-        outputs["spectral"] = spectral
+        spec_for_rgb = spectral.detach() if c.method == "spectral" else spectral  # no_grad pseudo-rgb (:289-293)
+        rgb, depth_c, seg_probs, seg_raw, seg_pred = ops.RayEpilogueFn.apply(
+            spec_for_rgb, self.converter.transform_matrix, self.field.endmembers.detach(), accumulation, depth, mm,
+            self.class_colors, 0.2)
+        outputs: Dict[str, Tensor] = {"accumulation": accumulation, "depth": depth_c, "spectral": spectral}
         if c.pred_specular:
             outputs["spectral2"], outputs["specular"] = comp[1], comp[2]
-        if c.method == "spectral":
-            with torch.no_grad():
-                outputs["rgb"] = self.converter(spectral)
-        else:
-            outputs["rgb"] = self.converter(spectral)
+        outputs["rgb"] = rgb
         outputs["num_samples_per_ray"] = packed_info[:, 1]
         abund = comp[-1]
         outputs["abundances"] = abund
@@ -202,13 +201,7 @@ class UMHSModel(nn.Module):
                     outputs[f"residual_{i}"] = comp[2][..., i]
             for i in range(abund.shape[-1]):
                 outputs[f"abundances_{i}"] = abund[:, i]
-        _, cluster_probs = self.cluster_probe(spectral, alpha=0.2, clusters=self.field.endmembers)
-        outputs["seg_probs"] = cluster_probs
-        with torch.no_grad():
-            acc_if = (accumulation > 0.5).to(accumulation.dtype)
-            arg = cluster_probs.argmax(1)
-            outputs["seg_raw"] = arg * acc_if.squeeze(-1)
-            outputs["seg_pred"] = self.label_to_rgb(arg) * acc_if
+        outputs["seg_probs"], outputs["seg_raw"], outputs["seg_pred"] = seg_probs, seg_raw, seg_pred
         outputs["weights"] = weights
         return outputs
 
@@ -227,8 +220,17 @@ class UMHSModel(nn.Module):
         """umhs_model.py:329-383: 5*MSE(spectral) + rgb_loss_weight*MSE(rgb blended with a random background)."""
         loss_dict = {}
         image = batch["image"].to(self.device)
-        pred_rgb, gt_rgb = self.blend_background_for_loss_computation(outputs["rgb"], outputs["accumulation"], image)
         m = self.config.method
+        if m != "rgb" and image.shape[-1] == 3:  # fused path: both MSEs (+ random-background blend) in one launch
+            hs = batch["hs_image"].to(self.device)
+            if m == "spectral":
+                loss_dict["spectral_loss"], _ = ops.LossFn.apply(outputs["spectral"], hs, None, None, None, None, 1.0, 0.0)
+            else:
+                bg = torch.rand_like(outputs["rgb"]) if self.background_color == "random" else None
+                loss_dict["spectral_loss"], loss_dict["rgb_loss"] = ops.LossFn.apply(
+                    outputs["spectral"], hs, outputs["rgb"], outputs["accumulation"], bg, image, 5.0, float(self.config.rgb_loss_weight))
+            return loss_dict
+        pred_rgb, gt_rgb = self.blend_background_for_loss_computation(outputs["rgb"], outputs["accumulation"], image)
         if m == "rgb":
             loss_dict["rgb_loss"] = torch.nn.functional.mse_loss(pred_rgb, gt_rgb)
         elif m == "spectral":
