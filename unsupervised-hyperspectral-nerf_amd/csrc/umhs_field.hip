@@ -837,25 +837,40 @@ __device__ __forceinline__ int stage_col_to_in(int kind, int col) {
 
 __global__ __launch_bounds__(256) void field_reduce_kernel(const float* __restrict__ slabs, int nslabs, SlabLayout sl,
                                                            PackDesc pd, GradPtrs gp, int n_bias_items) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= sl.total_w + n_bias_items) return;
-  if (idx >= sl.total_w) {  // bias item: (layer, output) -> sum over workgroups and row groups
-    int o = idx - sl.total_w, l = 0;
+  // 64 slab entries per workgroup; the 4 waves each sum a quarter of the slabs (8 loads in flight), LDS combines
+  __shared__ float part[4][64];
+  const int e = threadIdx.x & 63, pw = threadIdx.x >> 6;
+  const int item = blockIdx.x * 64 + e;
+  const int nitems = sl.total_w + n_bias_items;
+  int src = -1, bias_l = -1, bias_o = 0;  // slab offset this item sums
+  if (item < sl.total_w) {
+    src = item;
+  } else if (item < nitems) {
+    int o = item - sl.total_w, l = 0;
     while (l < NLAYERS && o >= sl.cols[l]) o -= sl.cols[l], ++l;
-    if (l >= NLAYERS || l == L_MX) return;
-    float s = 0.0f;
-    for (int w = 0; w < nslabs; ++w) s += slabs[(size_t)w * sl.total + sl.off_db[l] + o];
-    if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
+    if (l < NLAYERS && l != L_MX) bias_l = l, bias_o = o, src = sl.off_db[l] + o;
+  }
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+  if (src >= 0) {
+    const int per = (nslabs + 3) / 4, w0 = pw * per, w1 = min(nslabs, w0 + per);
+    int w = w0;
+    for (; w + 7 < w1; w += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += slabs[(size_t)(w + k) * sl.total + src];
+    }
+    for (; w < w1; ++w) acc[0] += slabs[(size_t)w * sl.total + src];
+  }
+  part[pw][e] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (pw != 0 || src < 0) return;
+  const float s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  if (bias_l >= 0) {
+    if (bias_o < pd.L[bias_l].OUT && gp.b[bias_l]) gp.b[bias_l][bias_o] = s;
     return;
   }
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  int w = 0;
-  for (; w + 3 < nslabs; w += 4) {  // 4 independent loads in flight per thread
-    s0 += slabs[(size_t)w * sl.total + idx], s1 += slabs[(size_t)(w + 1) * sl.total + idx];
-    s2 += slabs[(size_t)(w + 2) * sl.total + idx], s3 += slabs[(size_t)(w + 3) * sl.total + idx];
-  }
-  for (; w < nslabs; ++w) s0 += slabs[(size_t)w * sl.total + idx];
-  const float s = (s0 + s1) + (s2 + s3);
+  const int idx = item;
   for (int l = 0; l < NLAYERS; ++l) {
     const LayerDesc& L = pd.L[l];
     const int nw = sl.waves * sl.nacc[l] * 256;
@@ -1192,7 +1207,7 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
   const PackDesc& pd_all = pl.pd_all;
   const int items = pl.sl.total_w + pl.n_bias_items;
-  hipLaunchKernelGGL(field_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, umhs_s(stream), (const float*)slabs,
+  hipLaunchKernelGGL(field_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, umhs_s(stream), (const float*)slabs,
                      (int)grid, pl.sl, pd_all, gp, pl.n_bias_items);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;

@@ -904,7 +904,13 @@ __global__ __launch_bounds__(256) void tmid_minmax_kernel(const float* __restric
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) lo = fminf(lo, __shfl_xor(lo, d, 64)), hi = fmaxf(hi, __shfl_xor(hi, d, 64));
-  if ((threadIdx.x & 63) == 0) atomicMin(&mm[0], f2ord(lo)), atomicMax(&mm[1], f2ord(hi));
+  __shared__ float plo[4], phi[4];
+  if ((threadIdx.x & 63) == 0) plo[threadIdx.x >> 6] = lo, phi[threadIdx.x >> 6] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic pair per workgroup (memory-side atomics on two words serialise)
+    atomicMin(&mm[0], f2ord(fminf(fminf(plo[0], plo[1]), fminf(plo[2], plo[3]))));
+    atomicMax(&mm[1], f2ord(fmaxf(fmaxf(phi[0], phi[1]), fmaxf(phi[2], phi[3]))));
+  }
 }
 
 extern "C" int umhs_tmid_minmax(const float* t_starts, const float* t_ends, int64_t n, float* minmax2, umhs_stream_t stream) {
@@ -912,8 +918,8 @@ extern "C" int umhs_tmid_minmax(const float* t_starts, const float* t_ends, int6
   const uint32_t init[2] = {0xffffffffu, 0u};
   if (hipMemcpyAsync(minmax2, init, 8, hipMemcpyHostToDevice, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
   if (n == 0) return UMHS_OK;
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  int64_t blocks = (n + 2047) / 2048;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(tmid_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, umhs_s(stream), t_starts, t_ends, n,
                      reinterpret_cast<uint32_t*>(minmax2));
   UMHS_CHECK_LAUNCH();
@@ -1009,28 +1015,31 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ spe
                                                    float* __restrict__ d_spec, float* __restrict__ d_rgb,
                                                    float* __restrict__ d_acc) {
   const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const bool live = r < n_rays;
-  float ls = 0.0f, lr = 0.0f, ga = 0.0f;
+  float ls = 0.0f, lr = 0.0f;
   const float gs = g_up ? g_up[0] : 1.0f, gr = g_up ? g_up[1] : 1.0f;
-  if (live) {
-    const float cs = gs * w_spec * 2.0f / ((float)n_rays * (float)B);
-    for (int b = lane; b < B; b += 64) {
-      const float d = spec[r * B + b] - gt_spec[r * B + b];
-      ls += d * d;
-      if (d_spec) d_spec[r * B + b] = cs * d;
+  const float cs = gs * w_spec * 2.0f / ((float)n_rays * (float)B);
+  for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < n_rays; r0 += (int64_t)gridDim.x * 4) {  // wave-uniform trip count
+    const int64_t r = r0 + (threadIdx.x >> 6);
+    const bool live = r < n_rays;
+    float ga = 0.0f;
+    if (live) {
+      for (int b = lane; b < B; b += 64) {
+        const float d = spec[r * B + b] - gt_spec[r * B + b];
+        ls += d * d;
+        if (d_spec) d_spec[r * B + b] = cs * d;
+      }
+      if (rgb && lane < 3) {
+        const float beta = bg ? bg[3 * r + lane] : 0.0f;
+        const float d = rgb[3 * r + lane] + beta * (1.0f - acc[r]) - gt_rgb[3 * r + lane];
+        lr += d * d;
+        const float g = gr * w_rgb * 2.0f / ((float)n_rays * 3.0f) * d;
+        if (d_rgb) d_rgb[3 * r + lane] = g;
+        ga = -g * beta;  // d/d acc of beta*(1-acc)
+      }
     }
-    if (rgb && lane < 3) {
-      const float beta = bg ? bg[3 * r + lane] : 0.0f;
-      const float d = rgb[3 * r + lane] + beta * (1.0f - acc[r]) - gt_rgb[3 * r + lane];
-      lr = d * d;
-      const float g = gr * w_rgb * 2.0f / ((float)n_rays * 3.0f) * d;
-      if (d_rgb) d_rgb[3 * r + lane] = g;
-      ga = -g * beta;  // d/d acc of beta*(1-acc)
-    }
+    ga = wave_reduce_sum(ga);
+    if (live && rgb && d_acc && lane == 0) d_acc[r] = ga;
   }
-  ga = wave_reduce_sum(ga);
-  if (live && rgb && d_acc && lane == 0) d_acc[r] = ga;
   if (!losses) return;
   ls = wave_reduce_sum(ls), lr = wave_reduce_sum(lr);
   __shared__ float part[2][4];
@@ -1048,8 +1057,9 @@ extern "C" int umhs_loss_fwd(const float* spectral, const float* gt_spectral, co
   if (n_rays < 1 || n_bands < 1 || !spectral || !gt_spectral || !losses2) return UMHS_ERR_ARG;
   if (rgb && (!accumulation || !gt_rgb)) return UMHS_ERR_ARG;
   if (hipMemsetAsync(losses2, 0, 8, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
-  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), spectral, gt_spectral,
-                     rgb, accumulation, background, gt_rgb, n_rays, n_bands, w_spectral, w_rgb, (const float*)nullptr,
+  hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((n_rays + 3) / 4 < 256 ? (n_rays + 3) / 4 : 256)), dim3(256), 0,
+                     umhs_s(stream), spectral, gt_spectral, rgb, accumulation, background, gt_rgb, n_rays, n_bands,
+                     w_spectral, w_rgb, (const float*)nullptr,
                      losses2, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;

@@ -250,7 +250,7 @@ def composite_bwd(sigma, t0, t1, packed_info, weights, values, d_outs, want_dval
         d_values.append(dv)
         k += 1
     g.n_streams = k
-    d_sigma = torch.zeros((n,), device=dev, dtype=torch.float32)
+    d_sigma = torch.empty((n,), device=dev, dtype=torch.float32)  # every packed sample belongs to a ray: fully written
     _hip.check(_hip.lib().umhs_composite_bwd(ptr(sigma), ptr(t0), ptr(t1), ptr(packed_info), R, n, ptr(weights), C.byref(g),
                                              ptr(d_acc), int(grad_scaling), ptr(d_sigma), _hip.stream()), "umhs_composite_bwd")
     return d_sigma, d_values
@@ -288,6 +288,7 @@ class FieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flat, origins, directions, starts, ends, spec: FieldSpec):
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None instead of freshly filled zero tensors
         L = spec.layout
         o, d = _hip.f32c(origins), _hip.f32c(directions)
         s, e = _hip.f32c(starts).view(-1), _hip.f32c(ends).view(-1)
@@ -343,6 +344,7 @@ class CompositeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sigma, starts, ends, packed_info, grad_scaling: bool, *values):
+        ctx.set_materialize_grads(False)
         s = _hip.f32c(sigma).view(-1)
         t0, t1 = _hip.f32c(starts).view(-1), _hip.f32c(ends).view(-1)
         vals = [_hip.f32c(v).view(v.shape[-2], v.shape[-1]) for v in values]
@@ -424,6 +426,7 @@ class RayEpilogueFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spectral, M, endmembers, accumulation, depth, tminmax, colors, alpha: float):
+        ctx.set_materialize_grads(False)
         s, m = _hip.f32c(spectral), _hip.f32c(M)
         E = _hip.f32c(endmembers)
         R, B = s.shape
@@ -451,6 +454,7 @@ class LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spectral, gt_spectral, rgb, accumulation, background, gt_rgb, w_spec: float, w_rgb: float):
+        ctx.set_materialize_grads(False)
         c = lambda t: _hip.f32c(t) if t is not None else None
         s, g, r, bg, gr = c(spectral), c(gt_spectral), c(rgb), c(background), c(gt_rgb)
         a = c(accumulation).view(-1) if accumulation is not None else None
