@@ -427,12 +427,18 @@ __global__ __launch_bounds__(256) void field_pack_T_kernel(TPackDesc td, float* 
   }
 }
 
-// ---- LDS staging of [sample][feature] tiles (row stride FS = 16 mod 32: conflict-free transposed reads)
+// ---- LDS staging of [sample][feature] tiles.  Row stride FS = 16 (mod 32) makes the transposed ds_read_b32 of the dW
+// products conflict-free (4 consecutive rows per instruction); but ds_write_b128 works in 8-lane groups = 8 consecutive
+// rows, and rows r, r+2 would share banks (4-way conflict, measured: SQ_LDS_BANK_CONFLICT > SQ_ACTIVE_INST_LDS).  So each
+// row is rotated by 4*((r>>1)&3) floats inside its padding: 8 consecutive rows hit 8 distinct bank quads, while the two
+// rows of a read pair keep a common rotation.  Every tile therefore needs FS >= features + 12.
+__device__ __forceinline__ int swz(int row) { return 4 * ((row >> 1) & 3); }
+
 template <int OT>
 __device__ __forceinline__ void stage_hid(float* st, int FS, int row, int q, const float (&x)[OT * 4]) {
 #pragma unroll
   for (int t = 0; t < OT; ++t)
-    *reinterpret_cast<v4f*>(st + row * FS + 16 * t + 4 * q) = v4f{x[4 * t], x[4 * t + 1], x[4 * t + 2], x[4 * t + 3]};
+    *reinterpret_cast<v4f*>(st + row * FS + swz(row) + 16 * t + 4 * q) = v4f{x[4 * t], x[4 * t + 1], x[4 * t + 2], x[4 * t + 3]};
 }
 
 // dW tile pairs of one layer, split over the WAVES waves of the workgroup.  TI divides WAVES, so every pair of a
@@ -447,14 +453,15 @@ __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restri
   const int j = lane & 15, q = lane >> 4;
   const int ti = wave % TI, to0 = wave / TI, tstep = WAVES / TI;
   if (to0 >= TO) return;
-  const float* __restrict__ px = stX + q * FSx + 16 * ti + j;
-  const float* __restrict__ pz = stZ + q * FSz + 16 * to0 + j;
+  // row 4ks+q is rotated by swz = 4*(((2ks)&3) + (q>>1)) = 8*(ks&1) + 4*(q>>1)
+  const float* __restrict__ px = stX + q * FSx + 16 * ti + j + 4 * (q >> 1);
+  const float* __restrict__ pz = stZ + q * FSz + 16 * to0 + j + 4 * (q >> 1);
 #pragma unroll 8
   for (int ks = 0; ks < 4 * WAVES; ++ks) {
-    const float b = px[4 * ks * FSx];
+    const float b = px[4 * ks * FSx + 8 * (ks & 1)];
 #pragma unroll
     for (int idx = 0; idx < NACC; ++idx) {
-      if (to0 + idx * tstep < TO) acc[idx] = MFMA(pz[4 * ks * FSz + 16 * idx * tstep], b, acc[idx]);
+      if (to0 + idx * tstep < TO) acc[idx] = MFMA(pz[4 * ks * FSz + 8 * (ks & 1) + 16 * idx * tstep], b, acc[idx]);
     }
   }
 }
@@ -470,7 +477,7 @@ __device__ __forceinline__ float col_sum_part(const float* __restrict__ st, int 
   if (rg >= RG) return 0.0f;
   const int rpg = (S + RG - 1) / RG, r0 = rg * rpg, r1 = min(S, r0 + rpg);
   float s = 0.0f;
-  for (int r = r0; r < r1; ++r) s += st[r * FS + col];
+  for (int r = r0; r < r1; ++r) s += st[r * FS + swz(r) + col];
   return s;
 }
 
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
   float* const stX = st + S * 80;   // [S][<=80]
   float* const stZd = st;           // [S][FSd]   dZ of mlp_directional's output layer
   float* const stXh = st + S * FSd; // [S][16]    hidden of mlp_directional
-  float* const stXm = stXh + S * 16;  // [S][16]  mixing coefficients m
+  float* const stXm = stXh + S * 48;  // [S][16]  mixing coefficients m   (16-wide tiles use FS = 48: 16 + 12 + pad)
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t n0 = tile * S;
     int64_t n = n0 + row;
@@ -609,23 +616,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
           dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
         }
         gemm_pack<1, 4, NT, false>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
-        *reinterpret_cast<v4f*>(stZd + row * FSd + 16 * t + 4 * q) = v4f{dzd[0][0], dzd[0][1], dzd[0][2], dzd[0][3]};
+        *reinterpret_cast<v4f*>(stZd + row * FSd + swz(row) + 16 * t + 4 * q) = v4f{dzd[0][0], dzd[0][1], dzd[0][2], dzd[0][3]};
       }
     }
-    if (SPEC) *reinterpret_cast<v4f*>(stXh + row * 16 + 4 * q) = v4f{hdir[0][0], hdir[0][1], hdir[0][2], hdir[0][3]};
-    *reinterpret_cast<v4f*>(stXm + row * 16 + 4 * q) = v4f{hs.m[0][0], hs.m[0][1], hs.m[0][2], hs.m[0][3]};
+    if (SPEC) *reinterpret_cast<v4f*>(stXh + row * 48 + swz(row) + 4 * q) = v4f{hdir[0][0], hdir[0][1], hdir[0][2], hdir[0][3]};
+    *reinterpret_cast<v4f*>(stXm + row * 48 + swz(row) + 4 * q) = v4f{hs.m[0][0], hs.m[0][1], hs.m[0][2], hs.m[0][3]};
     ds1 = xq_sum(ds1);
     BSYNC();
     if (SPEC) {
-      dw_accum<NA, WAVES>(aD1, stZd, FSd, stXh, 16, TB, 1, wave, lane);
+      dw_accum<NA, WAVES>(aD1, stZd, FSd, stXh, 48, TB, 1, wave, lane);
       dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
     }
     {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: its rows are samples)
-      const float* __restrict__ pm = stXm + q * 16 + j;
+      const float* __restrict__ pm = stXm + q * 48 + j + 4 * (q >> 1);
 #pragma unroll 8
       for (int ks = 0; ks < 4 * WAVES; ++ks) {
         const int64_t ns = n0 + 4 * ks + q;
-        const float bm = pm[4 * ks * 16];
+        const float bm = pm[4 * ks * 48 + 8 * (ks & 1)];
 #pragma unroll
         for (int idx = 0; idx < NA; ++idx) {
           const int to = wave + idx * WAVES;
@@ -665,14 +672,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
       BSYNC();
-      *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dz[0], dz[1], dz[2], dz[3]};
-      *reinterpret_cast<v4f*>(stX + row * 48 + 4 * q) = v4f{dir28[0][0], dir28[0][1], dir28[0][2], dir28[0][3]};
+      *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dz[0], dz[1], dz[2], dz[3]};
+      *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 4 * q) = v4f{dir28[0][0], dir28[0][1], dir28[0][2], dir28[0][3]};
 #pragma unroll
-      for (int s = 0; s < 3; ++s) stX[row * 48 + 16 + 3 * q + s] = dir28[0][4 + s];
-      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 16 + 3 * q + s] = dir28[0][4 + s];
+      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       BSYNC();
-      dw_accum<1, WAVES>(aD0, stZ, 16, stX, 48, 1, 2, wave, lane);
-      dbD0 += col_sum_part<WAVES>(stZ, 16, 16, tid);
+      dw_accum<1, WAVES>(aD0, stZ, 48, stX, 48, 1, 2, wave, lane);
+      dbD0 += col_sum_part<WAVES>(stZ, 48, 16, tid);
     }
     v4f dbo4[NT][1];
     dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
@@ -681,11 +688,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
                         v4f(&acc1)[NH1], v4f(&acc0)[NH0], float& db2, float& db1, float& db0, int t2, int t1,
                         int t0) __attribute__((always_inline)) {
       BSYNC();
-      *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
+      *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
       stage_hid<4>(stX, 80, row, q, a2[0]);
       BSYNC();
-      dw_accum<1, WAVES>(acc2, stZ, 16, stX, 80, 1, 4, wave, lane);
-      db2 += col_sum_part<WAVES>(stZ, 16, 16, tid);
+      dw_accum<1, WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
+      db2 += col_sum_part<WAVES>(stZ, 48, 16, tid);
       v4f g4[NT][4];
       gemm_pack<4, 4, NT, true>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
       float dz1[NT][16];
@@ -705,9 +712,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       stage_hid<4>(stZ, 80, row, q, dz0[0]);
       // X = [pe(12) | base-MLP output slots(16)] : 28 columns, 28..31 zero
 #pragma unroll
-      for (int s = 0; s < 3; ++s) stX[row * 48 + 3 * q + s] = in27[0][s];
-      *reinterpret_cast<v4f*>(stX + row * 48 + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
-      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 3 * q + s] = in27[0][s];
+      *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
+      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       BSYNC();
       dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
       db0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
@@ -786,11 +793,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
       }
     }
     BSYNC();
-    *reinterpret_cast<v4f*>(stZ + row * 16 + 4 * q) = v4f{dzb1[0][0], dzb1[0][1], dzb1[0][2], dzb1[0][3]};
+    *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzb1[0][0], dzb1[0][1], dzb1[0][2], dzb1[0][3]};
     stage_hid<4>(stX, 80, row, q, h[0]);
     BSYNC();
-    dw_accum<1, WAVES>(aB1, stZ, 16, stX, 80, 1, 4, wave, lane);
-    dbB1 += col_sum_part<WAVES>(stZ, 16, 16, tid);
+    dw_accum<1, WAVES>(aB1, stZ, 48, stX, 80, 1, 4, wave, lane);
+    dbB1 += col_sum_part<WAVES>(stZ, 48, 16, tid);
     v4f g4[NT][4];
     gemm_pack<4, 4, NT, true>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
     float dzb0[NT][16];
@@ -798,8 +805,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
     BSYNC();
     stage_hid<4>(stZ, 80, row, q, dzb0[0]);
-    *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q) = v4f{encf[0][0], encf[0][1], encf[0][2], encf[0][3]};
-    *reinterpret_cast<v4f*>(stX + row * 48 + 8 * q + 4) = v4f{encf[0][4], encf[0][5], encf[0][6], encf[0][7]};
+    *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 8 * q) = v4f{encf[0][0], encf[0][1], encf[0][2], encf[0][3]};
+    *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 8 * q + 4) = v4f{encf[0][4], encf[0][5], encf[0][6], encf[0][7]};
     BSYNC();
     dw_accum<NB0, WAVES>(aB0, stZ, 80, stX, 48, 4, 2, wave, lane);
     dbB0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
@@ -1043,9 +1050,9 @@ static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p,
   rc = build_pack_desc(cfg, p, &pl->pd_base, &TB, 1);
   if (rc) return rc;
   pl->TB = TB;
-  pl->FSd = (TB & 1) ? 16 * TB : 16 * TB + 16;
+  pl->FSd = 16 + 32 * ((16 * TB - 4 + 31) / 32);  // >= 16*TB + 12 (row rotation), = 16 (mod 32)
   auto stage_floats = [&](int S) {
-    const int tail = S * pl->FSd + 2 * S * 16;
+    const int tail = S * pl->FSd + 2 * S * 48;
     return tail > 2 * S * 80 ? tail : 2 * S * 80;
   };
   pl->stage_off_h = (pl->pd_all.total - pl->first + 3) & ~3;
