@@ -456,7 +456,7 @@ __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restri
   // row 4ks+q is rotated by swz = 4*(((2ks)&3) + (q>>1)) = 8*(ks&1) + 4*(q>>1)
   const float* __restrict__ px = stX + q * FSx + 16 * ti + j + 4 * (q >> 1);
   const float* __restrict__ pz = stZ + q * FSz + 16 * to0 + j + 4 * (q >> 1);
-#pragma unroll 8
+#pragma unroll 4
   for (int ks = 0; ks < 4 * WAVES; ++ks) {
     const float b = px[4 * ks * FSx + 8 * (ks & 1)];
 #pragma unroll
@@ -571,18 +571,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
         for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
       }
     }
-    float a1h[NT][16], a2h[NT][16], a1f[NT][16], a2f[NT][16];
+    // The feature MLP's hidden activations are NOT kept across the head MLP's backward: they are recomputed right
+    // before their own backward (+92 MFMAs per tile) so that 32 fewer registers are live -- at 2 waves/SIMD the
+    // kernel is capped at 256 VGPRs and every spilled dword costs a scratch round trip behind s_waitcnt vmcnt.
+    float a1h[NT][16], a2h[NT][16];
     v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
     gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
     relu_to<4, NT>(a1h, t4);
     gemm_pack<4, 16, NT, true>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
     relu_to<4, NT>(a2h, t4);
     gemm_pack<1, 16, NT, true>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
-    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
-    relu_to<4, NT>(a1f, t4);
-    gemm_pack<4, 16, NT, true>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
-    relu_to<4, NT>(a2f, t4);
-    gemm_pack<1, 16, NT, true>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    {
+      float a1f[NT][16], a2f[NT][16];
+      gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+      relu_to<4, NT>(a1f, t4);
+      gemm_pack<4, 16, NT, true>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+      relu_to<4, NT>(a2f, t4);
+      gemm_pack<1, 16, NT, true>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    }
     HeadState<NT> hs;
     head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
     float hdir[NT][4];
@@ -721,7 +727,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       gemm_pack<1, 16, NT, false>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
     };
     mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
-    mlp3_bwd(dfl, a2f, a1f, aF2, aF1, aF0, dbF2, dbF1, dbF0, T_F2, T_F1, T_F0);
+    {
+      float a1f[NT][16], a2f[NT][16];
+      gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+      relu_to<4, NT>(a1f, t4);
+      gemm_pack<4, 16, NT, true>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+      relu_to<4, NT>(a2f, t4);
+      mlp3_bwd(dfl, a2f, a1f, aF2, aF1, aF0, dbF2, dbF1, dbF0, T_F2, T_F1, T_F0);
+    }
     if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
   }
   float* const slab = slabs + (size_t)blockIdx.x * sl.total;
