@@ -110,15 +110,18 @@ __device__ __forceinline__ void load_fwd_image(float* lds, const PackDesc& pd, c
 }
 
 // acc[ct][t] (+)= W-pack(t, :) x B-operand regs b[ct][:]   (A from LDS or global, 16 B per lane per 4 k-steps)
-template <int OT, int KS, int NT, bool INIT>
+// INIT: 0 = accumulate into acc, 1 = start from zero, 2 = start from the bias (compile-time: a runtime `if (bias)` is a
+// real branch -- LDS address 0 is valid -- and every branch ends a scheduling region, pinning the operand loads to
+// their gemm instead of letting them be hoisted over the previous one)
+template <int OT, int KS, int NT, int INIT>
 __device__ __forceinline__ void gemm_pack(v4f (&acc)[NT][OT], const float (&b)[NT][KS], const float* __restrict__ w,
                                           const float* __restrict__ bias, int lane) {
   constexpr int KS4 = (KS + 3) / 4;
-  if (INIT) {
+  if (INIT != 0) {
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
       v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (bias) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+      if (INIT == 2) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) acc[ct][t] = bv;
     }
@@ -180,6 +183,7 @@ struct FieldIO {
   // backward
   const float *d_sigma, *d_spectral, *d_emb;
   float* d_enc;
+  int stagger;                         // forward, 8-wave variant: waves 4-7 start this many x 4096 cycles late
   const float *emb_in, *sigma_raw_in;  // saved forward outputs (heads / base backward)
   float* d_bo;                         // [N,16] gradient w.r.t. the base MLP's outputs (heads -> base)
 };
@@ -259,6 +263,28 @@ __device__ __forceinline__ void head_epilogue(HeadState<NT>& hs, const v4f (&hd4
   }
 }
 
+template <int NT>
+__device__ __forceinline__ void store_density(const FieldIO& io, const v4f (&bo4)[NT][1], const int64_t (&nn)[NT],
+                                              const bool (&ok)[NT], int q) {
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    if (ok[ct]) {
+      if (q == 0) {
+        const float raw = bo4[ct][0][0];
+        io.sigma[nn[ct]] = expf(raw) * io.sel[nn[ct]];
+        if (io.sigma_raw) io.sigma_raw[nn[ct]] = raw;
+      }
+      if (io.emb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = 4 * q + r - 1;
+          if (e >= 0) io.emb[nn[ct] * 15 + e] = bo4[ct][0][r];
+        }
+      }
+    }
+  }
+}
+
 // =============================================================================================
 // Forward
 // =============================================================================================
@@ -271,6 +297,13 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
   constexpr int TILE = 16 * NT * WAVES;  // samples per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int64_t ntiles = (io.n + TILE - 1) / TILE;
+  if (WAVES == 8 && io.stagger > 0) {
+    // Waves w and w+4 of an 8-wave workgroup share a SIMD and run the same program: left alone they move in
+    // lockstep (both in their VALU-only stretches together, matrix pipe idle).  Delay the second half once by
+    // about half an iteration so one wave's MFMA chains cover the other's encodings / epilogue / stores.
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4)
+      for (int i = 0; i < io.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t nn[NT];
     bool ok[NT];
@@ -288,84 +321,67 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
         const float2 v = *reinterpret_cast<const float2*>(io.enc + nn[ct] * io.sn + (int64_t)(4 * q + lv) * io.sl);
         encf[ct][2 * lv] = v.x, encf[ct][2 * lv + 1] = v.y;
       }
+    // ---- encodings first (sinf's slow path and the loads branch; keep them out of the gemm chain) --------
+    float pe_[NT][3], sh_[NT][4];
+    if (!DENSITY_ONLY) {
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        pe_slots(pe_[ct], io.wpos[3 * nn[ct]], io.wpos[3 * nn[ct] + 1], io.wpos[3 * nn[ct] + 2], q);
+        if (SPEC) sh_slots(sh_[ct], io.dirs[3 * nn[ct]], io.dirs[3 * nn[ct] + 1], io.dirs[3 * nn[ct] + 2], q);
+      }
+    }
     // ---- mlp_base: 32 -> 64 -> 16 -------------------------------------------------------------
     v4f h4[NT][4];
-    gemm_pack<4, 8, NT, true>(h4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+    gemm_pack<4, 8, NT, 2>(h4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
     float h[NT][16];
     relu_to<4, NT>(h, h4);
     v4f bo4[NT][1];
-    gemm_pack<1, 16, NT, true>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-      if (ok[ct]) {
-        if (q == 0) {
-          const float raw = bo4[ct][0][0];
-          io.sigma[nn[ct]] = expf(raw) * io.sel[nn[ct]];
-          if (io.sigma_raw) io.sigma_raw[nn[ct]] = raw;
-        }
-        if (io.emb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int e = 4 * q + r - 1;
-            if (e >= 0) io.emb[nn[ct] * 15 + e] = bo4[ct][0][r];
-          }
-        }
-      }
+    gemm_pack<1, 16, NT, 2>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+    if (DENSITY_ONLY) {
+      store_density<NT>(io, bo4, nn, ok, q);
+      continue;
     }
-    if (DENSITY_ONLY) continue;
-    // ---- encodings -----------------------------------------------------------------------------
     float in27[NT][7], dir28[NT][7];
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
-      float pe[3];
-      pe_slots(pe, io.wpos[3 * nn[ct]], io.wpos[3 * nn[ct] + 1], io.wpos[3 * nn[ct] + 2], q);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) in27[ct][s] = pe[s];
+      for (int s = 0; s < 3; ++s) in27[ct][s] = pe_[ct][s];
 #pragma unroll
       for (int r = 0; r < 4; ++r) in27[ct][3 + r] = bo4[ct][0][r];
       if (SPEC) {
-        float sh[4];
-        sh_slots(sh, io.dirs[3 * nn[ct]], io.dirs[3 * nn[ct] + 1], io.dirs[3 * nn[ct] + 2], q);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) dir28[ct][s] = sh[s];
+        for (int s = 0; s < 4; ++s) dir28[ct][s] = sh_[ct][s];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) dir28[ct][4 + s] = pe[s];
+        for (int s = 0; s < 3; ++s) dir28[ct][4 + s] = pe_[ct][s];
       }
     }
     // ---- mlp_head / feature_mlp: 27 -> 64 -> 64 -> C(+1) ----------------------------------------
     v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
     float a1[NT][16], a2[NT][16];
-    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
     relu_to<4, NT>(a1, t4);
-    gemm_pack<4, 16, NT, true>(t4, a1, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+    gemm_pack<4, 16, NT, 2>(t4, a1, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
     relu_to<4, NT>(a2, t4);
-    gemm_pack<1, 16, NT, true>(hd4, a2, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
-    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+    gemm_pack<1, 16, NT, 2>(hd4, a2, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
     relu_to<4, NT>(a1, t4);
-    gemm_pack<4, 16, NT, true>(t4, a1, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+    gemm_pack<4, 16, NT, 2>(t4, a1, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
     relu_to<4, NT>(a2, t4);
-    gemm_pack<1, 16, NT, true>(fl4, a2, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    gemm_pack<1, 16, NT, 2>(fl4, a2, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
     HeadState<NT> hs;
     head_epilogue<NT, SPEC>(hs, hd4, fl4, io.C, io.temperature, lane);
-    if (io.abund) {
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ok[ct] && 4 * q + r < io.C) io.abund[nn[ct] * io.C + 4 * q + r] = hs.ab[ct][r];
-    }
     // ---- mlp_directional hidden: 28 -> 16 ---------------------------------------------------------
     float hdir[NT][4];
     if (SPEC) {
       v4f d4[NT][1];
-      gemm_pack<1, 7, NT, true>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+      gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
       relu_to<1, NT>(hdir, d4);
     }
     // ---- per 16-band tile: mixing (K = classes) and specular (K = 16 hidden) -------------------------
     for (int t = 0; t < io.TB; ++t) {
       v4f sp[NT][1], sc[NT][1];
-      gemm_pack<1, 4, NT, true>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
-      if (SPEC) gemm_pack<1, 4, NT, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+      gemm_pack<1, 4, NT, 1>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
+      if (SPEC) gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
@@ -381,6 +397,15 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
           }
         }
       }
+    }
+    // ---- per-sample scalars last (conditional stores = branches) -----------------------------------
+    store_density<NT>(io, bo4, nn, ok, q);
+    if (io.abund) {
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ok[ct] && 4 * q + r < io.C) io.abund[nn[ct] * io.C + 4 * q + r] = hs.ab[ct][r];
     }
   }
 }
@@ -576,25 +601,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
     // kernel is capped at 256 VGPRs and every spilled dword costs a scratch round trip behind s_waitcnt vmcnt.
     float a1h[NT][16], a2h[NT][16];
     v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
-    gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
     relu_to<4, NT>(a1h, t4);
-    gemm_pack<4, 16, NT, true>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+    gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
     relu_to<4, NT>(a2h, t4);
-    gemm_pack<1, 16, NT, true>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+    gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
     {
       float a1f[NT][16], a2f[NT][16];
-      gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
       relu_to<4, NT>(a1f, t4);
-      gemm_pack<4, 16, NT, true>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+      gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
       relu_to<4, NT>(a2f, t4);
-      gemm_pack<1, 16, NT, true>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+      gemm_pack<1, 16, NT, 2>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
     }
     HeadState<NT> hs;
     head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
     float hdir[NT][4];
     if (SPEC) {
       v4f d4[NT][1];
-      gemm_pack<1, 7, NT, true>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+      gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
       relu_to<1, NT>(hdir, d4);
     }
     // =================== phase A: band tiles (mixing + specular tail) ============================
@@ -610,10 +635,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
         const int b = 16 * t + 4 * q + r;
         dsp[0][r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
       }
-      gemm_pack<1, 4, NT, false>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+      gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
       if (SPEC) {
         v4f sc[NT][1];
-        gemm_pack<1, 4, NT, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+        gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
         float dzd[NT][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -621,7 +646,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
           ds1 += dsp[0][r] * sp;
           dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
         }
-        gemm_pack<1, 4, NT, false>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
+        gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
         *reinterpret_cast<v4f*>(stZd + row * FSd + swz(row) + 16 * t + 4 * q) = v4f{dzd[0][0], dzd[0][1], dzd[0][2], dzd[0][3]};
       }
     }
@@ -700,7 +725,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       dw_accum<1, WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
       db2 += col_sum_part<WAVES>(stZ, 48, 16, tid);
       v4f g4[NT][4];
-      gemm_pack<4, 4, NT, true>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
+      gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
       float dz1[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
@@ -710,7 +735,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       BSYNC();
       dw_accum<NH1, WAVES>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
       db1 += col_sum_part<WAVES>(stZ, 80, 64, tid);
-      gemm_pack<4, 16, NT, true>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
+      gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
       float dz0[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
@@ -724,14 +749,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       BSYNC();
       dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
       db0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
-      gemm_pack<1, 16, NT, false>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
+      gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
     };
     mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
     {
       float a1f[NT][16], a2f[NT][16];
-      gemm_pack<4, 7, NT, true>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
       relu_to<4, NT>(a1f, t4);
-      gemm_pack<4, 16, NT, true>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+      gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
       relu_to<4, NT>(a2f, t4);
       mlp3_bwd(dfl, a2f, a1f, aF2, aF1, aF0, dbF2, dbF1, dbF0, T_F2, T_F1, T_F0);
     }
@@ -788,7 +813,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     }
     v4f t4[NT][4];
     float h[NT][16];
-    gemm_pack<4, 8, NT, true>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+    gemm_pack<4, 8, NT, 2>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
     relu_to<4, NT>(h, t4);
     float dzb1[NT][4];
     {
@@ -812,7 +837,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     dw_accum<1, WAVES>(aB1, stZ, 48, stX, 80, 1, 4, wave, lane);
     dbB1 += col_sum_part<WAVES>(stZ, 48, 16, tid);
     v4f g4[NT][4];
-    gemm_pack<4, 4, NT, true>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
+    gemm_pack<4, 4, NT, 1>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
     float dzb0[NT][16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
@@ -824,7 +849,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     dw_accum<NB0, WAVES>(aB0, stZ, 80, stX, 48, 4, 2, wave, lane);
     dbB0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
     v4f de4[NT][2];
-    gemm_pack<2, 16, NT, true>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
+    gemm_pack<2, 16, NT, 1>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
     if (ok && io.d_enc) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1009,6 +1034,7 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances;
+  io.stagger = getenv("UMHS_FWD_STAGGER") ? atoi(getenv("UMHS_FWD_STAGGER")) : 0;
   const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
   static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;  // tuning knob
   const int tile_samples = 128;  // every variant processes 128 samples per workgroup iteration
