@@ -220,9 +220,29 @@ struct HbArgs {
   float2* rec_val;
 };
 
-__device__ __forceinline__ void seg_scan_step(float& v, bool take, int d) {
-  const float pv = __shfl_up(v, d, 64);
-  if (take) v += pv;
+// DPP row_shr:D -- lane l receives the value of lane l-D of its 16-lane row (0 when l%16 < D).  Pure VALU: unlike
+// __shfl_up (ds_bpermute) it does not go through the LDS unit, which this kernel already loads with its atomics.
+template <int D>
+__device__ __forceinline__ float row_shr(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xF, 0xF, true));
+}
+template <int D>
+__device__ __forceinline__ uint32_t row_shr_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int row_shl1(int v) {  // lane l <- lane l+1 of its row (0 at the row end)
+  return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true);
+}
+template <int D>
+__device__ __forceinline__ void seg_scan_step(float2 (&val)[8], bool& f, int l16) {
+  const bool take = l16 >= D && !f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float px = row_shr<D>(val[c].x), py = row_shr<D>(val[c].y);
+    if (take) val[c].x += px, val[c].y += py;
+  }
+  const int pf = (int)row_shr_u<D>((uint32_t)f);
+  if (l16 >= D) f = f || pf;
 }
 
 template <bool SCATTER>
@@ -265,24 +285,18 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
         kx = h.fx, ky = h.fy, kz = h.fz, kf = h.eqx | (h.eqy << 1) | (h.eqz << 2);
       }
     }
-    // all four shuffles are executed by every lane (no short-circuit: a shuffle under divergent control flow
-    // would read the registers of inactive lanes)
-    const uint32_t px_ = __shfl_up(kx, 1, 64), py_ = __shfl_up(ky, 1, 64), pz_ = __shfl_up(kz, 1, 64), pf_ = __shfl_up(kf, 1, 64);
-    const bool head = (lane == 0) | (px_ != kx) | (py_ != ky) | (pz_ != kz) | (pf_ != kf);
-    const int nhead = __shfl_down((int)head, 1, 64);
-    emit[k] = act && (lane == 63 || nhead);  // tail lane of a run of equal cells emits the run's sum
+    // runs of equal cells are merged inside each 16-lane DPP row (all cross-lane ops executed by every lane)
+    const int l16 = lane & 15;
+    const uint32_t px_ = row_shr_u<1>(kx), py_ = row_shr_u<1>(ky), pz_ = row_shr_u<1>(kz), pf_ = row_shr_u<1>(kf);
+    const bool head = (l16 == 0) | (px_ != kx) | (py_ != ky) | (pz_ != kz) | (pf_ != kf);
+    const int nhead = row_shl1((int)head);
+    emit[k] = act && (l16 == 15 || nhead);  // tail lane of a run of equal cells emits the run's sum
     if (SCATTER) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) val[k][c] = make_float2(w[c] * g0, w[c] * g1);
-      bool f = head;  // segmented inclusive scan over the wave: (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv)
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const bool take = lane >= d && !f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) seg_scan_step(val[k][c].x, take, d), seg_scan_step(val[k][c].y, take, d);
-        const int pf = __shfl_up((int)f, d, 64);
-        if (lane >= d) f = f || pf;
-      }
+      bool f = head;  // segmented inclusive scan over the row: (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv)
+      seg_scan_step<1>(val[k], f, l16), seg_scan_step<2>(val[k], f, l16);
+      seg_scan_step<4>(val[k], f, l16), seg_scan_step<8>(val[k], f, l16);
     }
     if (emit[k]) {
 #pragma unroll
