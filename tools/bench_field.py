@@ -7,7 +7,7 @@ import numpy as np, torch
 from umhsnerf import ops
 
 dev = "cuda:0"
-C, B, spec = int(os.environ.get("C", 6)), int(os.environ.get("B", 31)), True
+C, B, spec = int(os.environ.get("C", 6)), int(os.environ.get("B", 31)), os.environ.get("SPEC", "1") == "1"
 layout = ops.FieldLayout(C, B, spec, 19)
 g = torch.Generator().manual_seed(0)
 flat = ((torch.rand(layout.total, generator=g) - 0.5) * 0.5).to(dev)
@@ -22,7 +22,7 @@ def timeit(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
-for N in ([262144] if os.environ.get('ONLY') else [16384, 65536, 262144, 1048576]):
+for N in ([int(os.environ.get('N', 262144))] if os.environ.get('ONLY') else [16384, 65536, 262144, 1048576]):
     enc = (torch.rand(16, N, 2, device=dev) - 0.5)
     wpos = torch.rand(N, 3, device=dev) * 2 - 1
     dirs = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)

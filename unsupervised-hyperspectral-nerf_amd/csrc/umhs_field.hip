@@ -378,6 +378,7 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
       relu_to<1, NT>(hdir, d4);
     }
     // ---- per 16-band tile: mixing (K = classes) and specular (K = 16 hidden) -------------------------
+#pragma unroll 1  // a runtime loop: left alone hipcc unrolls the (small) no-specular body 8x and spills 200+ registers
     for (int t = 0; t < io.TB; ++t) {
       v4f sp[NT][1], sc[NT][1];
       gemm_pack<1, 4, NT, 1>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
