@@ -216,19 +216,34 @@ def main():
         }
         kern = {k: round(v[0], 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][0])}
         dom = next(iter(kern))
+        # HBM traffic / MFMA-busy of the dominant operator from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/r01/pmc_summary.json; counters cannot be read from inside the process)
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")) as f:
+                pmc = json.load(f)["kernels"]
+        except Exception:
+            pass
+        op_kernels = {"field_bwd": ("field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce_kernel", "field_pack"),
+                      "field_fwd": ("field_fwd_kernel", "field_pack_fwd"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
+                      "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"), "adam_step": ("adam_kernel",)}
+        traffic = sum(v["hbm_traffic_bytes"] for k, v in pmc.items() if any(k.startswith(p_) for p_ in op_kernels.get(dom, ()))) or None
+        busy = [v["mfma_util"] for k, v in pmc.items() if k.startswith("field_bwd_heads" if dom == "field_bwd" else "field_fwd_kernel")]
         roof = None
         if dom in alg:
             ach = alg[dom] / (ksum[dom][0] * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=None, avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1],
-                        note=("float-atomic scatter: practical ceiling %.0f GB/s of added bytes (MI355X_MICROARCH.md)" % ATOMIC_PEAK_GBS)
-                        if dom == "hashgrid_bwd" else None)
-        else:  # MFMA-bound field kernels: fp32-input MFMA peak 157.3 TFLOP/s
-            flops = {"field_fwd": 33.9e3 * N, "field_bwd": (2 * 33.9e3 + 33.9e3) * N}.get(dom)
+                        traffic=traffic, avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1])
+        else:  # fp32-input MFMA (v_mfma_f32_16x16x4_f32), dense peak 157.3 TFLOP/s; algorithmic FLOPs per sample: SURVEY 8d
+            fwd_flop = 33.9e3
+            flops = {"field_fwd": fwd_flop * N, "field_bwd": 2 * fwd_flop * N}.get(dom)  # backward = dX + dW = 2x forward
             if flops:
                 ach = flops / (ksum[dom][0] * 1e-3) / 1e12
-                roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=157.3, unit="TFLOP/s", frac=round(ach / 157.3, 4),
-                            traffic=None, avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1])
+                roof = dict(bound="mfma", kernel=dom + " (heads+base kernels, pack, slab reduce)" if dom == "field_bwd" else dom,
+                            achieved=round(ach, 2), peak=157.3, unit="TFLOP/s", frac=round(ach / 157.3, 4), traffic=traffic,
+                            avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1],
+                            mfma_busy_frac_pmc=(busy[0] if busy else None),
+                            note="frac = algorithmic FLOPs / time / peak; mfma_busy_frac_pmc = SQ_VALU_MFMA_BUSY_CYCLES share incl. recompute and tile padding")
         line = {
             "metric": "train rays/sec (hotdog-shaped 31-band, C2)", "value": round(R * world * args.steps / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
