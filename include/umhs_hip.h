@@ -65,7 +65,8 @@ int umhs_positions_fwd(const float* origins, const float* directions, const floa
 /* enc element (n,l,f) is written at enc[n*stride_n + l*stride_l + f] (f in {0,1}):             */
 /*   stride_n=2L, stride_l=2  -> the reference's [N, L*F] layout;                               */
 /*   stride_n=2,  stride_l=2N -> level-major [L][N][2] (what the fused field kernels prefer).   */
-/* hashgrid_bwd ACCUMULATES into d_table (caller zeroes it): d_table[idx] += w_corner * d_enc.  */
+/* hashgrid_bwd: overwrite == 0 ACCUMULATES (d_table[idx] += w_corner * d_enc, caller zeroes   */
+/* it); overwrite != 0 writes the whole [L*T,2] gradient (no memset / read-modify-write needed).*/
 /* With a workspace (umhs_hashgrid_bwd_workspace_bytes; 0 = not available for this shape) the   */
 /* scatter is atomics-free (radix partition into LDS-sized slot buckets); with workspace ==     */
 /* NULL it falls back to global float atomics (no workspace, ~20x slower at N = 262k).          */
@@ -75,7 +76,7 @@ int umhs_hashgrid_fwd(const float* pos01, const float* table, const float* scali
 size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_table_size);
 int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
                       const float* scalings, int64_t n, int n_levels, int log2_table_size, float* d_table,
-                      void* workspace, size_t workspace_bytes, umhs_stream_t stream);
+                      int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* R3-R9, R18: fused per-sample field.  Replaces mlp_base's MLP, NeRFEncoding, SHEncoding,      */

@@ -98,6 +98,10 @@ def test_hashgrid_fwd_bwd(level_major, log2_T, method):
     # accumulate semantics: a second call doubles the gradient
     ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, level_major, method=method)
     assert_close("d_table x2", d_table, 2 * gref, 2e-5)
+    # overwrite semantics: garbage in, gradient out
+    d_table.fill_(123.0)
+    ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, level_major, method=method, overwrite=True)
+    assert_close("d_table overwrite", d_table, gref, 2e-5)
 
 
 def test_hashgrid_bwd_partition_reproducible_and_keeps_small_gradients():

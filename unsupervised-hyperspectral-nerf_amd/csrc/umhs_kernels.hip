@@ -218,6 +218,7 @@ struct HbArgs {
   uint32_t* lmax;                       // [nlev] bits of the level's max |record value|
   uint16_t* rec_idx;                    // [8 * n * nlev]
   float2* rec_val;
+  int overwrite;                        // reduce: d_table slab = tile (zeros where untouched) instead of +=
 };
 
 // DPP row_shr:D -- lane l receives the value of lane l-D of its 16-lane row (0 when l%16 < D).  Pure VALU: unlike
@@ -360,8 +361,14 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
   extern __shared__ __attribute__((aligned(16))) long long tile[];  // [2 << bucket_bits] int64 fixed point
   const int tid = threadIdx.x, b = blockIdx.x, lev = blockIdx.y, l = a.level0 + lev;
   const uint32_t start = a.offsets[lev * a.nb + b], cnt = a.counts[lev * a.nb + b];
-  if (cnt == 0) return;  // nothing to add to this slab (uniform over the workgroup)
   const int nsl = 2 << a.bucket_bits;
+  if (cnt == 0) {  // nothing lands in this slab (uniform over the workgroup)
+    if (a.overwrite) {
+      float* dst0 = d_table + 2 * (((size_t)l << a.log2_T) + ((size_t)b << a.bucket_bits));
+      for (int j = tid * 4; j < nsl; j += 4096) *reinterpret_cast<float4*>(dst0 + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   for (int i = tid; i < nsl; i += 1024) tile[i] = 0;
   // fixed-point scale 2^k:  |v| <= vmax < 2^e, at most cnt < 2^hb addends  =>  |sum| * 2^k < 2^62
   int e;
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
   __syncthreads();
   float* dst = d_table + 2 * (((size_t)l << a.log2_T) + ((size_t)b << a.bucket_bits));
   for (int j = tid * 4; j < nsl; j += 4096) {
-    float4 d = *reinterpret_cast<float4*>(dst + j);
+    float4 d = a.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(dst + j);
     d.x += (float)ldexp((double)tile[j], -k), d.y += (float)ldexp((double)tile[j + 1], -k);
     d.z += (float)ldexp((double)tile[j + 2], -k), d.w += (float)ldexp((double)tile[j + 3], -k);
     *reinterpret_cast<float4*>(dst + j) = d;
@@ -409,8 +416,11 @@ extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int
 
 extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
                                  const float* scalings, int64_t n, int n_levels, int log2_T, float* d_table,
-                                 void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
+                                 int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
   if (n < 0 || !pos01 || !d_enc || !scalings || !d_table) return UMHS_ERR_ARG;
+  if (overwrite && (!workspace || n == 0)) {  // only the partitioned path writes every slot itself
+    if (hipMemsetAsync(d_table, 0, ((size_t)n_levels << log2_T) * 8, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
+  }
   if (n_levels < 1 || n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
   if (n == 0) return UMHS_OK;
   if (!workspace) {  // v1: memory-side float atomics (no workspace needed; fine for small N)
@@ -427,7 +437,7 @@ extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t
   HbArgs a;
   a.pos01 = pos01, a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.scalings = scalings, a.n = n;
   a.log2_T = log2_T, a.bucket_bits = hb_bucket_bits(log2_T), a.nb = 1 << (log2_T - a.bucket_bits), a.level0 = 0;
-  a.nlev = n_levels;
+  a.nlev = n_levels, a.overwrite = overwrite;
   const size_t m = (size_t)n_levels * a.nb, cap = (size_t)8 * n * n_levels;
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
   a.counts = reinterpret_cast<uint32_t*>(p), a.lmax = a.counts + m, a.offsets = a.lmax + 64, a.cursor = a.offsets + m;
@@ -536,16 +546,19 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
       for (int kc = 0; kc < K; kc += 64) {
         const int k = kc + lane;
         const bool kv = k < K;
+        // the per-ray sum runs in sample order: 64 dependent-free row loads, 8 of them in flight per lane
         float p0 = 0.0f, p1 = 0.0f;
+        const float* __restrict__ vk = v + (kv ? k : 0);
         int j = 0;
-        for (; j + 1 < nvalid; j += 2) {
-          float w0 = __shfl(w, j, 64), w1 = __shfl(w, j + 1, 64);
-          float v0 = kv ? v[(int64_t)j * K + k] : 0.0f;
-          float v1 = kv ? v[(int64_t)(j + 1) * K + k] : 0.0f;
-          p0 += w0 * v0;
-          p1 += w1 * v1;
+        for (; j + 7 < nvalid; j += 8) {
+          float x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = vk[(int64_t)(j + u) * K];
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) p0 += __shfl(w, j + u, 64) * x[u], p1 += __shfl(w, j + u + 1, 64) * x[u + 1];
         }
-        if (j < nvalid) p0 += __shfl(w, j, 64) * (kv ? v[(int64_t)j * K + k] : 0.0f);
+        for (; j < nvalid; ++j) p0 += __shfl(w, j, 64) * vk[(int64_t)j * K];
+        if (!kv) p0 = p1 = 0.0f;
         if (kv) {
           float* o = st.out[s] + r * K + k;
           *o = (base == 0) ? (p0 + p1) : (*o + (p0 + p1));

@@ -143,8 +143,10 @@ def hashgrid_fwd(pos01, table, scalings, log2_T: int, level_major: bool = True):
     return enc
 
 
-def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, method: str = "auto"):
-    """d_table += scatter(d_enc).  method: "partition" (atomics-free, needs a workspace), "atomic", or "auto"."""
+def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, method: str = "auto",
+                 overwrite: bool = False):
+    """d_table (+)= scatter(d_enc).  method: "partition" (atomics-free, needs a workspace), "atomic", or "auto".
+    overwrite=True: every slot of d_table is written (no need to zero it first)."""
     n = pos01.shape[0]
     sn, sl = enc_strides(n, level_major)
     nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, NUM_LEVELS, log2_T) if method != "atomic" else 0
@@ -152,7 +154,8 @@ def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool
         raise RuntimeError("partitioned hash-grid backward unavailable for this shape")
     ws = _workspace(nbytes, pos01.device, slot=1) if nbytes else None
     _hip.check(_hip.lib().umhs_hashgrid_bwd(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, NUM_LEVELS, log2_T,
-                                            ptr(d_table), ptr(ws), ws.numel() if ws is not None else 0, _hip.stream()),
+                                            ptr(d_table), int(overwrite), ptr(ws), ws.numel() if ws is not None else 0,
+                                            _hip.stream()),
                "umhs_hashgrid_bwd")
 
 
@@ -313,9 +316,11 @@ class FieldFn(torch.autograd.Function):
         d_sigma = _hip.f32c(d_sigma).view(-1) if d_sigma is not None else zeros(n)
         d_spectral = _hip.f32c(d_spectral) if d_spectral is not None else zeros(n, L.wavelengths)
         d_emb = _hip.f32c(d_emb) if d_emb is not None else None
-        d_flat = torch.zeros_like(flat)
+        d_flat = torch.empty_like(flat)  # the 64 MiB table segment is fully written by hashgrid_bwd(overwrite=True)
+        d_flat[L.offset("mlp_base.mlp.layers.0.weight"):].zero_()  # MLP / endmember segments (+ alignment padding)
         d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat)
-        hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, L.view(d_flat, "mlp_base.encoder.hash_table"), True)
+        hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, L.view(d_flat, "mlp_base.encoder.hash_table"), True,
+                     overwrite=True)
         return d_flat, None, None, None, None, None
 
 
