@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 // same cell are merged by a wave segmented scan before a record is emitted (2-30x fewer records there).
 // ---------------------------------------------------------------------------------------------
 #define HB_BUCKET_BITS 13
-#define HB_SPT 4  // samples per thread -> 1024 samples per workgroup
+#define HB_SPT 2  // samples per thread -> 512 samples per workgroup (<= 4096 records staged in 44 KiB of LDS)
 
 struct HbArgs {
   const float* pos01;
@@ -250,7 +250,14 @@ template <bool SCATTER>
 __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
   __shared__ uint32_t hist[64];
   __shared__ uint32_t base[64];
+  __shared__ uint32_t lbase[65];
   __shared__ uint32_t wgmax;
+  // scatter pass: records are first ordered by bucket in LDS, then written out with consecutive lanes on consecutive
+  // records (PMC: writing each record straight to its slot cost 288 MB of HBM writes for 146 MB of records)
+  constexpr int MAXREC = SCATTER ? 256 * HB_SPT * 8 : 1;
+  __shared__ float2 recV[MAXREC];
+  __shared__ uint16_t recI[MAXREC];
+  __shared__ uint8_t recB[MAXREC];
   const int tid = threadIdx.x, lane = tid & 63, lev = blockIdx.y, l = a.level0 + lev;
   if (tid < 64) hist[tid] = 0;
   if (tid == 0) wgmax = 0;
@@ -317,10 +324,20 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
     if (tid < a.nb && hist[tid]) atomicAdd(&a.counts[lev * a.nb + tid], hist[tid]);
     return;
   }
-  if (tid < a.nb) {
-    const uint32_t c = hist[tid];
-    base[tid] = c ? atomicAdd(&a.cursor[lev * a.nb + tid], c) : 0u;
-    hist[tid] = 0;
+  if (tid < 64) {  // wave 0: local exclusive prefix of the bucket counts + one global reservation per bucket
+    const uint32_t c = tid < a.nb ? hist[tid] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    lbase[tid] = incl - c;
+    if (tid == 63) lbase[64] = incl;
+    if (tid < a.nb) {
+      base[tid] = c ? atomicAdd(&a.cursor[lev * a.nb + tid], c) : 0u;
+      hist[tid] = 0;
+    }
   }
   if (tid == 0 && wgmax) atomicMax(&a.lmax[lev], wgmax);
   __syncthreads();
@@ -331,11 +348,20 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint32_t b = slot[k][c] >> a.bucket_bits;
-        const uint32_t pos = base[b] + atomicAdd(&hist[b], 1u);
-        a.rec_idx[pos] = (uint16_t)(slot[k][c] & lowmask);
-        a.rec_val[pos] = val[k][c];
+        const uint32_t pos = lbase[b] + atomicAdd(&hist[b], 1u);
+        recI[pos] = (uint16_t)(slot[k][c] & lowmask);
+        recV[pos] = val[k][c];
+        recB[pos] = (uint8_t)b;
       }
     }
+  }
+  __syncthreads();
+  const uint32_t total = lbase[64];
+  for (uint32_t i = tid; i < total; i += 256) {
+    const uint32_t b = recB[i];
+    const uint32_t g = base[b] + (i - lbase[b]);
+    a.rec_idx[g] = recI[i];
+    a.rec_val[g] = recV[i];
   }
 }
 
