@@ -217,6 +217,28 @@ int umhs_loss_bwd(const float* spectral, const float* gt_spectral, const float* 
                   const float* grad_losses2, float* d_spectral, float* d_rgb, float* d_accumulation, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* occupancy-grid ray marcher.  Replaces nerfacc.OccGridEstimator.sampling (traverse_grids +        */
+/* render_visibility_from_density, CUDA only) behind nerfstudio's VolumetricSampler, umhs_model.py:201-209,229-237. */
+/* binaries: uint8 [levels][res][res][res] (x-major); level l covers the roi enlarged 2^l about its centre;          */
+/* roi_aabb_host6 = 6 HOST floats (min xyz, max xyz).  Samples have size dt = max(t*cone_angle, step_size) and are   */
+/* emitted while their mid-point lies in an occupied voxel; a run restarts at the voxel entry after empty space.     */
+/* nears / fars: optional per-ray planes [R] (stratified jitter, collider).                                          */
+/* Two passes: umhs_march_count -> counts [R] (caller scans them into packed_info), umhs_march_write -> packed        */
+/* t_starts / t_ends [N] fp32 and ray_indices [N] int64.  umhs_visibility: mask[n] = T_n >= early_stop_eps &&         */
+/* (alpha_thre <= 0 || alpha_n >= alpha_thre) with sigma from the density-only field forward.                        */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_march_count(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
+                     const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
+                     float step_size, float cone_angle, const float* nears, const float* fars, int64_t* counts,
+                     umhs_stream_t stream);
+int umhs_march_write(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
+                     const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
+                     float step_size, float cone_angle, const float* nears, const float* fars, const int64_t* packed_info,
+                     float* t_starts, float* t_ends, int64_t* ray_indices, umhs_stream_t stream);
+int umhs_visibility(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                    int64_t n_rays, int64_t n, float early_stop_eps, float alpha_thre, uint8_t* mask, umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Optimizer: torch.optim.Adam step for param group "fields" (AdamOptimizerConfig(lr=2e-2,      */
 /* eps=1e-15), umhs_config.py:59-64) over one flat fp32 buffer, with the clamp_endmembers        */
 /* callback (umhs_model.py:568-572) fused for elements [clamp_begin, clamp_end).  grad_scale     */

@@ -112,3 +112,35 @@ def test_float64_oracle_close_to_float32():
     o32 = T.model_outputs(p32, b["origins"], b["directions"], b["starts"], b["ends"], b["ray_indices"], 8, 0.4, M)
     o64 = T.model_outputs(p64, *(b[k].double() for k in ("origins", "directions", "starts", "ends")), b["ray_indices"], 8, 0.4, M)
     np.testing.assert_allclose(o32["spectral"].detach().numpy(), o64["spectral"].detach().numpy(), rtol=2e-4, atol=1e-6)
+
+
+def test_oracle_marcher_analytic_cases():
+    """No reference fixture exists for nerfacc's marcher (CUDA-only, not installable): pin the restatement on closed-form cases."""
+    full = np.ones((1, 4, 4, 4), dtype=bool)
+    roi = [-1, -1, -1, 1, 1, 1]
+    # axis ray through a fully occupied single-level grid: samples tile [t_in, t_out) with constant dt
+    ts, te = T.march_ray_ref([-3.0, 0.1, 0.2], [1.0, 0.0, 0.0], full, roi, 0.05, 1e3, 0.125, 0.0)
+    ts, te = np.array(ts), np.array(te)
+    assert len(ts) == 16 and abs(ts[0] - 2.0) < 1e-6 and abs(te[-1] - 4.0) < 1e-5
+    np.testing.assert_allclose(te[:-1], ts[1:], atol=1e-6)  # contiguous while the voxels stay occupied
+    # cone angle: dt = max(t*cone, step)
+    ts, te = T.march_ray_ref([-3.0, 0.1, 0.2], [1.0, 0.0, 0.0], full, roi, 0.05, 1e3, 0.01, 0.05)
+    np.testing.assert_allclose(np.array(te) - np.array(ts), np.maximum(np.array(ts) * 0.05, 0.01), rtol=1e-5)
+    # empty grid, ray that misses, far plane before the box
+    assert T.march_ray_ref([-3, 0, 0], [1, 0, 0], np.zeros((2, 4, 4, 4), bool), roi, 0.05, 1e3, 0.1, 0.0) == ([], [])
+    assert T.march_ray_ref([-3, 5, 0], [1, 0, 0], full, roi, 0.05, 1e3, 0.1, 0.0) == ([], [])
+    assert T.march_ray_ref([-3, 0, 0], [1, 0, 0], full, roi, 0.05, 1.5, 0.1, 0.0) == ([], [])
+    # a gap of empty voxels restarts the run at the next occupied voxel's entry
+    gap = full.copy()
+    gap[0, 1:3] = False
+    ts, te = T.march_ray_ref([-3.0, 0.1, 0.2], [1.0, 0.0, 0.0], gap, roi, 0.05, 1e3, 0.2, 0.0)
+    ts = np.array(ts)
+    assert (ts < 2.5).sum() >= 2 and abs(ts[ts >= 2.5][0] - 3.5) < 1e-5
+    # two levels: the coarse level takes over outside the roi (voxels twice as large)
+    two = np.zeros((2, 4, 4, 4), bool)
+    two[1] = True
+    ts, te = T.march_ray_ref([-3.0, 0.1, 0.2], [1.0, 0.0, 0.0], two, roi, 0.05, 1e3, 0.25, 0.0)
+    ts = np.array(ts)
+    assert ts.min() >= 1.0 - 1e-6 and not ((ts > 2.05) & (ts < 3.8)).any() and (ts > 3.9).any()  # [-2,-1] and [1,2] only
+    aabbs = T.occ_grid_aabbs(roi, 3)
+    np.testing.assert_array_equal(aabbs[2], [-4, -4, -4, 4, 4, 4])

@@ -1,0 +1,177 @@
+// occupancy-grid ray marcher and visibility pruning for gfx950.
+// Replaces nerfacc==0.5.2 OccGridEstimator.sampling (CUDA-only traverse_grids + render_visibility_from_density) reached
+// through nerfstudio's VolumetricSampler at umhs_model.py:201-209,229-237.  nerfacc's source is not available offline: the
+// traversal below restates its published behaviour (see oracle/torch_ref.py march_ray_ref, which this kernel reproduces
+// bit for bit: float32, fixed operation order, fp contraction off).  One thread per ray; two passes (count, then write at
+// the offsets of an exclusive scan) because the number of samples per ray is data dependent.
+#include "umhs_common.h"
+
+struct MarchArgs {
+  const float* o;
+  const float* d;
+  int64_t n_rays;
+  const uint8_t* bin;  // [levels][res][res][res], x-major like nerfacc's binaries
+  float cx, cy, cz, hx, hy, hz;  // roi centre and half extent (level 0)
+  int levels, res;
+  float near, far, step, cone;
+  const float *nears, *fars;   // optional per-ray planes [R] (override near / far)
+  const int64_t* packed_info;  // write pass: [R,2] (start, count)
+  int64_t* counts;             // count pass
+  float *t_starts, *t_ends;
+  int64_t* ray_indices;
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
+#pragma clang fp contract(off)
+  const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= a.n_rays) return;
+  const float BIG = 1e30f;
+  const float o[3] = {a.o[3 * r], a.o[3 * r + 1], a.o[3 * r + 2]};
+  const float d[3] = {a.d[3 * r], a.d[3 * r + 1], a.d[3 * r + 2]};
+  const float c[3] = {a.cx, a.cy, a.cz}, h[3] = {a.hx, a.hy, a.hz};
+  float inv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) inv[k] = d[k] != 0.0f ? 1.0f / d[k] : (signbit(d[k]) ? -BIG : BIG);
+  const float top = (float)(1 << (a.levels - 1));
+  float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float ho = h[k] * top;
+    const float t0 = (c[k] - ho - o[k]) * inv[k], t1 = (c[k] + ho - o[k]) * inv[k];
+    tn = fmaxf(tn, fminf(t0, t1)), tf = fminf(tf, fmaxf(t0, t1));
+  }
+  float t = fmaxf(tn, a.nears ? a.nears[r] : a.near);
+  const float t_end = fminf(tf, a.fars ? a.fars[r] : a.far);
+  int64_t cnt = 0;
+  int64_t w = WRITE ? a.packed_info[2 * r] : 0;
+  if (t < t_end) {
+    bool continuous = false;
+    float t_last = t;
+    for (int guard = 0; t < t_end && guard < 100000; ++guard) {
+      const float tm = t + 1e-5f * fmaxf(1.0f, fabsf(t));
+      float p[3], m = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        p[k] = o[k] + d[k] * tm;
+        m = fmaxf(m, fabsf(p[k] - c[k]) / h[k]);
+      }
+      if (!(m < top)) break;
+      int lvl = 0;
+      if (!(m < 1.0f)) (void)frexpf(m, &lvl);  // m in [2^(e-1), 2^e) -> level e
+      lvl = min(max(lvl, 0), a.levels - 1);
+      const float sc = (float)(1 << lvl);
+      int idx[3];
+      float t_exit = BIG;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float hl = h[k] * sc, vmin = c[k] - hl, vs = (hl * 2.0f) / (float)a.res;
+        int i = (int)floorf((p[k] - vmin) / vs);
+        i = min(max(i, 0), a.res - 1);
+        idx[k] = i;
+        const float lo = vmin + (float)i * vs, hi = vmin + (float)(i + 1) * vs;
+        const float tx = ((d[k] >= 0.0f ? hi : lo) - o[k]) * inv[k];
+        if (d[k] != 0.0f) t_exit = fminf(t_exit, tx);
+      }
+      if (!(t_exit > t)) t_exit = nextafterf(t, BIG);
+      const float t_clip = fminf(t_exit, t_end);
+      const size_t cell = (((size_t)lvl * a.res + idx[0]) * a.res + idx[1]) * a.res + idx[2];
+      if (a.bin[cell]) {
+        if (!continuous) t_last = t;
+        while (true) {
+          const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
+          if (!(t_last + dt * 0.5f < t_clip)) break;
+          if (WRITE) {
+            a.t_starts[w] = t_last, a.t_ends[w] = t_last + dt, a.ray_indices[w] = r;
+            ++w;
+          }
+          ++cnt;
+          t_last = t_last + dt;
+        }
+        continuous = true;
+      } else {
+        continuous = false;
+      }
+      t = t_clip;
+    }
+  }
+  if (!WRITE) a.counts[r] = cnt;
+}
+
+static int fill_march(MarchArgs* a, const float* o, const float* d, int64_t n_rays, const uint8_t* bin, const float* roi6, int levels,
+                      int res, float near_plane, float far_plane, float step, float cone, const float* nears, const float* fars) {
+  if (n_rays < 0 || !roi6 || (n_rays > 0 && (!o || !d || !bin))) return UMHS_ERR_ARG;
+  if (levels < 1 || levels > 8 || res < 1 || res > 512 || !(step > 0.0f)) return UMHS_ERR_UNSUPPORTED;
+  a->o = o, a->d = d, a->n_rays = n_rays, a->bin = bin, a->levels = levels, a->res = res;
+  a->cx = (roi6[0] + roi6[3]) / 2.0f, a->cy = (roi6[1] + roi6[4]) / 2.0f, a->cz = (roi6[2] + roi6[5]) / 2.0f;
+  a->hx = (roi6[3] - roi6[0]) / 2.0f, a->hy = (roi6[4] - roi6[1]) / 2.0f, a->hz = (roi6[5] - roi6[2]) / 2.0f;
+  a->near = near_plane, a->far = far_plane, a->step = step, a->cone = cone, a->nears = nears, a->fars = fars;
+  a->packed_info = nullptr, a->counts = nullptr, a->t_starts = a->t_ends = nullptr, a->ray_indices = nullptr;
+  return UMHS_OK;
+}
+
+extern "C" int umhs_march_count(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
+                                const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
+                                float step_size, float cone_angle, const float* nears, const float* fars, int64_t* counts,
+                                umhs_stream_t stream) {
+  MarchArgs a;
+  int rc = fill_march(&a, origins, directions, n_rays, binaries, roi_aabb_host6, levels, resolution, near_plane, far_plane,
+                      step_size, cone_angle, nears, fars);
+  if (rc) return rc;
+  if (!counts && n_rays > 0) return UMHS_ERR_ARG;
+  if (n_rays == 0) return UMHS_OK;
+  a.counts = counts;
+  hipLaunchKernelGGL(march_kernel<false>, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, umhs_s(stream), a);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+extern "C" int umhs_march_write(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
+                                const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
+                                float step_size, float cone_angle, const float* nears, const float* fars,
+                                const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,
+                                umhs_stream_t stream) {
+  MarchArgs a;
+  int rc = fill_march(&a, origins, directions, n_rays, binaries, roi_aabb_host6, levels, resolution, near_plane, far_plane,
+                      step_size, cone_angle, nears, fars);
+  if (rc) return rc;
+  if (n_rays == 0) return UMHS_OK;
+  if (!packed_info || !t_starts || !t_ends || !ray_indices) return UMHS_ERR_ARG;
+  a.packed_info = packed_info, a.t_starts = t_starts, a.t_ends = t_ends, a.ray_indices = ray_indices;
+  hipLaunchKernelGGL(march_kernel<true>, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, umhs_s(stream), a);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// visibility mask of nerfacc.render_visibility_from_density: keep sample n iff T_n = exp(-sum_{m<n} sigma dt) >= early_stop_eps
+// and alpha_n = 1 - exp(-sigma dt) >= alpha_thre.  One wave per ray, 64-lane scan with carry (as the compositing kernels).
+__global__ __launch_bounds__(256) void visibility_kernel(const float* __restrict__ sigma, const float* __restrict__ t0,
+                                                         const float* __restrict__ t1, const int64_t* __restrict__ pinfo,
+                                                         int64_t n_rays, float eps, float thre, uint8_t* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (r >= n_rays) return;
+  const int64_t start = pinfo[2 * r];
+  const int cnt = (int)pinfo[2 * r + 1];
+  float carry = 0.0f;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < cnt;
+    const float x = valid ? sigma[start + i] * (t1[start + i] - t0[start + i]) : 0.0f;
+    const float incl = wave_inclusive_scan(x, lane);
+    const float T = expf(-(carry + (incl - x))), alpha = 1.0f - expf(-x);
+    if (valid) mask[start + i] = (T >= eps && (thre <= 0.0f || alpha >= thre)) ? 1 : 0;
+    carry += __shfl(incl, 63, 64);
+  }
+}
+
+extern "C" int umhs_visibility(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                               int64_t n_rays, int64_t n, float early_stop_eps, float alpha_thre, uint8_t* mask,
+                               umhs_stream_t stream) {
+  if (n_rays < 0 || n < 0 || !packed_info || (n > 0 && (!sigma || !t_starts || !t_ends || !mask))) return UMHS_ERR_ARG;
+  if (n_rays == 0 || n == 0) return UMHS_OK;
+  hipLaunchKernelGGL(visibility_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), sigma, t_starts, t_ends,
+                     packed_info, n_rays, early_stop_eps, alpha_thre, mask);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}

@@ -73,6 +73,9 @@ SIGNATURES = {
     "umhs_ray_epilogue_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "umhs_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp]),
     "umhs_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "umhs_march_count": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "umhs_march_write": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "umhs_visibility": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "umhs_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _i64, _i64, _vp]),
 }
 

@@ -1,0 +1,165 @@
+"""Occupancy-grid volumetric sampler for ROCm.
+
+Mirror of what the reference gets from nerfacc==0.5.2 ``OccGridEstimator`` + nerfstudio's ``VolumetricSampler``
+(``umhs_model.py:201-209`` construction, ``:229-237`` sampling, ``:549-554`` grid update): same constructor arguments,
+buffers (``aabbs``, ``occs``, ``binaries``) and method names.  nerfacc ships CUDA kernels only; the ray marching and the
+visibility pruning run in libumhs_hip.so (``umhs_march_count/write``, ``umhs_visibility``), the density queries in the
+density-only field kernel.  The grid bookkeeping of ``update_every_n_steps`` is index arithmetic in torch (runs every 16
+steps).  nerfacc's source is not available offline: behaviour is restated from its published algorithm (parity unpinned).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _hip
+from ._hip import ptr
+from ._ns_compat import RayBundle, RaySamples, packed_ray_samples
+
+
+def march_rays(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aabb, levels: int, resolution: int, near: float,
+               far: float, step: float, cone: float, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None):
+    """-> (ray_indices int64 [N], t_starts [N], t_ends [N], packed_info [R,2]) on the device."""
+    o, d = _hip.f32c(origins), _hip.f32c(directions)
+    R, dev = o.shape[0], o.device
+    roi = (C.c_float * 6)(*[float(v) for v in roi_aabb])
+    counts = torch.empty((R,), device=dev, dtype=torch.int64)
+    nears = _hip.f32c(nears) if nears is not None else None
+    fars = _hip.f32c(fars) if fars is not None else None
+    _hip.check(_hip.lib().umhs_march_count(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
+                                           ptr(nears), ptr(fars), ptr(counts), _hip.stream()), "umhs_march_count")
+    ends_excl = torch.cumsum(counts, 0)
+    packed_info = torch.stack([ends_excl - counts, counts], dim=-1).contiguous()
+    n = int(ends_excl[-1].item()) if R > 0 else 0  # the sample count sizes the outputs: one host sync per batch, as in nerfacc
+    t0 = torch.empty((n,), device=dev, dtype=torch.float32)
+    t1 = torch.empty((n,), device=dev, dtype=torch.float32)
+    ri = torch.empty((n,), device=dev, dtype=torch.int64)
+    if n > 0:
+        _hip.check(_hip.lib().umhs_march_write(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
+                                               ptr(nears), ptr(fars), ptr(packed_info), ptr(t0), ptr(t1), ptr(ri), _hip.stream()),
+                   "umhs_march_write")
+    return ri, t0, t1, packed_info
+
+
+def visibility_mask(sigma: Tensor, t_starts: Tensor, t_ends: Tensor, packed_info: Tensor, early_stop_eps: float, alpha_thre: float):
+    s = _hip.f32c(sigma).view(-1)
+    mask = torch.empty(s.shape, device=s.device, dtype=torch.uint8)
+    _hip.check(_hip.lib().umhs_visibility(ptr(s), ptr(t_starts), ptr(t_ends), ptr(packed_info), packed_info.shape[0], s.shape[0],
+                                          float(early_stop_eps), float(alpha_thre), ptr(mask), _hip.stream()), "umhs_visibility")
+    return mask.bool()
+
+
+class OccGridEstimator(nn.Module):
+    """Multi-level occupancy grid: level l covers ``roi_aabb`` enlarged 2^l about its centre (nerfacc ``OccGridEstimator``)."""
+
+    def __init__(self, roi_aabb, resolution: int = 128, levels: int = 1):
+        super().__init__()
+        roi = torch.as_tensor(roi_aabb, dtype=torch.float32).flatten()
+        assert roi.numel() == 6
+        self.levels, self.res = int(levels), int(resolution)
+        self.cells_per_lvl = self.res**3
+        c, h = (roi[:3] + roi[3:]) / 2, (roi[3:] - roi[:3]) / 2
+        self.register_buffer("aabbs", torch.stack([torch.cat([c - h * 2**l, c + h * 2**l]) for l in range(levels)]))
+        self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros((self.levels, self.res, self.res, self.res), dtype=torch.bool))
+        g = torch.arange(self.res)
+        self.register_buffer("grid_coords", torch.stack(torch.meshgrid(g, g, g, indexing="ij"), dim=-1).reshape(-1, 3))
+        self._roi = [float(v) for v in roi.tolist()]
+
+    # ---- sampling ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None, near_plane: float = 0.0,
+                 far_plane: float = 1e10, t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None,
+                 render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
+                 cone_angle: float = 0.0) -> Tuple[Tensor, Tensor, Tensor]:
+        nears = t_min if t_min is not None else torch.full_like(rays_o[..., 0], near_plane)
+        fars = t_max if t_max is not None else torch.full_like(rays_o[..., 0], far_plane)
+        if stratified:
+            nears = nears + torch.rand_like(nears) * render_step_size
+        bin_u8 = self.binaries.view(torch.uint8)
+        ri, t0, t1, pinfo = march_rays(rays_o, rays_d, bin_u8, self._roi, self.levels, self.res, near_plane, far_plane,
+                                       render_step_size, cone_angle, nears, fars)
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None and t0.numel() > 0:
+            alpha_thre = min(alpha_thre, float(self.occs.mean()))  # nerfacc: a host read per batch
+            sigmas = sigma_fn(t0, t1, ri)
+            keep = visibility_mask(sigmas, t0, t1, pinfo, early_stop_eps, alpha_thre)
+            ri, t0, t1 = ri[keep], t0[keep], t1[keep]
+        return ri, t0, t1
+
+    # ---- grid update (nerfacc OccGridEstimator._update) -----------------------------------------------------------
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
+                             warmup_steps: int = 256, n: int = 16) -> None:
+        if not self.training:
+            raise RuntimeError("update_every_n_steps() is a training-time call")
+        if step % n == 0:
+            self._update(step, occ_eval_fn, occ_thre, ema_decay, warmup_steps)
+
+    def _sample_cells(self, step: int, warmup_steps: int):
+        dev = self.occs.device
+        if step < warmup_steps:
+            every = torch.arange(self.cells_per_lvl, device=dev)
+            return [every] * self.levels
+        n = self.cells_per_lvl // 4
+        out = []
+        for lvl in range(self.levels):
+            uniform = torch.randint(self.cells_per_lvl, (n,), device=dev)
+            occupied = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
+            if n < occupied.numel():
+                occupied = occupied[torch.randint(occupied.numel(), (n,), device=dev)]
+            out.append(torch.cat([uniform, occupied]))
+        return out
+
+    @torch.no_grad()
+    def _update(self, step, occ_eval_fn, occ_thre, ema_decay, warmup_steps):
+        for lvl, idx in enumerate(self._sample_cells(step, warmup_steps)):
+            coords = self.grid_coords[idx].to(torch.float32)
+            x = (coords + torch.rand_like(coords)) / self.res
+            x = self.aabbs[lvl, :3] + x * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
+            occ = occ_eval_fn(x).squeeze(-1)
+            cell = lvl * self.cells_per_lvl + idx
+            self.occs[cell] = torch.maximum(self.occs[cell] * ema_decay, occ)
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).view(self.binaries.shape)
+
+    def mark_all_occupied(self) -> None:
+        self.occs.fill_(1.0)
+        self.binaries = torch.ones_like(self.binaries)
+
+
+class VolumetricSampler(nn.Module):
+    """nerfstudio ``VolumetricSampler``: marches rays through the occupancy grid and returns packed RaySamples."""
+
+    def __init__(self, occupancy_grid: OccGridEstimator, density_fn: Optional[Callable] = None):
+        super().__init__()
+        self.occupancy_grid, self.density_fn = occupancy_grid, density_fn
+
+    def get_sigma_fn(self, origins: Tensor, directions: Tensor) -> Optional[Callable]:
+        if self.density_fn is None or not self.training:
+            return None
+        density_fn = self.density_fn
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            pos = origins[ray_indices] + directions[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
+            return density_fn(pos).squeeze(-1)
+
+        return sigma_fn
+
+    def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane: Optional[float] = None,
+                alpha_thre: float = 0.01, cone_angle: float = 0.0) -> Tuple[RaySamples, Tensor]:
+        rays_o, rays_d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        t_min = ray_bundle.nears.contiguous().reshape(-1) if ray_bundle.nears is not None and ray_bundle.fars is not None else None
+        t_max = ray_bundle.fars.contiguous().reshape(-1) if t_min is not None else None
+        far_plane = 1e10 if far_plane is None else far_plane
+        ri, t0, t1 = self.occupancy_grid.sampling(rays_o, rays_d, sigma_fn=self.get_sigma_fn(rays_o, rays_d), near_plane=near_plane,
+                                                  far_plane=far_plane, t_min=t_min, t_max=t_max, render_step_size=render_step_size,
+                                                  stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre)
+        if t0.shape[0] == 0:  # nerfstudio: one fake sample so that downstream shapes stay valid
+            ri = torch.zeros((1,), dtype=torch.long, device=rays_o.device)
+            t0 = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+            t1 = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+        cam = ray_bundle.camera_indices[ri] if ray_bundle.camera_indices is not None else None
+        return packed_ray_samples(rays_o[ri], rays_d[ri], t0, t1, cam), ri

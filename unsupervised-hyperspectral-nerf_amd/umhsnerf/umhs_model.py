@@ -20,6 +20,7 @@ from torch import Tensor, nn
 from . import ops
 from ._ns_compat import FieldHeadNames, RayBundle, RaySamples, packed_ray_samples
 from .optim import UMHSAdam
+from .sampler import OccGridEstimator, VolumetricSampler
 from .umhs_field import UMHSField
 from .umhs_renderer import SpectralRenderer
 from .utils.clusterprobe import ClusterLookup
@@ -60,6 +61,7 @@ class UMHSConfig:
     pred_specular: bool = False
     load_vca: bool = False
     eval_num_rays_per_chunk: int = 512
+    sampler: Literal["occupancy", "uniform"] = "occupancy"  # "occupancy" = the reference's nerfacc grid marcher (HIP port)
     samples_per_ray: int = 64  # PackedUniformSampler only
     per_band_outputs: bool = True  # wv_i / residual_i / abundances_i views (umhs_model.py:273-304)
 
@@ -127,7 +129,12 @@ class UMHSModel(nn.Module):
         self.scene_aabb = nn.Parameter(self.scene_aabb_t.flatten(), requires_grad=False)
         if c.render_step_size is None:
             c.render_step_size = float(((self.scene_aabb_t[1] - self.scene_aabb_t[0]) ** 2).sum().sqrt() / 1000)
-        self.sampler = PackedUniformSampler(c.samples_per_ray)
+        # umhs_model.py:201-209: nerfacc.OccGridEstimator(roi_aabb, resolution, levels) + VolumetricSampler(grid, density_fn)
+        self.occupancy_grid = OccGridEstimator(self.scene_aabb_t.flatten(), resolution=int(c.grid_resolution), levels=c.grid_levels)
+        if c.sampler == "occupancy":
+            self.sampler = VolumetricSampler(self.occupancy_grid, density_fn=self.field.density_fn)
+        else:
+            self.sampler = PackedUniformSampler(c.samples_per_ray)
         self.cluster_probe = ClusterLookup(len(wl), self.kwargs["num_classes"])
         self.background_color = c.background_color
 
@@ -153,14 +160,24 @@ class UMHSModel(nn.Module):
         with torch.no_grad():
             self.field.endmembers[:] = self.field.endmembers.clamp(0, 1)
 
+    def update_occupancy_grid(self, step: int) -> None:
+        """BEFORE_TRAIN_ITERATION callback of the reference (umhs_model.py:549-554)."""
+        self.step = step
+        self.occupancy_grid.update_every_n_steps(step=step, occ_eval_fn=lambda x: self.field.density_fn(x) * self.config.render_step_size)
+
     def get_training_callbacks(self, training_callback_attributes=None) -> List:
-        return [("after_train_iteration", self.clamp_endmembers)]
+        return [("before_train_iteration", self.update_occupancy_grid), ("after_train_iteration", self.clamp_endmembers)]
 
     # ---- forward -----------------------------------------------------------------------------------
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         c = self.config
         with torch.no_grad():
-            ray_samples, ray_indices = self.sampler(ray_bundle, c.near_plane, c.far_plane, c.render_step_size, c.alpha_thre, c.cone_angle)
+            if isinstance(self.sampler, VolumetricSampler):
+                ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
+                                                        render_step_size=c.render_step_size, alpha_thre=c.alpha_thre,
+                                                        cone_angle=c.cone_angle)
+            else:
+                ray_samples, ray_indices = self.sampler(ray_bundle, c.near_plane, c.far_plane, c.render_step_size, c.alpha_thre, c.cone_angle)
         return self.get_outputs_from_samples(ray_samples, ray_indices, len(ray_bundle))
 
     def forward(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
