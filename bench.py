@@ -147,10 +147,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # (rehearsals with more ranks than GPUs share a device; the driver runs one rank per GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # RCCL
+        backend = os.environ.get("UMHS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for 1-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from umhsnerf import ops
