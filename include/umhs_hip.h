@@ -74,9 +74,11 @@ int umhs_positions_fwd(const float* origins, const float* directions, const floa
 int umhs_hashgrid_fwd(const float* pos01, const float* table, const float* scalings, int64_t n, int n_levels,
                       int log2_table_size, float* enc, int64_t stride_n, int64_t stride_l, umhs_stream_t stream);
 size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_table_size);
+/* Levels [level_begin, level_begin + n_levels) are processed (d_enc / d_table / scalings are indexed with the     */
+/* absolute level): callers may run the backward per level group, e.g. to all-reduce finished slabs early.          */
 int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
-                      const float* scalings, int64_t n, int n_levels, int log2_table_size, float* d_table,
-                      int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
+                      const float* scalings, int64_t n, int level_begin, int n_levels, int log2_table_size,
+                      float* d_table, int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* R3-R9, R18: fused per-sample field.  Replaces mlp_base's MLP, NeRFEncoding, SHEncoding,      */

@@ -1,0 +1,39 @@
+"""N>1 flow on the GPU box: 2 ranks sharing the one GPU, gloo as the transport (RCCL needs one device per rank).
+Checks the early per-segment gradient reduction (parallel.FlatGradSink) against the plain post-backward all-reduce."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_async_segment_reduce_is_bit_identical_to_plain_allreduce():
+    from umhsnerf import ops
+
+    # group-wise hash-grid backward == one call over all levels (single process)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    n = 5000
+    pos = torch.rand(n, 3, generator=g).to(dev)
+    d_enc = torch.randn(n, 32, generator=g).to(dev)
+    sc = ops.hash_scalings(ops.NUM_LEVELS, 16, 2048).to(dev)
+    full = torch.empty(ops.NUM_LEVELS << 19, 2, device=dev)
+    ops.hashgrid_bwd(pos, d_enc, sc, 19, full, True, overwrite=True)
+    parts = torch.full_like(full, float("nan"))
+    for l0 in range(0, 16, 4):
+        ops.hashgrid_bwd(pos, d_enc, sc, 19, parts, True, overwrite=True, level_begin=l0, level_count=4)
+    assert torch.equal(full, parts)
+    parts.fill_(1.0)  # accumulate mode on a sub-range leaves the other levels alone
+    ops.hashgrid_bwd(pos, d_enc, sc, 19, parts, True, overwrite=False, level_begin=12, level_count=4)
+    assert torch.equal(parts[: 12 << 19], torch.ones_like(parts[: 12 << 19]))
+    torch.testing.assert_close(parts[12 << 19:], full[12 << 19:] + 1.0, rtol=1e-6, atol=1e-7)
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(HERE, "dist_async_reduce_check.py")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "ASYNC_REDUCE_CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

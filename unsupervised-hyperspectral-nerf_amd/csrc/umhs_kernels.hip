@@ -165,10 +165,10 @@ extern "C" int umhs_hashgrid_fwd(const float* pos01, const float* table, const f
 __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restrict__ pos01,
                                                            const float* __restrict__ d_enc, int64_t stride_n,
                                                            int64_t stride_l, const float* __restrict__ scalings,
-                                                           int64_t n, int log2_T, float* __restrict__ d_table) {
+                                                           int64_t n, int log2_T, float* __restrict__ d_table, int level0) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  int l = blockIdx.y;
+  int l = level0 + blockIdx.y;
   const float* g = d_enc + i * stride_n + (int64_t)l * stride_l;
   float g0 = g[0], g1 = g[1];
   if (g0 == 0.0f && g1 == 0.0f) return;  // masked / zero-weight samples contribute exact zeros
@@ -441,18 +441,21 @@ extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int
 }
 
 extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
-                                 const float* scalings, int64_t n, int n_levels, int log2_T, float* d_table,
-                                 int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
-  if (n < 0 || !pos01 || !d_enc || !scalings || !d_table) return UMHS_ERR_ARG;
+                                 const float* scalings, int64_t n, int level_begin, int n_levels, int log2_T,
+                                 float* d_table, int overwrite, void* workspace, size_t workspace_bytes,
+                                 umhs_stream_t stream) {
+  if (n < 0 || !pos01 || !d_enc || !scalings || !d_table || level_begin < 0) return UMHS_ERR_ARG;
   if (overwrite && (!workspace || n == 0)) {  // only the partitioned path writes every slot itself
-    if (hipMemsetAsync(d_table, 0, ((size_t)n_levels << log2_T) * 8, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
+    if (hipMemsetAsync(d_table + (((size_t)level_begin << log2_T) * 2), 0, ((size_t)n_levels << log2_T) * 8, umhs_s(stream)) !=
+        hipSuccess)
+      return UMHS_ERR_LAUNCH;
   }
-  if (n_levels < 1 || n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (n_levels < 1 || level_begin + n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
   if (n == 0) return UMHS_OK;
   if (!workspace) {  // v1: memory-side float atomics (no workspace needed; fine for small N)
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
     hipLaunchKernelGGL(hashgrid_bwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01, d_enc, stride_n, stride_l,
-                       scalings, n, log2_T, d_table);
+                       scalings, n, log2_T, d_table, level_begin);
     UMHS_CHECK_LAUNCH();
     return UMHS_OK;
   }
@@ -462,7 +465,7 @@ extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t
   if ((size_t)8 * n * n_levels >= ((size_t)1 << 32)) return UMHS_ERR_UNSUPPORTED;
   HbArgs a;
   a.pos01 = pos01, a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.scalings = scalings, a.n = n;
-  a.log2_T = log2_T, a.bucket_bits = hb_bucket_bits(log2_T), a.nb = 1 << (log2_T - a.bucket_bits), a.level0 = 0;
+  a.log2_T = log2_T, a.bucket_bits = hb_bucket_bits(log2_T), a.nb = 1 << (log2_T - a.bucket_bits), a.level0 = level_begin;
   a.nlev = n_levels, a.overwrite = overwrite;
   const size_t m = (size_t)n_levels * a.nb, cap = (size_t)8 * n * n_levels;
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;

@@ -55,7 +55,7 @@ SIGNATURES = {
     "umhs_positions_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.POINTER(_f32), _vp, _vp, _vp, _vp]),
     "umhs_hashgrid_fwd": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _i64, _i64, _vp]),
     "umhs_hashgrid_bwd_workspace_bytes": (C.c_size_t, [_i64, C.c_int, C.c_int]),
-    "umhs_hashgrid_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "umhs_hashgrid_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, _vp]),
     "umhs_field_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FieldCfg)]),
     "umhs_field_fwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _i64,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),

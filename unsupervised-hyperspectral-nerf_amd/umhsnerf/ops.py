@@ -104,6 +104,7 @@ class FieldSpec:
     contraction: bool = True
     aabb: Tuple[float, ...] = (-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)
     scalings: Optional[torch.Tensor] = None  # device [16] float32
+    grad_sink: Optional[object] = None  # parallel.FlatGradSink: persistent flat-gradient buffer + early all-reduce
 
     def cfg(self, density_only: bool = False) -> _hip.FieldCfg:
         return _hip.FieldCfg(self.layout.wavelengths, self.layout.num_classes, int(self.layout.pred_specular),
@@ -144,16 +145,16 @@ def hashgrid_fwd(pos01, table, scalings, log2_T: int, level_major: bool = True):
 
 
 def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, method: str = "auto",
-                 overwrite: bool = False):
-    """d_table (+)= scatter(d_enc).  method: "partition" (atomics-free, needs a workspace), "atomic", or "auto".
-    overwrite=True: every slot of d_table is written (no need to zero it first)."""
+                 overwrite: bool = False, level_begin: int = 0, level_count: int = NUM_LEVELS):
+    """d_table (+)= scatter(d_enc) for levels [level_begin, level_begin+level_count).  method: "partition" (atomics-free,
+    needs a workspace), "atomic", or "auto".  overwrite=True: every slot of those levels is written (no zeroing needed)."""
     n = pos01.shape[0]
     sn, sl = enc_strides(n, level_major)
-    nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, NUM_LEVELS, log2_T) if method != "atomic" else 0
+    nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, level_count, log2_T) if method != "atomic" else 0
     if method == "partition" and nbytes == 0:
         raise RuntimeError("partitioned hash-grid backward unavailable for this shape")
     ws = _workspace(nbytes, pos01.device, slot=1) if nbytes else None
-    _hip.check(_hip.lib().umhs_hashgrid_bwd(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, NUM_LEVELS, log2_T,
+    _hip.check(_hip.lib().umhs_hashgrid_bwd(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, level_begin, level_count, log2_T,
                                             ptr(d_table), int(overwrite), ptr(ws), ws.numel() if ws is not None else 0,
                                             _hip.stream()),
                "umhs_hashgrid_bwd")
@@ -316,11 +317,24 @@ class FieldFn(torch.autograd.Function):
         d_sigma = _hip.f32c(d_sigma).view(-1) if d_sigma is not None else zeros(n)
         d_spectral = _hip.f32c(d_spectral) if d_spectral is not None else zeros(n, L.wavelengths)
         d_emb = _hip.f32c(d_emb) if d_emb is not None else None
-        d_flat = torch.empty_like(flat)  # the 64 MiB table segment is fully written by hashgrid_bwd(overwrite=True)
-        d_flat[L.offset("mlp_base.mlp.layers.0.weight"):].zero_()  # MLP / endmember segments (+ alignment padding)
+        sink = spec.grad_sink
+        own = sink is not None and sink.param is flat and sink.owns_next_backward()
+        # the 64 MiB table segment is fully written by hashgrid_bwd(overwrite=True): no memset of the flat gradient
+        d_flat = sink.begin() if own else torch.empty_like(flat)
+        tail = L.offset("mlp_base.mlp.layers.0.weight")
+        d_flat[tail:].zero_()  # MLP / endmember segments (+ alignment padding)
         d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat)
-        hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, L.view(d_flat, "mlp_base.encoder.hash_table"), True,
-                     overwrite=True)
+        if own:
+            sink.segment_done(d_flat[tail:])
+        table = L.view(d_flat, "mlp_base.encoder.hash_table")
+        T = 1 << L.log2_hashmap_size
+        for l0, cnt in (sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]):
+            hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
+            if own:
+                sink.segment_done(table[l0 * T:(l0 + cnt) * T])
+        if own:  # the buffer becomes param.grad directly (autograd gets None: nothing to accumulate or copy)
+            sink.commit()
+            return None, None, None, None, None, None
         return d_flat, None, None, None, None, None
 
 

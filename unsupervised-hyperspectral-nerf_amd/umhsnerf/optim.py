@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import ops
-from .parallel import allreduce_flat_grad
+from .parallel import allreduce_flat_grad, world
 
 
 def exp_decay_lr(step: int, lr_init: float = 2e-2, lr_final: float = 1e-5, max_steps: int = 30000) -> float:
@@ -38,7 +38,11 @@ class UMHSAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
                 st["step"] += 1
-                grad_scale = allreduce_flat_grad(p.grad)  # one 67 MB RCCL all-reduce over xGMI (no-op at world 1)
+                sink = getattr(p, "_umhs_grad_sink", None)
+                if sink is not None and sink.finish(p.grad):  # segments were all-reduced while the backward was still running
+                    grad_scale = 1.0 / world()[1]
+                else:
+                    grad_scale = allreduce_flat_grad(p.grad)  # one 67 MB RCCL all-reduce over xGMI (no-op at world 1)
                 lr = group["lr"]
                 if group["lr_final"] is not None:
                     lr = exp_decay_lr(st["step"] - 1, group["lr_init"], group["lr_final"], group["max_steps"])

@@ -38,3 +38,60 @@ def allreduce_flat_grad(grad: torch.Tensor) -> float:
 def broadcast_params(flat: torch.Tensor, src: int = 0) -> None:
     if world()[1] > 1:
         dist.broadcast(flat, src=src)
+
+
+class FlatGradSink:
+    """Persistent flat gradient buffer for the "fields" parameter, with early reduction of finished segments.
+
+    ``ops.FieldFn.backward`` writes the gradient straight into this buffer and hands it over as ``param.grad`` itself (no
+    autograd accumulation copy).  With more than one rank every segment is all-reduced (async, RCCL stream) as soon as the
+    kernel that finishes it has been launched: the small MLP/endmember tail right after the field backward, then the hash
+    table per level group while the partition/reduce kernels of the next group still run -- so most of the 67 MB
+    exchange hides behind the tail of the backward instead of following it.  ``UMHSAdam.step`` waits for the pending
+    reductions and applies 1/world.  Gradient accumulation (``param.grad`` already set) falls back to the plain path.
+    """
+
+    def __init__(self, param: torch.nn.Parameter, level_groups: int = 4):
+        import os
+
+        self.param, self.buffer, self.works = param, None, []
+        self.level_groups = level_groups
+        self.async_reduce = os.environ.get("UMHS_ASYNC_REDUCE", "1") != "0"
+        self.reduced_ptr = None
+
+    def owns_next_backward(self) -> bool:
+        return self.param.grad is None
+
+    def begin(self) -> torch.Tensor:
+        p = self.param
+        if self.buffer is None or self.buffer.shape != p.shape or self.buffer.device != p.device:
+            self.buffer = torch.empty_like(p.data)
+        self.works.clear()
+        self.reduced_ptr = None
+        return self.buffer
+
+    def groups(self, n_levels: int):
+        if world()[1] == 1 or not self.async_reduce:
+            return [(0, n_levels)]
+        g = max(1, n_levels // self.level_groups)
+        return [(l, min(g, n_levels - l)) for l in range(0, n_levels, g)]
+
+    def segment_done(self, view: torch.Tensor) -> None:
+        if world()[1] > 1 and self.async_reduce:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def commit(self) -> None:
+        self.param.grad = self.buffer
+        if self.works:
+            self.reduced_ptr = self.buffer.data_ptr()
+
+    def finish(self, grad: torch.Tensor) -> bool:
+        """Wait for pending reductions; True if ``grad`` is already summed over the ranks."""
+        if not self.works:
+            return False
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        if grad.data_ptr() != self.reduced_ptr:
+            raise RuntimeError("param.grad is not the buffer that was reduced (was .grad replaced after backward?)")
+        return True

@@ -92,6 +92,8 @@ class UMHSField(nn.Module):
         L.view(flat, "endmembers").copy_(E)
         self.flat = nn.Parameter(flat)
         self._cache: Optional[Tuple] = None
+        self.use_grad_sink = False  # UMHSPipeline turns this on: backward writes param.grad in place (+ early all-reduce)
+        self._grad_sink = None
 
     # ---- parameter views under the reference's names ------------------------------------------------
     @property
@@ -122,6 +124,12 @@ class UMHSField(nn.Module):
         if c is None or c.scalings.device != self.scalings.device or c.temperature != float(self.temperature):
             c = ops.FieldSpec(self.layout, float(self.temperature), self.spatial_distortion is not None, self._aabb_host, self.scalings)
             self._spec_cache = c
+        if self.use_grad_sink and (self._grad_sink is None or self._grad_sink.param is not self.flat):
+            from .parallel import FlatGradSink
+
+            self._grad_sink = FlatGradSink(self.flat)
+            self.flat._umhs_grad_sink = self._grad_sink
+        c.grad_sink = self._grad_sink if self.use_grad_sink else None
         return c
 
     # ---- reference API ------------------------------------------------------------------------------

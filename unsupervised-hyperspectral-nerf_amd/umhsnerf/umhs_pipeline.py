@@ -25,6 +25,7 @@ class UMHSPipeline(torch.nn.Module):
         self._model = UMHSModel(config, scene_box=scene_box, metadata=metadata, seed=seed).to(device)
         if world_size > 1:  # identical parameters on every rank (DDP's initial broadcast)
             dist.broadcast(self._model.field.flat.data, src=0)
+        self._model.field.use_grad_sink = True  # backward fills param.grad in place and reduces finished segments early
         self.optimizer = self._model.make_optimizer()
 
     @property
