@@ -77,3 +77,44 @@ def test_shard_rays_partitions_exactly():
         assert sl[0][0] == 0 and sl[-1][1] == R and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
         assert max(e - b for b, e in sl) - min(e - b for b, e in sl) <= 1
     assert rank_seed(42, 3) == 45
+
+
+def _sink_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from umhsnerf import parallel
+        from umhsnerf.optim import UMHSAdam  # noqa: F401  (import only: the fused step itself needs the GPU)
+
+        p = torch.nn.Parameter(torch.zeros(64))
+        sink = parallel.FlatGradSink(p, level_groups=4)
+        assert sink.groups(16) == [(0, 4), (4, 4), (8, 4), (12, 4)]
+        for it in range(2):  # the buffer is reused from one backward to the next
+            assert sink.owns_next_backward()
+            buf = sink.begin()
+            buf.copy_(torch.arange(64.0) * (rank + 1) + it)
+            sink.segment_done(buf[48:])
+            for l0, cnt in sink.groups(12):
+                sink.segment_done(buf[l0 * 4:(l0 + cnt) * 4])
+            sink.commit()
+            assert p.grad is buf and not sink.owns_next_backward()  # a second backward would have to accumulate: plain path
+            assert sink.finish(p.grad)
+            torch.testing.assert_close(p.grad, torch.arange(64.0) * 3 + 2 * it)
+            assert not sink.finish(p.grad)  # nothing pending any more
+            p.grad = None
+        sink.async_reduce = False
+        assert sink.groups(16) == [(0, 16)]
+        sink.begin().fill_(1.0)
+        sink.segment_done(sink.buffer)
+        sink.commit()
+        assert not sink.finish(p.grad) and parallel.allreduce_flat_grad(p.grad) == 0.5 and float(p.grad[0]) == 2.0
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_sink_reduces_segments_early_and_falls_back():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sink_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}
