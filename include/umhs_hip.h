@@ -241,6 +241,37 @@ int umhs_visibility(const float* sigma, const float* t_starts, const float* t_en
                     int64_t n_rays, int64_t n, float early_stop_eps, float alpha_thre, uint8_t* mask, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* pixel sampler, ray generator and ground-truth gather (images resident in HBM, --images-on-gpu).    */
+/* Replaces, under UMHSDataManager.next_train (umhs_datamanager.py:95-108), nerfstudio's PixelSampler.sample          */
+/* (indices = long(rand[R,3] * (n, H, W)); batch[key] = stack[c, y, x]) and RayGenerator -> Cameras.generate_rays     */
+/* (perspective, no distortion: d = R_c2w * ((x+.5-cx)/fx, -(y+.5-cy)/fy, -1) normalised, origin = t_c2w,             */
+/* pixel_area from the +x / +y neighbour directions).  indices [R,3] int64 rows (camera, y, x); c2w [n,3,4];          */
+/* intrinsics [n,4] = (fx, fy, cx, cy); stack [n,H,W,K] fp32 or uint8 (scaled by 1/255); pixel_area /                 */
+/* directions_norm [R] optional.                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_pixel_indices(const float* uniform, int64_t n_rays, int64_t n_images, int64_t height, int64_t width,
+                       int64_t* indices, umhs_stream_t stream);
+int umhs_raygen(const int64_t* indices, const float* c2w, const float* intrinsics, int64_t n_rays, int64_t n_cams,
+                float* origins, float* directions, float* pixel_area, float* directions_norm, umhs_stream_t stream);
+int umhs_pixel_gather(const int64_t* indices, const void* stack, int src_is_u8, int64_t n_images, int64_t height,
+                      int64_t width, int n_channels, int64_t n_rays, float* out, umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* image metrics of the eval path, get_image_metrics_and_images (umhs_model.py:407-453), on channel-last */
+/* images [H*W, K] as rendered.  umhs_pixel_metrics: partial[b] = {sum (p-g)^2, sum of finite spectral angles          */
+/* acos(clamp(<p,g>/(|p||g|))), count of finite angles} per block b < n_partial (PSNR :430,444, RMSE :452, SAM :447).   */
+/* umhs_ssim: torchmetrics==1.5.2 structural_similarity_index_measure (:431,445; 11x11 gaussian sigma 1.5, k1 .01,      */
+/* k2 .03): partial[] = per-block sums of the SSIM index over the (H-10)(W-10)K windows inside the image;               */
+/* data_range = DEVICE float (max(a.max-a.min, b.max-b.min) for the default data_range=None).                           */
+/* The caller adds the partials (fixed order: reproducible) and divides.                                                */
+/* ------------------------------------------------------------------------------------------ */
+int umhs_pixel_metrics(const float* pred, const float* gt, int64_t n_pixels, int n_channels, double* partial, int n_partial,
+                       umhs_stream_t stream);
+int64_t umhs_ssim_partials(int height, int width, int n_channels);
+int umhs_ssim(const float* a, const float* b, int height, int width, int n_channels, const float* data_range,
+              double* partial, int64_t n_partial, umhs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Optimizer: torch.optim.Adam step for param group "fields" (AdamOptimizerConfig(lr=2e-2,      */
 /* eps=1e-15), umhs_config.py:59-64) over one flat fp32 buffer, with the clamp_endmembers        */
 /* callback (umhs_model.py:568-572) fused for elements [clamp_begin, clamp_end).  grad_scale     */

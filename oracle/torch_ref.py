@@ -672,3 +672,112 @@ def render_visibility_from_density(t_starts, t_ends, sigmas, packed_info, early_
     if alpha_thre > 0:
         vis = vis & (alphas >= alpha_thre)
     return vis
+
+
+# ------------------------------------------------------------------------------------------------ #
+# pixel sampler / ray generator / GT gather (nerfstudio==1.1.5 behind umhs_datamanager.py:95-108).
+# nerfstudio is not available offline: [upstream-recalled], parity unpinned for these three.
+# ------------------------------------------------------------------------------------------------ #
+def pixel_sample_indices(uniform: torch.Tensor, n_images: int, height: int, width: int) -> torch.Tensor:
+    """PixelSampler.sample_method: ``(rand((R,3)) * tensor([n, H, W])).long()`` -> rows (camera, y, x)."""
+    return (uniform.float() * torch.tensor([n_images, height, width], dtype=torch.float32)).long()
+
+
+def generate_rays(indices: torch.Tensor, c2w: torch.Tensor, intrinsics: torch.Tensor):
+    """RayGenerator.forward + Cameras._generate_rays_from_coords, perspective, no distortion.
+
+    indices [R,3] (camera, y, x); c2w [n,3,4]; intrinsics [n,4] = fx, fy, cx, cy.  Pixel centres (+0.5), camera looks down -z,
+    y up; returns origins, unit directions, pixel_area [R,1] (|d - d_x+1| * |d - d_y+1|), directions_norm [R,1]."""
+    c, y, x = indices[:, 0], indices[:, 1].float() + 0.5, indices[:, 2].float() + 0.5
+    fx, fy, cx, cy = (intrinsics[c, k] for k in range(4))
+    coord = torch.stack([(x - cx) / fx, -(y - cy) / fy], -1)
+    coord_x = torch.stack([(x - cx + 1) / fx, -(y - cy) / fy], -1)
+    coord_y = torch.stack([(x - cx) / fx, -(y - cy + 1) / fy], -1)
+    cs = torch.stack([coord, coord_x, coord_y], 0)  # [3,R,2]
+    ds = torch.cat([cs, -torch.ones_like(cs[..., :1])], -1)  # [3,R,3]
+    rot = c2w[c][:, :3, :3]
+    ds = torch.sum(ds[..., None, :] * rot, dim=-1)
+    nrm = torch.maximum(torch.linalg.vector_norm(ds, dim=-1, keepdim=True), torch.tensor([torch.finfo(torch.float32).eps]))
+    ds = ds / nrm
+    dx = torch.sqrt(torch.sum((ds[0] - ds[1]) ** 2, dim=-1))
+    dy = torch.sqrt(torch.sum((ds[0] - ds[2]) ** 2, dim=-1))
+    return c2w[c][:, :3, 3], ds[0], (dx * dy)[:, None], nrm[0]
+
+
+def gather_pixels(indices: torch.Tensor, stack: torch.Tensor) -> torch.Tensor:
+    """collate_image_dataset_batch: ``stack[c, y, x]`` (uint8 stacks are float32/255 as in InputDataset.get_image_float32)."""
+    v = stack[indices[:, 0], indices[:, 1], indices[:, 2]]
+    return v.float() / 255.0 if stack.dtype == torch.uint8 else v
+
+
+def auto_orient_and_center_poses(poses: torch.Tensor, method: str = "up", center_method: str = "poses"):
+    """nerfstudio camera_utils.auto_orient_and_center_poses for the settings the reference's dataparser defaults to
+    (umhs_dataparser.py:86-89: orientation "up", center "poses"; "none" supported).  poses [n,3|4,4] float32."""
+    origins = poses[:, :3, 3]
+    translation = origins.mean(0) if center_method == "poses" else torch.zeros(3)
+    if center_method not in ("poses", "none") or method not in ("up", "none"):
+        raise NotImplementedError((method, center_method))
+    if method == "up":
+        up = poses[:, :3, 1].mean(0)
+        up = up / torch.linalg.norm(up)
+        a, b = up, torch.tensor([0.0, 0.0, 1.0])
+        v = torch.linalg.cross(a, b)
+        cth = torch.dot(a, b)
+        if float(cth) < -1 + 1e-8:  # opposite vectors: nerfstudio perturbs a and retries
+            a = a + (torch.rand(3) - 0.5) * 0.01
+            a = a / torch.linalg.norm(a)
+            v, cth = torch.linalg.cross(a, b), torch.dot(a, b)
+        s = torch.linalg.norm(v)
+        K = torch.tensor([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        R = torch.eye(3) + K + K @ K * ((1 - cth) / (s ** 2 + 1e-8))
+        transform = torch.cat([R, R @ -translation[..., None]], dim=-1)
+    else:
+        transform = torch.eye(4)[:3].clone()
+        transform[:3, 3] = -translation
+    p4 = poses if poses.shape[1] == 4 else torch.cat([poses, torch.tensor([[[0.0, 0, 0, 1]]]).expand(poses.shape[0], 1, 4)], 1)
+    return transform @ p4, transform
+
+
+# ------------------------------------------------------------------------------------------------ #
+# SURVEY 8(f)-4: image metrics of get_image_metrics_and_images (umhs_model.py:407-453).  torchmetrics==1.5.2 is not
+# available offline: [upstream-recalled] restatement of structural_similarity_index_measure and SpectralAngleMapper.
+# ------------------------------------------------------------------------------------------------ #
+def ssim_ref(preds: torch.Tensor, target: torch.Tensor, data_range=None) -> torch.Tensor:
+    """preds/target [1,C,H,W].  gaussian_kernel=True, sigma=1.5 (kernel 11), k1=.01, k2=.03, reduction elementwise_mean."""
+    if data_range is None:
+        data_range = max(preds.max() - preds.min(), target.max() - target.min())
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    ch, ks, pad = preds.shape[1], 11, 5
+    dist = torch.arange((1 - ks) / 2, (1 + ks) / 2, 1, dtype=preds.dtype)
+    g = torch.exp(-((dist / 1.5) ** 2) / 2)
+    g = (g / g.sum()).unsqueeze(0)
+    kernel = torch.matmul(g.t(), g).expand(ch, 1, ks, ks)
+    p = torch.nn.functional.pad(preds, (pad, pad, pad, pad), mode="reflect")
+    t = torch.nn.functional.pad(target, (pad, pad, pad, pad), mode="reflect")
+    out = torch.nn.functional.conv2d(torch.cat((p, t, p * p, t * t, p * t)), kernel, groups=ch).split(preds.shape[0])
+    mpp, mtt, mpt = out[0].pow(2), out[1].pow(2), out[0] * out[1]
+    vp, vt = torch.clamp(out[2] - mpp, min=0.0), torch.clamp(out[3] - mtt, min=0.0)
+    cov = out[4] - mpt
+    full = ((2 * mpt + c1) * (2 * cov + c2)) / ((mpp + mtt + c1) * (vp + vt + c2))
+    idx = full[..., pad:-pad, pad:-pad]
+    return idx.reshape(idx.shape[0], -1).mean(-1).mean()
+
+
+def sam_ref(preds: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """SpectralAngleMapper(reduction="none") on [1,C,H,W] -> [1,H,W] angles (NaN where a spectrum is all zero)."""
+    dot = (preds * target).sum(dim=1)
+    return torch.clamp(dot / (preds.norm(dim=1) * target.norm(dim=1)), -1, 1).acos()
+
+
+def image_metrics_ref(pred_rgb, gt_rgb, pred_spec=None, gt_spec=None):
+    """Metric values of umhs_model.py:430-452 for channel-last images [H,W,K] (lpips omitted: pretrained weights)."""
+    chw = lambda x: torch.moveaxis(x, -1, 0)[None]
+    g, p = chw(gt_rgb), chw(pred_rgb)
+    md = {"psnr": float(10 * torch.log10(1.0 / torch.mean((g - p) ** 2))), "ssim": float(ssim_ref(g, p))}
+    if pred_spec is not None:
+        gs, ps = chw(gt_spec), chw(pred_spec)
+        md["psnr_spectral"] = float(10 * torch.log10(1.0 / torch.mean((gs - ps) ** 2)))
+        md["ssim_spectral"] = float(ssim_ref(gs, ps))
+        md["sam_spectral"] = float(torch.nanmean(sam_ref(ps, gs)))
+        md["rmse_spectral"] = float(torch.sqrt(torch.nn.functional.mse_loss(ps, gs)))
+    return md

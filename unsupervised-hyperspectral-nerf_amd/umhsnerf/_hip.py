@@ -76,6 +76,12 @@ SIGNATURES = {
     "umhs_march_count": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "umhs_march_write": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "umhs_visibility": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "umhs_pixel_indices": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "umhs_raygen": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "umhs_pixel_gather": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _i64, _vp, _vp]),
+    "umhs_pixel_metrics": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, C.c_int, _vp]),
+    "umhs_ssim_partials": (_i64, [C.c_int, C.c_int, C.c_int]),
+    "umhs_ssim": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp]),
     "umhs_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _i64, _i64, _vp]),
 }
 

@@ -53,6 +53,7 @@ except Exception:  # ModuleNotFoundError offline
         camera_indices: Optional[Tensor] = None
         nears: Optional[Tensor] = None
         fars: Optional[Tensor] = None
+        metadata: Optional[dict] = None
 
         def __len__(self):
             return self.origins.shape[0]

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libumhs_hip.so")
-SOURCES = ("umhs_kernels.hip", "umhs_field.hip", "umhs_sampler.hip")
+SOURCES = ("umhs_kernels.hip", "umhs_field.hip", "umhs_sampler.hip", "umhs_data.hip", "umhs_metrics.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-munsafe-fp-atomics", "-std=c++17"]
 
 

@@ -1,0 +1,127 @@
+"""UMHSDataManager (mirror of ``umhsnerf/data/umhs_datamanager.py``) with the image stacks resident in HBM.
+
+``next_train`` (``:95-108``) is: draw pixel indices, gather their rows from the image / hs_image stacks, generate the rays.
+In the reference those are nerfstudio's PixelSampler, a fancy-index gather per key and ``Cameras.generate_rays``; here each
+is one kernel of libumhs_hip.so (``umhs_pixel_indices`` / ``umhs_pixel_gather`` / ``umhs_raygen``) on tensors that never
+leave the GPU.  The uniform draws come from ``torch.rand`` on the device generator, so runs are seeded the same way."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .. import ops
+from .._ns_compat import RayBundle
+from .umhs_dataparser import Cameras, DataparserOutputs, UMHSDataParserConfig
+from .utils.hs_dataloader import HyperspectralDataset
+
+
+@dataclass
+class UMHSDataManagerConfig:
+    dataparser: UMHSDataParserConfig = field(default_factory=UMHSDataParserConfig)
+    train_num_rays_per_batch: int = 4096
+    eval_num_rays_per_batch: int = 4096
+    images_on_gpu: bool = True
+    patch_size: int = 1
+
+    def setup(self, **kwargs) -> "UMHSDataManager":
+        return UMHSDataManager(self, **kwargs)
+
+
+class ResidentSplit:
+    """One split: cameras + contiguous [n,H,W,K] stacks on the device."""
+
+    def __init__(self, cameras: Cameras, image: torch.Tensor, hs_image: Optional[torch.Tensor], device):
+        self.cameras = cameras.to(device)
+        self.c2w = self.cameras.camera_to_worlds.float().contiguous()
+        self.intrinsics = self.cameras.intrinsics
+        self.image = image.to(device).contiguous()
+        self.hs_image = hs_image.to(device).contiguous() if hs_image is not None else None
+        n, h, w = self.image.shape[:3]
+        if (h, w) != (cameras.height, cameras.width) or n != len(cameras):
+            raise ValueError(f"stack {tuple(self.image.shape)} does not match {n} cameras of {cameras.height}x{cameras.width}")
+
+    def __len__(self) -> int:
+        return self.image.shape[0]
+
+    def sample(self, num_rays: int, generator=None) -> Tuple[RayBundle, Dict]:
+        n, h, w = self.image.shape[:3]
+        u = torch.rand((num_rays, 3), device=self.image.device, generator=generator)
+        indices = ops.pixel_indices(u, n, h, w)
+        return self.rays(indices), self.batch(indices)
+
+    def batch(self, indices: torch.Tensor) -> Dict:
+        b = {"image": ops.pixel_gather(indices, self.image), "indices": indices}
+        if self.hs_image is not None:
+            b["hs_image"] = ops.pixel_gather(indices, self.hs_image)
+        return b
+
+    def rays(self, indices: torch.Tensor) -> RayBundle:
+        o, d, area, nrm = ops.raygen(indices, self.c2w, self.intrinsics, want_area=True, want_norm=True)
+        return RayBundle(origins=o, directions=d, pixel_area=area, camera_indices=indices[:, :1].contiguous(),
+                         metadata={"directions_norm": nrm})
+
+    def image_rays(self, camera_index: int) -> RayBundle:
+        """``cameras.generate_rays(camera_indices=i, keep_shape=True)``: one ray per pixel, [H,W,...]."""
+        _, h, w = self.image.shape[:3]
+        dev = self.image.device
+        yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+        idx = torch.stack([torch.full_like(yy, camera_index), yy, xx], -1).reshape(-1, 3).contiguous()
+        rb = self.rays(idx)
+        return RayBundle(origins=rb.origins.view(h, w, 3), directions=rb.directions.view(h, w, 3), pixel_area=rb.pixel_area.view(h, w, 1),
+                         camera_indices=rb.camera_indices.view(h, w, 1))
+
+
+class UMHSDataManager:
+    """Train/eval splits of one scene, images on the GPU.  ``world_size``/``local_rank``: every rank keeps the full stacks
+    and draws its own full per-rank batch from its own generator (seed + rank), as nerfstudio's data managers do."""
+
+    def __init__(self, config: UMHSDataManagerConfig, device="cpu", test_mode: str = "val", world_size: int = 1, local_rank: int = 0,
+                 num_classes: int = 5, seed: int = 42, train: Optional[ResidentSplit] = None, eval: Optional[ResidentSplit] = None,
+                 metadata: Optional[Dict] = None, **kwargs):
+        if not config.images_on_gpu:
+            raise NotImplementedError("the gather kernels read resident stacks: images_on_gpu must be True (scripts/hotdog.sh:8)")
+        if config.patch_size != 1:
+            raise NotImplementedError("patch_size > 1 (PatchPixelSampler) is not used by the reference's scripts")
+        self.config, self.device, self.world_size, self.local_rank = config, torch.device(device), world_size, local_rank
+        config.dataparser.num_classes = num_classes
+        if train is None:
+            parser = config.dataparser.setup()
+            self.train_dataparser_outputs: DataparserOutputs = parser.get_dataparser_outputs("train")
+            tr = HyperspectralDataset(self.train_dataparser_outputs)
+            train = ResidentSplit(tr.cameras, tr.image, tr.hs_image, self.device)
+            ev_out = parser.get_dataparser_outputs("val" if test_mode != "test" else "test")
+            if len(ev_out.image_filenames):
+                ev = HyperspectralDataset(ev_out)
+                eval = ResidentSplit(ev.cameras, ev.image, ev.hs_image, self.device)
+            metadata = self.train_dataparser_outputs.metadata
+            self.scene_box = self.train_dataparser_outputs.scene_box
+        self.train_split, self.eval_split, self.metadata = train, eval, metadata or {}
+        self.train_count = self.eval_count = 0
+        self.generator = torch.Generator(device=self.device)
+        self.generator.manual_seed(seed + local_rank)
+        self._eval_cursor = 0
+
+    def get_train_rays_per_batch(self) -> int:
+        return self.config.train_num_rays_per_batch
+
+    def get_eval_rays_per_batch(self) -> int:
+        return self.config.eval_num_rays_per_batch
+
+    def next_train(self, step: int) -> Tuple[RayBundle, Dict]:
+        self.train_count += 1
+        return self.train_split.sample(self.config.train_num_rays_per_batch, self.generator)
+
+    def next_eval(self, step: int) -> Tuple[RayBundle, Dict]:
+        self.eval_count += 1
+        return (self.eval_split or self.train_split).sample(self.config.eval_num_rays_per_batch, self.generator)
+
+    def next_eval_image(self, step: int):
+        split = self.eval_split or self.train_split
+        i = self._eval_cursor % len(split)
+        self._eval_cursor += 1
+        batch = {"image": split.image[i], "image_idx": i}
+        if split.hs_image is not None:
+            batch["hs_image"] = split.hs_image[i]
+        return split.image_rays(i), batch

@@ -280,6 +280,64 @@ def adam_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps=1e-15, g
                                          grad_scale, clamp_range[0], clamp_range[1], _hip.stream()), "umhs_adam_step")
 
 
+def pixel_indices(uniform, n_images: int, height: int, width: int):
+    """PixelSampler.sample_method: long(uniform[R,3] * (n, H, W)) -> [R,3] int64 rows (camera, y, x)."""
+    u = _hip.f32c(uniform)
+    out = torch.empty(u.shape, dtype=torch.int64, device=u.device)
+    _hip.check(_hip.lib().umhs_pixel_indices(ptr(u), u.shape[0], n_images, height, width, ptr(out), _hip.stream()), "umhs_pixel_indices")
+    return out
+
+
+def raygen(indices, c2w, intrinsics, want_area: bool = True, want_norm: bool = False):
+    """Cameras.generate_rays for perspective cameras: -> origins [R,3], directions [R,3], pixel_area [R,1] | None, norm | None."""
+    r, dev = indices.shape[0], indices.device
+    o, d = torch.empty(r, 3, device=dev), torch.empty(r, 3, device=dev)
+    area = torch.empty(r, 1, device=dev) if want_area else None
+    nrm = torch.empty(r, 1, device=dev) if want_norm else None
+    _hip.check(_hip.lib().umhs_raygen(ptr(indices), ptr(c2w), ptr(intrinsics), r, c2w.shape[0], ptr(o), ptr(d), ptr(area), ptr(nrm),
+                                      _hip.stream()), "umhs_raygen")
+    return o, d, area, nrm
+
+
+def pixel_gather(indices, stack):
+    """batch[key] = stack[c, y, x] for a resident image stack [n,H,W,K] (fp32, or uint8 -> /255)."""
+    assert stack.dim() == 4 and stack.is_contiguous() and stack.dtype in (torch.float32, torch.uint8)
+    n, h, w, k = stack.shape
+    out = torch.empty(indices.shape[0], k, device=indices.device)
+    _hip.check(_hip.lib().umhs_pixel_gather(ptr(indices), ptr(stack), int(stack.dtype == torch.uint8), n, h, w, k, indices.shape[0],
+                                            ptr(out), _hip.stream()), "umhs_pixel_gather")
+    return out
+
+
+def pixel_metrics(pred, gt):
+    """(sum of squared errors, sum of finite spectral angles, number of finite angles) over channel-last images [...,K]; float64."""
+    k = pred.shape[-1]
+    p, g = _hip.f32c(pred).view(-1, k), _hip.f32c(gt).view(-1, k)
+    assert p.shape == g.shape
+    nb = max(1, min(1024, (p.shape[0] + 255) // 256))
+    part = torch.empty(nb, 3, dtype=torch.float64, device=p.device)
+    _hip.check(_hip.lib().umhs_pixel_metrics(ptr(p), ptr(g), p.shape[0], k, ptr(part), nb, _hip.stream()), "umhs_pixel_metrics")
+    return part.sum(0)
+
+
+def ssim(a, b, data_range=None):
+    """torchmetrics structural_similarity_index_measure (gaussian 11x11, sigma 1.5) of channel-last images [H,W,K] -> 0-dim float64."""
+    a, b = _hip.f32c(a), _hip.f32c(b)
+    assert a.dim() == 3 and a.shape == b.shape
+    h, w, k = a.shape
+    n = _hip.lib().umhs_ssim_partials(h, w, k)
+    if n == 0:
+        raise ValueError(f"SSIM needs images of at least 11x11 pixels, got {h}x{w}")
+    if data_range is None:
+        (alo, ahi), (blo, bhi) = torch.aminmax(a), torch.aminmax(b)
+        dr = torch.maximum(ahi - alo, bhi - blo).reshape(1)
+    else:
+        dr = torch.full((1,), float(data_range), device=a.device)
+    part = torch.empty(n, dtype=torch.float64, device=a.device)
+    _hip.check(_hip.lib().umhs_ssim(ptr(a), ptr(b), h, w, k, ptr(dr), ptr(part), n, _hip.stream()), "umhs_ssim")
+    return part.sum() / float((h - 10) * (w - 10) * k)
+
+
 # --------------------------------------------------------------------------------------------- #
 # autograd glue
 # --------------------------------------------------------------------------------------------- #

@@ -276,15 +276,59 @@ class UMHSModel(nn.Module):
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
-        """umhs_model.py:593-620, chunked by eval_num_rays_per_chunk."""
+        """umhs_model.py:593-620.  The reference walks the image in 512-ray chunks (its kernels are launch-bound there); here a
+        chunk is ``max(eval_num_rays_per_chunk, 32768)`` rays, i.e. a 128x128 image or a quarter-megapixel strip is ONE fused
+        inference launch per kernel, and outputs stay on the model device."""
         o = camera_ray_bundle.origins
         hw = o.shape[:-1]
-        flat = RayBundle(origins=o.reshape(-1, 3), directions=camera_ray_bundle.directions.reshape(-1, 3))
+        origins, directions = o.reshape(-1, 3).to(self.device), camera_ray_bundle.directions.reshape(-1, 3).to(self.device)
         outs: Dict[str, List[Tensor]] = {}
-        n, ch = flat.origins.shape[0], self.config.eval_num_rays_per_chunk
+        n, ch = origins.shape[0], max(int(self.config.eval_num_rays_per_chunk), 32768)
         for i in range(0, n, ch):
-            rb = RayBundle(origins=flat.origins[i:i + ch].to(self.device), directions=flat.directions[i:i + ch].to(self.device))
+            rb = RayBundle(origins=origins[i:i + ch], directions=directions[i:i + ch])
             for k, v in self.forward(rb).items():
                 if isinstance(v, Tensor) and v.shape[:1] == (len(rb),):
-                    outs.setdefault(k, []).append(v.to(o.device))
-        return {k: torch.cat(v).view(*hw, -1) for k, v in outs.items()}
+                    outs.setdefault(k, []).append(v)
+        return {k: (v[0] if len(v) == 1 else torch.cat(v)).view(*hw, -1) for k, v in outs.items()}
+
+    def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Tensor]:
+        """umhs_model.py:527-539: ``camera`` is anything with ``generate_rays(camera_indices=0, keep_shape=True)`` or a RayBundle."""
+        rb = camera if isinstance(camera, RayBundle) else camera.generate_rays(camera_indices=0, keep_shape=True)
+        return self.get_outputs_for_camera_ray_bundle(rb)
+
+    @torch.no_grad()
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
+        """umhs_model.py:407-512: psnr / ssim on rgb, psnr / ssim / sam / rmse on the spectral image; lpips is omitted (its
+        pretrained weights cannot be fetched offline).  One host read at the end instead of one ``.item()`` per metric."""
+        gt_rgb = batch["image"].to(self.device)
+        if gt_rgb.shape[-1] == 4:  # renderer_rgb.blend_background: composite RGBA ground truth over the background colour
+            bgv = 1.0 if self.background_color == "white" else 0.0
+            gt_rgb = gt_rgb[..., :3] * gt_rgb[..., 3:] + bgv * (1 - gt_rgb[..., 3:])
+        pred_rgb = outputs["rgb"]
+        vals = {}
+        sse, _, _ = ops.pixel_metrics(pred_rgb, gt_rgb)
+        vals["psnr"] = 10.0 * torch.log10(pred_rgb.numel() / sse)
+        vals["ssim"] = ops.ssim(gt_rgb, pred_rgb)
+        if "spectral" in self.config.method:
+            gt_s, pred_s = batch["hs_image"].to(self.device), outputs["spectral"]
+            sse, sam, cnt = ops.pixel_metrics(pred_s, gt_s)
+            mse = sse / pred_s.numel()
+            vals["psnr_spectral"] = 10.0 * torch.log10(1.0 / mse)
+            vals["ssim_spectral"] = ops.ssim(gt_s, pred_s)
+            vals["sam_spectral"] = sam / cnt
+            vals["rmse_spectral"] = torch.sqrt(mse)
+        keys = list(vals)
+        host = torch.stack([vals[k].double() for k in keys]).tolist()
+        metrics_dict = dict(zip(keys, host))
+        acc, depth = outputs["accumulation"], outputs["depth"]
+        near, far = depth.min(), depth.max()
+        images_dict = {"img": torch.cat([gt_rgb, pred_rgb], dim=1), "accumulation": acc.clamp(0, 1).expand(*acc.shape[:-1], 3),
+                       "depth": ((depth - near) / (far - near + 1e-10)).clamp(0, 1).expand(*depth.shape[:-1], 3),
+                       "se_per_pixel": ((gt_rgb - pred_rgb) ** 2).mean(dim=-1, keepdim=True)}
+        return metrics_dict, images_dict
+
+    @staticmethod
+    def compute_sam(pred: Tensor, gt: Tensor, eps: float = 1e-8) -> Tensor:
+        """umhs_model.py:514-525 (helper; mean spectral angle in radians, eps in the denominator)."""
+        cos = (pred * gt).sum(dim=-1) / (torch.norm(pred, dim=-1) * torch.norm(gt, dim=-1) + eps)
+        return torch.acos(torch.clamp(cos, -1, 1)).mean()

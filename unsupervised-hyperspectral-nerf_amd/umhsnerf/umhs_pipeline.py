@@ -18,10 +18,14 @@ class UMHSPipeline(torch.nn.Module):
     """Minimal pipeline: model + one train iteration on packed samples (what ``Trainer.train_iteration`` does around
     ``pipeline.get_train_loss_dict``: forward, loss, backward, optimizer step)."""
 
-    def __init__(self, config: UMHSConfig, device, metadata: Dict, world_size: int = 1, local_rank: int = 0,
-                 seed: Optional[int] = 42, scene_box=None):
+    def __init__(self, config: UMHSConfig, device, metadata: Optional[Dict] = None, world_size: int = 1, local_rank: int = 0,
+                 seed: Optional[int] = 42, scene_box=None, datamanager=None):
         super().__init__()
         self.world_size, self.local_rank = world_size, local_rank
+        self.datamanager = datamanager  # data.umhs_datamanager.UMHSDataManager (umhs_pipeline.py:87-94) or None (packed-sample callers)
+        if datamanager is not None:
+            metadata = {**(datamanager.metadata or {}), **(metadata or {})}
+            scene_box = scene_box if scene_box is not None else getattr(datamanager, "scene_box", None)
         self._model = UMHSModel(config, scene_box=scene_box, metadata=metadata, seed=seed).to(device)
         if world_size > 1:  # identical parameters on every rank (DDP's initial broadcast)
             dist.broadcast(self._model.field.flat.data, src=0)
@@ -40,6 +44,40 @@ class UMHSPipeline(torch.nn.Module):
         loss.backward()
         self.optimizer.step()
         return outputs, loss_dict
+
+    # ---- the reference's pipeline surface (umhs_pipeline.py:115-150 and VanillaPipeline.get_train_loss_dict) -----------
+    def get_train_loss_dict(self, step: int):
+        """One ``Trainer.train_iteration``: BEFORE callbacks (occupancy grid), next_train, forward, loss, backward, Adam (+ gradient
+        reduction), AFTER callbacks (clamp_endmembers, fused into the Adam kernel).  Returns (outputs, loss_dict, metrics_dict)."""
+        self._model.update_occupancy_grid(step)
+        ray_bundle, batch = self.datamanager.next_train(step)
+        self.optimizer.zero_grad(set_to_none=True)
+        outputs = self._model(ray_bundle)
+        metrics_dict = self._model.get_metrics_dict(outputs, batch)
+        loss_dict = self._model.get_loss_dict(outputs, batch, metrics_dict)
+        sum(loss_dict.values()).backward()
+        self.optimizer.step()
+        return outputs, loss_dict, metrics_dict
+
+    @torch.no_grad()
+    def get_eval_loss_dict(self, step: int):
+        self.eval()
+        ray_bundle, batch = self.datamanager.next_eval(step)
+        outputs = self._model(ray_bundle)
+        metrics_dict = self._model.get_metrics_dict(outputs, batch)
+        loss_dict = self._model.get_loss_dict(outputs, batch, metrics_dict)
+        self.train()
+        return outputs, loss_dict, metrics_dict
+
+    @torch.no_grad()
+    def get_eval_image_metrics_and_images(self, step: int):
+        self.eval()
+        camera_ray_bundle, batch = self.datamanager.next_eval_image(step)
+        outputs = self._model.get_outputs_for_camera_ray_bundle(camera_ray_bundle)
+        metrics_dict, images_dict = self._model.get_image_metrics_and_images(outputs, batch)
+        metrics_dict["num_rays"] = int(camera_ray_bundle.origins.shape[0] * camera_ray_bundle.origins.shape[1])
+        self.train()
+        return metrics_dict, images_dict
 
 
 def make_nerfstudio_trainer_config(defaults):  # pragma: no cover - needs nerfstudio
