@@ -165,3 +165,50 @@ def test_renderer_api_against_reference_goldens(golden_dir):
     assert float((vd.grad.cpu() - gv).abs().max()) < 1e-5 and float((wd.grad.cpu() - gw).abs().max()) < 1e-5
     dense = r(vd.detach()[:, :9], wd.detach()[:9])  # no ray_indices: one ray, sum over dim -2
     assert float((dense.cpu() - (vals[0, :9] * wts[:9]).sum(0).detach()).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("method,specular", [("rgb+spectral", True), ("spectral", False)])
+def test_direct_training_step_equals_the_autograd_path(method, specular, monkeypatch):
+    """UMHSPipeline.train_iteration runs the launch sequence without an autograd graph; the autograd Functions stay the general
+    path.  Same kernels, same order: losses, outputs, gradient and parameters after 3 steps must agree."""
+    from umhsnerf import ops
+    from umhsnerf._ns_compat import packed_ray_samples
+    from umhsnerf.umhs_model import BandOutputs, UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    R, S, B, Cn = 512, 24, 31, 5
+    b = T.synthetic_batch(R, S, B, seed=9)
+    b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+    rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])
+    pinfo = ops.pack_info(b["ray_indices"], R)
+    res = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("UMHS_DIRECT_STEP", direct)
+        torch.manual_seed(4)
+        cfg = UMHSConfig(method=method, pred_specular=specular, temperature=0.5, per_band_outputs=True)
+        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=8)
+        with torch.no_grad():
+            tab = pipe.model.field.layout.view(pipe.model.field.flat.data, "mlp_base.encoder.hash_table")
+            tab.mul_(300.0)
+            batch = {"image": pipe.model.converter(b["gt_spectral"]), "hs_image": b["gt_spectral"]}
+        assert pipe.model.direct_step_supported(batch) == (direct == "1")
+        out, loss = pipe.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
+        g1 = pipe.model.field.flat.grad.clone()
+        for _ in range(2):
+            out, loss = pipe.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
+        res[direct] = (out, {k: float(v) for k, v in loss.items()}, g1, pipe.model.field.flat.detach().clone())
+    (o1, l1, g1, p1), (o0, l0, g0, p0) = res["1"], res["0"]
+    assert isinstance(o1, BandOutputs) and l1.keys() == l0.keys()
+    for k in l0:
+        assert abs(l1[k] - l0[k]) <= 1e-6 * abs(l0[k])
+    assert float(g0.abs().max()) > 0
+    torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-9 + 1e-6 * float(g0.abs().max()))
+    torch.testing.assert_close(p1, p0, rtol=0, atol=2e-3)  # Adam turns last-bit gradient differences into +-lr steps on ~zero entries
+    assert float((p1 - p0).abs().mean()) < 1e-6
+    for k in o0:  # every key of the eager dict is reachable (per-band ones lazily), with the same values
+        assert k in o1
+        torch.testing.assert_close(o1[k].float(), o0[k].detach().float(), rtol=1e-5, atol=1e-6)
+    assert "wv_31" not in o1 and "foo" not in o1
+    with pytest.raises(KeyError):
+        o1["residual_99"]
+    assert set(o1.materialize().keys()) == set(o0.keys())

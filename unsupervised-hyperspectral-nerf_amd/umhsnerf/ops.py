@@ -267,10 +267,10 @@ def spec2rgb_fwd(spec_t, M):
     return rgb
 
 
-def spec2rgb_bwd(spec_t, M, d_rgb):
+def spec2rgb_bwd(spec_t, M, d_rgb, accumulate_into=None):
     R, B = spec_t.shape
-    d_spec = torch.empty_like(spec_t)
-    _hip.check(_hip.lib().umhs_spec2rgb_bwd(ptr(spec_t), ptr(M), ptr(d_rgb), R, B, ptr(d_spec), 0, _hip.stream()),
+    d_spec = torch.empty_like(spec_t) if accumulate_into is None else accumulate_into
+    _hip.check(_hip.lib().umhs_spec2rgb_bwd(ptr(spec_t), ptr(M), ptr(d_rgb), R, B, ptr(d_spec), int(accumulate_into is not None), _hip.stream()),
                "umhs_spec2rgb_bwd")
     return d_spec
 
@@ -338,6 +338,61 @@ def ssim(a, b, data_range=None):
     return part.sum() / float((h - 10) * (w - 10) * k)
 
 
+def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb):
+    """Backward of the field (field_bwd + hash-grid scatter) into the flat gradient.  With a gradient sink that owns the next
+    backward the buffer becomes ``param.grad`` directly, finished segments start their all-reduce, and None is returned;
+    otherwise the freshly written flat gradient is returned (autograd accumulates it)."""
+    L = spec.layout
+    sink = spec.grad_sink
+    own = sink is not None and sink.param is flat and sink.owns_next_backward()
+    # the 64 MiB table segment is fully written by hashgrid_bwd(overwrite=True): no memset of the flat gradient
+    d_flat = sink.begin() if own else torch.empty_like(flat)
+    tail = L.offset("mlp_base.mlp.layers.0.weight")
+    d_flat[tail:].zero_()  # MLP / endmember segments (+ alignment padding)
+    d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat)
+    if own:
+        sink.segment_done(d_flat[tail:])
+    table = L.view(d_flat, "mlp_base.encoder.hash_table")
+    T = 1 << L.log2_hashmap_size
+    for l0, cnt in (sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]):
+        hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
+        if own:
+            sink.segment_done(table[l0 * T:(l0 + cnt) * T])
+    if own:  # the buffer becomes param.grad directly (autograd gets None: nothing to accumulate or copy)
+        sink.commit()
+        return None
+    return d_flat
+
+
+def ray_epilogue_fwd(s, m, E, accumulation, depth, tminmax, colors, alpha: float):
+    R, B = s.shape
+    Cn = E.shape[0]
+    new = lambda *shp: torch.empty(shp, device=s.device, dtype=torch.float32)
+    rgb, dclip, probs, raw, pred = new(R, 3), new(R, 1), new(R, Cn), new(R), new(R, 3)
+    _hip.check(_hip.lib().umhs_ray_epilogue_fwd(ptr(s), ptr(m), ptr(E), ptr(accumulation), ptr(depth), ptr(tminmax), ptr(colors), R, B, Cn,
+                                                float(alpha), ptr(rgb), ptr(dclip), ptr(probs), ptr(raw), ptr(pred), _hip.stream()),
+               "umhs_ray_epilogue_fwd")
+    return rgb, dclip, probs, raw, pred
+
+
+def loss_fwd(s, g, r, a, bg, gr, w_spec: float, w_rgb: float):
+    R, B = s.shape
+    losses = torch.empty(2, device=s.device, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_loss_fwd(ptr(s), ptr(g), ptr(r), ptr(a), ptr(bg), ptr(gr), R, B, float(w_spec), float(w_rgb),
+                                        ptr(losses), _hip.stream()), "umhs_loss_fwd")
+    return losses
+
+
+def loss_bwd(s, g, r, a, bg, gr, w_spec: float, w_rgb: float, grad_losses):
+    R, B = s.shape
+    d_spec = torch.empty_like(s)
+    d_rgb = torch.empty_like(r) if r is not None else None
+    d_acc = torch.empty_like(a) if r is not None else None
+    _hip.check(_hip.lib().umhs_loss_bwd(ptr(s), ptr(g), ptr(r), ptr(a), ptr(bg), ptr(gr), R, B, float(w_spec), float(w_rgb), ptr(grad_losses),
+                                        ptr(d_spec), ptr(d_rgb), ptr(d_acc), _hip.stream()), "umhs_loss_bwd")
+    return d_spec, d_rgb, d_acc
+
+
 # --------------------------------------------------------------------------------------------- #
 # autograd glue
 # --------------------------------------------------------------------------------------------- #
@@ -375,24 +430,7 @@ class FieldFn(torch.autograd.Function):
         d_sigma = _hip.f32c(d_sigma).view(-1) if d_sigma is not None else zeros(n)
         d_spectral = _hip.f32c(d_spectral) if d_spectral is not None else zeros(n, L.wavelengths)
         d_emb = _hip.f32c(d_emb) if d_emb is not None else None
-        sink = spec.grad_sink
-        own = sink is not None and sink.param is flat and sink.owns_next_backward()
-        # the 64 MiB table segment is fully written by hashgrid_bwd(overwrite=True): no memset of the flat gradient
-        d_flat = sink.begin() if own else torch.empty_like(flat)
-        tail = L.offset("mlp_base.mlp.layers.0.weight")
-        d_flat[tail:].zero_()  # MLP / endmember segments (+ alignment padding)
-        d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat)
-        if own:
-            sink.segment_done(d_flat[tail:])
-        table = L.view(d_flat, "mlp_base.encoder.hash_table")
-        T = 1 << L.log2_hashmap_size
-        for l0, cnt in (sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]):
-            hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
-            if own:
-                sink.segment_done(table[l0 * T:(l0 + cnt) * T])
-        if own:  # the buffer becomes param.grad directly (autograd gets None: nothing to accumulate or copy)
-            sink.commit()
-            return None, None, None, None, None, None
+        d_flat = field_backward_into(spec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb)
         return d_flat, None, None, None, None, None
 
 
@@ -506,14 +544,8 @@ class RayEpilogueFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         s, m = _hip.f32c(spectral), _hip.f32c(M)
         E = _hip.f32c(endmembers)
-        R, B = s.shape
-        Cn = E.shape[0]
-        new = lambda *shp: torch.empty(shp, device=s.device, dtype=torch.float32)
-        rgb, dclip, probs, raw, pred = new(R, 3), new(R, 1), new(R, Cn), new(R), new(R, 3)
-        _hip.check(_hip.lib().umhs_ray_epilogue_fwd(ptr(s), ptr(m), ptr(E), ptr(_hip.f32c(accumulation).view(-1)),
-                                                    ptr(_hip.f32c(depth).view(-1)), ptr(tminmax), ptr(_hip.f32c(colors)), R, B, Cn,
-                                                    float(alpha), ptr(rgb), ptr(dclip), ptr(probs), ptr(raw), ptr(pred),
-                                                    _hip.stream()), "umhs_ray_epilogue_fwd")
+        rgb, dclip, probs, raw, pred = ray_epilogue_fwd(s, m, E, _hip.f32c(accumulation).view(-1), _hip.f32c(depth).view(-1), tminmax,
+                                                        _hip.f32c(colors), alpha)
         ctx.save_for_backward(s, m)
         ctx.mark_non_differentiable(dclip, probs, raw, pred)
         return rgb, dclip, probs, raw, pred
@@ -535,10 +567,7 @@ class LossFn(torch.autograd.Function):
         c = lambda t: _hip.f32c(t) if t is not None else None
         s, g, r, bg, gr = c(spectral), c(gt_spectral), c(rgb), c(background), c(gt_rgb)
         a = c(accumulation).view(-1) if accumulation is not None else None
-        R, B = s.shape
-        losses = torch.empty(2, device=s.device, dtype=torch.float32)
-        _hip.check(_hip.lib().umhs_loss_fwd(ptr(s), ptr(g), ptr(r), ptr(a), ptr(bg), ptr(gr), R, B, float(w_spec), float(w_rgb),
-                                            ptr(losses), _hip.stream()), "umhs_loss_fwd")
+        losses = loss_fwd(s, g, r, a, bg, gr, w_spec, w_rgb)
         ctx.save_for_backward(*[t for t in (s, g, r, a, bg, gr) if t is not None])
         ctx.has = [t is not None for t in (s, g, r, a, bg, gr)]
         ctx.w = (float(w_spec), float(w_rgb))
@@ -552,9 +581,5 @@ class LossFn(torch.autograd.Function):
         R, B = s.shape
         zero = lambda: torch.zeros((), device=s.device, dtype=torch.float32)
         gl = torch.stack([g_spec if g_spec is not None else zero(), g_rgb if g_rgb is not None else zero()]).to(torch.float32)
-        d_spec = torch.empty_like(s)
-        d_rgb = torch.empty_like(r) if r is not None else None
-        d_acc = torch.empty_like(a) if r is not None else None
-        _hip.check(_hip.lib().umhs_loss_bwd(ptr(s), ptr(g), ptr(r), ptr(a), ptr(bg), ptr(gr), R, B, ctx.w[0], ctx.w[1], ptr(gl),
-                                            ptr(d_spec), ptr(d_rgb), ptr(d_acc), _hip.stream()), "umhs_loss_bwd")
+        d_spec, d_rgb, d_acc = loss_bwd(s, g, r, a, bg, gr, ctx.w[0], ctx.w[1], gl)
         return d_spec, None, d_rgb, (d_acc.view(ctx.acc_shape) if d_acc is not None else None), None, None, None, None

@@ -38,10 +38,12 @@ class UMHSPipeline(torch.nn.Module):
 
     def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None):
         self.optimizer.zero_grad(set_to_none=True)
-        outputs = self._model.get_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
-        loss_dict = self._model.get_loss_dict(outputs, batch)
-        loss = sum(loss_dict.values())
-        loss.backward()
+        if self._model.direct_step_supported(batch):  # straight launch sequence, no autograd graph
+            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, num_rays, batch, packed_info)
+        else:
+            outputs = self._model.get_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
+            loss_dict = self._model.get_loss_dict(outputs, batch)
+            sum(loss_dict.values()).backward()
         self.optimizer.step()
         return outputs, loss_dict
 
@@ -52,10 +54,15 @@ class UMHSPipeline(torch.nn.Module):
         self._model.update_occupancy_grid(step)
         ray_bundle, batch = self.datamanager.next_train(step)
         self.optimizer.zero_grad(set_to_none=True)
-        outputs = self._model(ray_bundle)
-        metrics_dict = self._model.get_metrics_dict(outputs, batch)
-        loss_dict = self._model.get_loss_dict(outputs, batch, metrics_dict)
-        sum(loss_dict.values()).backward()
+        if self._model.direct_step_supported(batch):
+            ray_samples, ray_indices = self._model.sample(ray_bundle)
+            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch)
+            metrics_dict = self._model.get_metrics_dict(outputs, batch)
+        else:
+            outputs = self._model(ray_bundle)
+            metrics_dict = self._model.get_metrics_dict(outputs, batch)
+            loss_dict = self._model.get_loss_dict(outputs, batch, metrics_dict)
+            sum(loss_dict.values()).backward()
         self.optimizer.step()
         return outputs, loss_dict, metrics_dict
 
