@@ -22,7 +22,13 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// timing-only ablation builds (tools/ablate_fwd.sh) define UMHS_ABL_*; never defined in the shipped library
+#ifdef UMHS_ABL_NO_MFMA
+__device__ __forceinline__ v4f mfma_stub(float a, float b, v4f c) { c[0] += a * b; return c; }
+#define MFMA(a, b, c) mfma_stub((a), (b), (c))
+#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
 #ifdef UMHS_ABL_NO_SYNC  // timing-only ablation build (tools/ablate_field.sh); never defined in the shipped library
 #define BSYNC()
 #else
@@ -113,33 +119,68 @@ __device__ __forceinline__ void load_fwd_image(float* lds, const PackDesc& pd, c
 // INIT: 0 = accumulate into acc, 1 = start from zero, 2 = start from the bias (compile-time: a runtime `if (bias)` is a
 // real branch -- LDS address 0 is valid -- and every branch ends a scheduling region, pinning the operand loads to
 // their gemm instead of letting them be hoisted over the previous one)
-template <int OT, int KS, int NT, int INIT>
+// Software pipeline: the A fragments (one ds_read_b128 = 4 k-steps of one output tile) are consumed in bundles of G; the
+// next bundle's reads are issued BEFORE the current bundle's MFMAs (the compiler on its own emits read -> s_waitcnt
+// lgkmcnt(0) -> MFMAs, exposing the LDS latency once per fragment), and inside a bundle the MFMAs alternate between
+// >= 2 accumulators so that none waits on its predecessor (32-cycle issue vs 40-cycle dependent issue).
+// SWAP: operands exchanged -> the TRANSPOSED tile D[sample 4q+r][feature lane&15] (the same pack image serves: lane l holds
+// W[out = l&15][in = l>>4] either way); used for the last layers so that output rows are written 16 consecutive floats
+// per quarter-wave instead of one float per row.
+template <int OT, int KS, int NT, int INIT, bool SWAP = false>
 __device__ __forceinline__ void gemm_pack(v4f (&acc)[NT][OT], const float (&b)[NT][KS], const float* __restrict__ w,
                                           const float* __restrict__ bias, int lane) {
   constexpr int KS4 = (KS + 3) / 4;
+  constexpr int NF = KS4 * OT;                 // fragment f = s4 * OT + t
+  constexpr bool SPLIT = (OT == 1 && NT == 1 && KS4 >= 2);  // one tile, one column block: split K over two accumulators
+  constexpr int G = (NT >= 2) ? 1 : 2;
+  constexpr int NBUN = (NF + G - 1) / G;
   if (INIT != 0) {
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
       v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (INIT == 2) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+      if (INIT == 2 && !SWAP) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+      if (INIT == 2 && SWAP) {
+        const float bj = bias[16 * t + (lane & 15)];
+        bv = v4f{bj, bj, bj, bj};
+      }
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) acc[ct][t] = bv;
     }
   }
+  v4f acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+  v4f a[2][G];
 #pragma unroll
-  for (int s4 = 0; s4 < KS4; ++s4) {
+  for (int g = 0; g < G; ++g)
+    if (g < NF) a[0][g] = *reinterpret_cast<const v4f*>(w + (((g % OT) * KS4 + g / OT) * 64 + lane) * 4);
 #pragma unroll
-    for (int t = 0; t < OT; ++t) {
-      const v4f a = *reinterpret_cast<const v4f*>(w + ((t * KS4 + s4) * 64 + lane) * 4);
+  for (int bun = 0; bun < NBUN; ++bun) {
+    if (bun + 1 < NBUN) {
 #pragma unroll
-      for (int ss = 0; ss < 4; ++ss) {
-        if (s4 * 4 + ss < KS) {
+      for (int g = 0; g < G; ++g) {
+        const int f = (bun + 1) * G + g;
+        if (f < NF) a[(bun + 1) & 1][g] = *reinterpret_cast<const v4f*>(w + (((f % OT) * KS4 + f / OT) * 64 + lane) * 4);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // everything but LDS reads may move across: the prefetch stays ahead
 #pragma unroll
-          for (int ct = 0; ct < NT; ++ct) acc[ct][t] = MFMA(a[ss], b[ct][s4 * 4 + ss], acc[ct][t]);
+    for (int ss = 0; ss < 4; ++ss) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int f = bun * G + g, s4 = f / OT, t = f % OT;
+        if (f < NF && s4 * 4 + ss < KS) {
+          if (SPLIT && (f & 1)) {
+            acc2 = SWAP ? MFMA(b[0][s4 * 4 + ss], a[bun & 1][g][ss], acc2) : MFMA(a[bun & 1][g][ss], b[0][s4 * 4 + ss], acc2);
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+              acc[ct][t] = SWAP ? MFMA(b[ct][s4 * 4 + ss], a[bun & 1][g][ss], acc[ct][t])
+                                : MFMA(a[bun & 1][g][ss], b[ct][s4 * 4 + ss], acc[ct][t]);
+          }
         }
       }
     }
   }
+  if (SPLIT) acc[0][0] += acc2;
 }
 
 // relu as ONE integer max on the bit pattern (negative floats are negative ints; +NaN stays NaN like torch.relu);
@@ -190,13 +231,20 @@ struct FieldIO {
 
 // NeRF positional encoding slots of quarter q (3 per lane) and SH slots (4 per lane)
 __device__ __forceinline__ void pe_slots(float (&pe)[3], float x, float y, float z, int q) {
-  const float TWO_PI = 6.2831855f, HALF_PI = 1.5707964f;
+#ifdef UMHS_ABL_NO_TRIG
+  pe[0] = x * 0.5f, pe[1] = y * 0.25f, pe[2] = z + q;
+  return;
+#endif
   const bool odd = q & 1;
   const float c0 = odd ? y : x, c1 = odd ? z : x, c2 = odd ? z : y;
   const float f0 = odd ? 2.0f : 1.0f, f1 = odd ? 1.0f : 2.0f, f2 = odd ? 2.0f : 1.0f;
-  float a0 = (TWO_PI * c0) * f0, a1 = (TWO_PI * c1) * f1, a2 = (TWO_PI * c2) * f2;
-  if (q >= 2) a0 += HALF_PI, a1 += HALF_PI, a2 += HALF_PI;
-  pe[0] = sinf(a0), pe[1] = sinf(a1), pe[2] = sinf(a2);
+  // sin(2 pi x f [+ pi/2]) as v_sin_f32 of the phase in revolutions (x f [+ 1/4], reduced by v_fract): ~1e-6 absolute, an
+  // order of magnitude inside the parity budget; the libm sinf it replaces was ~6 % of the forward kernel (range reduction)
+  float r0 = c0 * f0, r1 = c1 * f1, r2 = c2 * f2;
+  if (q >= 2) r0 += 0.25f, r1 += 0.25f, r2 += 0.25f;
+  pe[0] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r0));
+  pe[1] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r1));
+  pe[2] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r2));
 }
 
 __device__ __forceinline__ void sh_slots(float (&sh)[4], float dx, float dy, float dz, int q) {
@@ -380,18 +428,25 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
     // ---- per 16-band tile: mixing (K = classes) and specular (K = 16 hidden) -------------------------
 #pragma unroll 1  // a runtime loop: left alone hipcc unrolls the (small) no-specular body 8x and spills 200+ registers
     for (int t = 0; t < io.TB; ++t) {
+      // transposed tiles: rows = samples 4q+r of the column tile, lanes&15 = bands 16t..16t+15 -> 64-byte row segments
       v4f sp[NT][1], sc[NT][1];
-      gemm_pack<1, 4, NT, 1>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
-      if (SPEC) gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+      gemm_pack<1, 4, NT, 1, true>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
+      if (SPEC) gemm_pack<1, 4, NT, 2, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+      const int b = 16 * t + j;
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
+        const int64_t nb = tile * TILE + wave * (16 * NT) + ct * 16 + 4 * q;  // first sample of this lane's 4 rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int b = 16 * t + 4 * q + r;
-          if (ok[ct] && b < io.B) {
+          const float s1r = SPEC ? __shfl(hs.s1[ct], 4 * q + r, 64) : 0.0f;  // s1 lives on lane&15 = sample
+#ifdef UMHS_ABL_NO_STORE
+          if (nb + r < io.n && b < io.B && sp[ct][0][r] == 1.2345e30f) {
+#else
+          if (nb + r < io.n && b < io.B) {
+#endif
             const float spec = sp[ct][0][r];
-            const float spl = SPEC ? hs.s1[ct] * sigmoidf_(sc[ct][0][r]) : 0.0f;
-            const int64_t o = nn[ct] * io.B + b;
+            const float spl = SPEC ? s1r * sigmoidf_(sc[ct][0][r]) : 0.0f;
+            const int64_t o = (nb + r) * io.B + b;
             io.spectral[o] = SPEC ? spec + spl : spec;
             if (SPEC && io.spectral2) io.spectral2[o] = spec;
             if (SPEC && io.specular) io.specular[o] = spl;
@@ -1048,13 +1103,15 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
     UMHS_CHECK_LAUNCH();
     image = img;
   }
-  const int blocks_per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
+  static const int one_per_cu = getenv("UMHS_FWD_ONE_PER_CU") ? atoi(getenv("UMHS_FWD_ONE_PER_CU")) : 0;  // experiment
+  const int blocks_per_cu = (lds_bytes <= 78 * 1024 && !one_per_cu) ? 2 : 1;
   const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
+  const size_t lds_launch = one_per_cu ? (lds_bytes > 100 * 1024 ? lds_bytes : 100 * 1024) : lds_bytes;
 #define LAUNCH_FWD(S, D, NT_, W_)                                                                               \
   do {                                                                                                          \
-    rc = set_lds(field_fwd_kernel<S, D, NT_, W_>, lds_bytes);                                                   \
+    rc = set_lds(field_fwd_kernel<S, D, NT_, W_>, lds_launch);                                                   \
     if (rc) return rc;                                                                                          \
-    hipLaunchKernelGGL((field_fwd_kernel<S, D, NT_, W_>), dim3(grid), dim3(64 * W_), lds_bytes, umhs_s(stream), \
+    hipLaunchKernelGGL((field_fwd_kernel<S, D, NT_, W_>), dim3(grid), dim3(64 * W_), lds_launch, umhs_s(stream), \
                        io, pd, image);                                                                          \
   } while (0)
   if (dens)

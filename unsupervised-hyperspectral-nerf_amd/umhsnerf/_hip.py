@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libumhs_hip.so")
+LIB_PATH = os.environ.get("UMHS_LIB_PATH") or os.path.join(_HERE, "libumhs_hip.so")  # override: A/B builds of tools/ab_lib.sh
 MAX_STREAMS = 4
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
