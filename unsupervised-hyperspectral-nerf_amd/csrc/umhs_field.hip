@@ -537,13 +537,30 @@ __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restri
   // row 4ks+q is rotated by swz = 4*(((2ks)&3) + (q>>1)) = 8*(ks&1) + 4*(q>>1)
   const float* __restrict__ px = stX + q * FSx + 16 * ti + j + 4 * (q >> 1);
   const float* __restrict__ pz = stZ + q * FSz + 16 * to0 + j + 4 * (q >> 1);
-#pragma unroll 4
-  for (int ks = 0; ks < 4 * WAVES; ++ks) {
-    const float b = px[4 * ks * FSx + 8 * (ks & 1)];
+  // Operands of U k-steps are read together and one batch ahead of the MFMAs that consume them (left to itself hipcc emits
+  // ds_read -> s_waitcnt lgkmcnt(0) -> MFMA per k-step: the LDS latency, ~3x the MFMA's own 32 cycles, on every step).
+  constexpr int U = 4, NB = (4 * WAVES) / U;
+  float bx[2][U], az[2][U][NACC];
+  auto fetch = [&](int batch, int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int idx = 0; idx < NACC; ++idx) {
-      if (to0 + idx * tstep < TO) acc[idx] = MFMA(pz[4 * ks * FSz + 8 * (ks & 1) + 16 * idx * tstep], b, acc[idx]);
+    for (int u = 0; u < U; ++u) {
+      const int ks = batch * U + u;
+      bx[slot][u] = px[4 * ks * FSx + 8 * (ks & 1)];
+#pragma unroll
+      for (int idx = 0; idx < NACC; ++idx)
+        az[slot][u][idx] = (to0 + idx * tstep < TO) ? pz[4 * ks * FSz + 8 * (ks & 1) + 16 * idx * tstep] : 0.0f;
     }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int batch = 0; batch < NB; ++batch) {
+    if (batch + 1 < NB) fetch(batch + 1, (batch + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int idx = 0; idx < NACC; ++idx)
+        if (to0 + idx * tstep < TO) acc[idx] = MFMA(az[batch & 1][u][idx], bx[batch & 1][u], acc[idx]);
   }
 }
 
@@ -715,20 +732,40 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
       dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
     }
     {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: its rows are samples)
+      // Branch-free clamped addresses, U k-steps of loads in flight, one batch ahead of their MFMAs: a conditional load per
+      // MFMA made hipcc wait for global memory (s_waitcnt vmcnt(0)) 32 times per round.
       const float* __restrict__ pm = stXm + q * 48 + j + 4 * (q >> 1);
-#pragma unroll 8
-      for (int ks = 0; ks < 4 * WAVES; ++ks) {
-        const int64_t ns = n0 + 4 * ks + q;
-        const float bm = pm[4 * ks * 48 + 8 * (ks & 1)];
+      constexpr int U = 8, NBAT = (4 * WAVES) / U;
+      float ga[2][U][NA], gb[2][U];
+      int bcol[NA];
+      bool bok[NA];
 #pragma unroll
-        for (int idx = 0; idx < NA; ++idx) {
-          const int to = wave + idx * WAVES;
-          if (to < TB) {
-            const int b = 16 * to + j;
-            const float a = (ns < io.n && b < B) ? io.d_spectral[ns * B + b] : 0.0f;
-            aMX[idx] = MFMA(a, bm, aMX[idx]);
-          }
+      for (int idx = 0; idx < NA; ++idx) {
+        const int to = wave + idx * WAVES, b = 16 * to + j;
+        bok[idx] = to < TB && b < B;
+        bcol[idx] = bok[idx] ? b : 0;
+      }
+      auto fetch = [&](int batch, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ks = batch * U + u;
+          const int64_t ns = n0 + 4 * ks + q;
+          const int64_t nsc = ns < io.n ? ns : io.n - 1;
+          gb[slot][u] = ns < io.n ? pm[4 * ks * 48 + 8 * (ks & 1)] : 0.0f;  // rows past the end carry zero weight
+#pragma unroll
+          for (int idx = 0; idx < NA; ++idx) ga[slot][u][idx] = io.d_spectral[nsc * B + bcol[idx]];
         }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int batch = 0; batch < NBAT; ++batch) {
+        if (batch + 1 < NBAT) fetch(batch + 1, (batch + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0x7ff & ~0x1b0);  // loads (VMEM / LDS reads) keep their place
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int idx = 0; idx < NA; ++idx)
+            if (wave + idx * WAVES < TB) aMX[idx] = MFMA(bok[idx] ? ga[batch & 1][u][idx] : 0.0f, gb[batch & 1][u], aMX[idx]);
       }
     }
     // =================== phase B: heads ===========================================================
