@@ -218,6 +218,18 @@ int umhs_loss_bwd(const float* spectral, const float* gt_spectral, const float* 
                   const float* background, const float* gt_rgb, int64_t n_rays, int n_bands, float w_spectral, float w_rgb,
                   const float* grad_losses2, float* d_spectral, float* d_rgb, float* d_accumulation, umhs_stream_t stream);
 
+/* umhs_ray_train_tail: the per-ray tail of a TRAINING step in one launch = umhs_ray_epilogue_fwd + umhs_loss_fwd +      */
+/*   umhs_loss_bwd with unit upstream gradients + umhs_spec2rgb_bwd accumulated into d_spectral (umhs_model.py:254-313,   */
+/*   358-370 and their autograd).  rgb_loss = 0: method "spectral" (no rgb term, d_accumulation unused).  scratch:        */
+/*   umhs_ray_train_tail_scratch_bytes() bytes, ZERO before the first call (the kernel leaves it zeroed again).          */
+size_t umhs_ray_train_tail_scratch_bytes(void);
+int umhs_ray_train_tail(const float* spectral, const float* M, const float* endmembers, const float* accumulation,
+                        const float* depth, const float* tmid_minmax2, const float* class_colors, const float* gt_spectral,
+                        const float* gt_rgb, const float* background, int64_t n_rays, int n_bands, int n_classes, float alpha,
+                        float w_spectral, float w_rgb, int rgb_loss, float* rgb, float* depth_clipped, float* seg_probs,
+                        float* seg_raw, float* seg_pred, float* losses2, float* d_spectral, float* d_accumulation,
+                        void* scratch, size_t scratch_bytes, umhs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* occupancy-grid ray marcher.  Replaces nerfacc.OccGridEstimator.sampling (traverse_grids +        */
 /* render_visibility_from_density, CUDA only) behind nerfstudio's VolumetricSampler, umhs_model.py:201-209,229-237. */

@@ -504,3 +504,44 @@ def test_model_train_iteration_matches_oracle_step():
     sd_new = pipe.model.field.state_dict()
     for k, v in p.reference_state_dict().items():
         assert_close(f"param after step: {k}", sd_new[k], v, 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,B,C,both", [(4096, 31, 6, True), (1001, 141, 4, True), (37, 3, 9, False), (5000, 128, 16, True)])
+def test_fused_training_tail_equals_the_separate_kernels(R, B, C, both):
+    """umhs_ray_train_tail == ray_epilogue_fwd + loss_fwd + loss_bwd(unit upstream) + spec2rgb_bwd(accumulate)."""
+    from umhsnerf import ops
+
+    g = torch.Generator().manual_seed(R + B)
+    dev = "cuda:0"
+    rnd = lambda *s: torch.rand(*s, generator=g).to(dev)
+    spec, gt = rnd(R, B) * 1.2 - 0.1, rnd(R, B)
+    M = (torch.rand(B, 3, generator=g) / B * 2.2).to(dev)  # some rgb values beyond 1 (clamp gradient) and near the gamma knee
+    spec[:5] *= 1e-3
+    E, acc, depth = rnd(C, B), rnd(R), rnd(R) * 5
+    colors, gt_rgb, bg = rnd(C, 3), rnd(R, 3), rnd(R, 3)
+    t0 = rnd(777)
+    mm = ops.tmid_minmax(t0 * 4, t0 * 4 + 0.1)
+    w = (5.0, 0.7) if both else (1.0, 0.0)
+    rgb0, dclip0, probs0, raw0, pred0 = ops.ray_epilogue_fwd(spec, M, E, acc, depth, mm, colors, 0.2)
+    largs = (spec, gt, rgb0, acc, bg, gt_rgb) if both else (spec, gt, None, None, None, None)
+    losses0 = ops.loss_fwd(*largs, *w)
+    d_spec0, d_rgb0, d_acc0 = ops.loss_bwd(*largs, *w, torch.ones(2, device=dev))
+    if both:
+        ops.spec2rgb_bwd(spec, M, d_rgb0, accumulate_into=d_spec0)
+    for rep in range(3):  # the arrival counter resets itself: repeated calls give the same sums
+        rgb, dclip, probs, raw, pred, losses, d_spec, d_acc = ops.ray_train_tail(spec, M, E, acc, depth, mm, colors, gt, gt_rgb if both else None,
+                                                                                 bg if both else None, 0.2, w[0], w[1], both)
+        torch.testing.assert_close(rgb, rgb0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(dclip, dclip0, rtol=0, atol=0)
+        torch.testing.assert_close(probs, probs0, rtol=1e-5, atol=1e-6)
+        assert float((raw != raw0).float().mean()) < 2e-3  # argmax ties under a different summation order
+        torch.testing.assert_close(losses[: 2 if both else 1], losses0[: 2 if both else 1], rtol=2e-5, atol=0)
+        torch.testing.assert_close(d_spec, d_spec0, rtol=2e-5, atol=1e-9)
+        if both:
+            torch.testing.assert_close(d_acc, d_acc0, rtol=1e-5, atol=1e-10)
+        else:
+            assert d_acc is None
+        if rep:
+            assert torch.equal(losses, first)
+        first = losses.clone()

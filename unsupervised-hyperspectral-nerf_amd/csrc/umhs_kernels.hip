@@ -1135,6 +1135,165 @@ extern "C" int umhs_loss_bwd(const float* spectral, const float* gt_spectral, co
 }
 
 // =============================================================================================
+// Training tail of one step, fused: ray epilogue (rgb, depth clip, cluster probe) + both losses + their backward down to
+// d_spectral / d_accumulation (loss_bwd with unit upstream gradients + spec2rgb_bwd).  Four launches of per-ray work on
+// R = 4096 rays (16 workgroups each, ~60 us together, almost all of it latency) become one with 16 lanes per ray.
+// Loss sums: per-block partials, added in block order by the last block to finish (reproducible); the arrival counter
+// in `scratch` is left at zero again.
+// =============================================================================================
+__device__ __forceinline__ float red16(float v) {  // sum over the 16 lanes of a ray group
+  v += __shfl_xor(v, 1, 64), v += __shfl_xor(v, 2, 64), v += __shfl_xor(v, 4, 64);
+  return v + __shfl_xor(v, 8, 64);
+}
+
+struct TailArgs {
+  const float *spec, *M, *E, *acc, *depth, *colors, *gt_spec, *gt_rgb, *bg;
+  const uint32_t* mm;
+  int64_t n_rays;
+  int B, C, rgb_loss;
+  float alpha, w_spec, w_rgb;
+  float *rgb, *depth_out, *seg_probs, *seg_raw, *seg_pred, *losses, *d_spec, *d_acc;
+  float* partial;     // [gridDim.x][2]
+  uint32_t* counter;  // zero on entry, zero on exit
+};
+
+__global__ __launch_bounds__(256) void ray_train_tail_kernel(TailArgs a) {
+  __shared__ float ee_inv[16];
+  __shared__ float part[2][16];
+  __shared__ bool last;
+  const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4;
+  const int B = a.B, C = a.C;
+  if (tid < 16) {  // 1 / max(||E_c||, 1e-12): F.normalize of the endmember rows (clusterprobe.py:20-25), once per block
+    float ee = 0.0f;
+    if (tid < C)
+      for (int b = 0; b < B; ++b) ee += a.E[tid * B + b] * a.E[tid * B + b];
+    ee_inv[tid] = 1.0f / fmaxf(sqrtf(ee), 1e-12f);
+  }
+  __syncthreads();
+  const float cs = a.w_spec * 2.0f / ((float)a.n_rays * (float)B);
+  const float cr = a.w_rgb * 2.0f / ((float)a.n_rays * 3.0f);
+  const float tlo = ord2f(a.mm[0]), thi = ord2f(a.mm[1]);
+  float ls = 0.0f, lr = 0.0f;
+  for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < a.n_rays; r0 += (int64_t)gridDim.x * 16) {  // block-uniform trip count
+    const int64_t r = r0 + grp;
+    const bool live = r < a.n_rays;
+    const int64_t rc = live ? r : a.n_rays - 1;
+    const float* row = a.spec + rc * B;
+    const float* grow = a.gt_spec + rc * B;
+    float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, ss = 0.0f, dl = 0.0f;
+    float ip[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ip[c] = 0.0f;
+    for (int b = l; b < B; b += 16) {
+      const float s = row[b], d = s - grow[b];
+      x0 += s * a.M[3 * b], x1 += s * a.M[3 * b + 1], x2 += s * a.M[3 * b + 2];
+      ss += s * s, dl += d * d;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < C) ip[c] += s * a.E[c * B + b];
+    }
+    x0 = red16(x0), x1 = red16(x1), x2 = red16(x2), ss = red16(ss);
+    if (live) ls += dl;  // per-lane partial; reduced once at the end
+    const float x[3] = {x0, x1, x2};
+    float rgbv[3], g[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgbv[k] = fminf(fmaxf(srgb_gamma(x[k]), 0.0f), 1.0f);
+    const float accv = a.acc[rc];
+    if (a.rgb_loss) {
+      float ga = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float beta = a.bg ? a.bg[3 * rc + k] : 0.0f;
+        const float d = rgbv[k] + beta * (1.0f - accv) - a.gt_rgb[3 * rc + k];
+        if (live && l == 0) lr += d * d;
+        const float gk = cr * d;
+        ga -= gk * beta;
+        g[k] = gk * srgb_gamma_grad(x[k]);
+      }
+      if (live && l == 0 && a.d_acc) a.d_acc[r] = ga;
+    }
+    if (live) {
+      float* drow = a.d_spec + r * B;
+      for (int b = l; b < B; b += 16)
+        drow[b] = cs * (row[b] - grow[b]) + (g[0] * a.M[3 * b] + g[1] * a.M[3 * b + 1] + g[2] * a.M[3 * b + 2]);
+      if (l < 3 && a.rgb) a.rgb[3 * r + l] = rgbv[l];
+      if (l == 3 && a.depth_out) a.depth_out[r] = fminf(fmaxf(a.depth[r], tlo), thi);
+    }
+    if (a.seg_probs) {
+      const float inv_x = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+      float mx = -INFINITY, mine = 0.0f;
+      int arg = 0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (c < C) {
+          const float v = red16(ip[c]) * inv_x * ee_inv[c];
+          if (v > mx) mx = v, arg = c;
+          if (c == l) mine = v;
+        }
+      }
+      const float e = l < C ? expf(a.alpha * (mine - mx)) : 0.0f;
+      const float sum = red16(e);
+      if (live) {
+        if (l < C) a.seg_probs[r * C + l] = e / sum;
+        const float on = accv > 0.5f ? 1.0f : 0.0f;
+        if (l == 0 && a.seg_raw) a.seg_raw[r] = (float)arg * on;
+        if (l < 3 && a.seg_pred) a.seg_pred[3 * r + l] = a.colors[3 * arg + l] * on;
+      }
+    }
+  }
+  ls = red16(ls), lr = red16(lr);
+  if (l == 0) part[0][grp] = ls, part[1][grp] = lr;
+  __syncthreads();
+  if (tid == 0) {
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int i = 0; i < 16; ++i) s0 += part[0][i], s1 += part[1][i];
+    a.partial[2 * blockIdx.x] = s0, a.partial[2 * blockIdx.x + 1] = s1;
+    __threadfence();
+    last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && tid == 0) {
+    __threadfence();
+    float s0 = 0.0f, s1 = 0.0f;
+    for (unsigned i = 0; i < gridDim.x; ++i) s0 += a.partial[2 * i], s1 += a.partial[2 * i + 1];
+    a.losses[0] = s0 * (a.w_spec / ((float)a.n_rays * (float)B));
+    a.losses[1] = a.rgb_loss ? s1 * (a.w_rgb / ((float)a.n_rays * 3.0f)) : 0.0f;
+    *a.counter = 0u;
+  }
+}
+
+extern "C" size_t umhs_ray_train_tail_scratch_bytes(void) { return 256 * 2 * sizeof(float) + 64; }
+
+extern "C" int umhs_ray_train_tail(const float* spectral, const float* M, const float* endmembers, const float* accumulation,
+                                   const float* depth, const float* tmid_minmax2, const float* class_colors,
+                                   const float* gt_spectral, const float* gt_rgb, const float* background, int64_t n_rays,
+                                   int n_bands, int n_classes, float alpha, float w_spectral, float w_rgb, int rgb_loss,
+                                   float* rgb, float* depth_clipped, float* seg_probs, float* seg_raw, float* seg_pred,
+                                   float* losses2, float* d_spectral, float* d_accumulation, void* scratch,
+                                   size_t scratch_bytes, umhs_stream_t stream) {
+  if (n_rays < 1 || n_bands < 1 || !spectral || !M || !gt_spectral || !accumulation || !tmid_minmax2 || !losses2 || !d_spectral ||
+      !scratch)
+    return UMHS_ERR_ARG;
+  if (rgb_loss && (!gt_rgb || !d_accumulation)) return UMHS_ERR_ARG;
+  if (depth_clipped && !depth) return UMHS_ERR_ARG;
+  if (seg_probs && (!endmembers || n_classes < 1)) return UMHS_ERR_ARG;
+  if (seg_pred && (!class_colors || !seg_probs)) return UMHS_ERR_ARG;
+  if (n_classes > 16) return UMHS_ERR_UNSUPPORTED;
+  if (scratch_bytes < umhs_ray_train_tail_scratch_bytes() || ((uintptr_t)scratch & 3)) return UMHS_ERR_WORKSPACE;
+  TailArgs a;
+  a.spec = spectral, a.M = M, a.E = endmembers, a.acc = accumulation, a.depth = depth, a.colors = class_colors;
+  a.gt_spec = gt_spectral, a.gt_rgb = gt_rgb, a.bg = background, a.mm = reinterpret_cast<const uint32_t*>(tmid_minmax2);
+  a.n_rays = n_rays, a.B = n_bands, a.C = seg_probs ? n_classes : 0, a.rgb_loss = rgb_loss, a.alpha = alpha;
+  a.w_spec = w_spectral, a.w_rgb = w_rgb, a.rgb = rgb, a.depth_out = depth_clipped, a.seg_probs = seg_probs;
+  a.seg_raw = seg_raw, a.seg_pred = seg_pred, a.losses = losses2, a.d_spec = d_spectral, a.d_acc = d_accumulation;
+  a.counter = reinterpret_cast<uint32_t*>(scratch), a.partial = reinterpret_cast<float*>(scratch) + 16;
+  const int64_t blocks = (n_rays + 15) / 16;
+  hipLaunchKernelGGL(ray_train_tail_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, umhs_s(stream), a);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// =============================================================================================
 // Fused Adam over the flat "fields" parameter buffer (28 B/param of pure HBM streaming, float4 lanes)
 // =============================================================================================
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,

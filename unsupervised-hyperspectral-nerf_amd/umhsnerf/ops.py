@@ -375,6 +375,30 @@ def ray_epilogue_fwd(s, m, E, accumulation, depth, tminmax, colors, alpha: float
     return rgb, dclip, probs, raw, pred
 
 
+_tail_scratch: Dict[int, torch.Tensor] = {}
+
+
+def ray_train_tail(s, m, E, accumulation, depth, tminmax, colors, gt_spec, gt_rgb, bg, alpha: float, w_spec: float, w_rgb: float,
+                   rgb_loss: bool):
+    """Per-ray tail of a training step in one launch: ray_epilogue_fwd + loss_fwd + loss_bwd(unit upstream) + spec2rgb_bwd.
+    -> (rgb, depth_clipped, seg_probs, seg_raw, seg_pred, losses[2], d_spectral, d_accumulation | None)"""
+    R, B = s.shape
+    Cn = E.shape[0]
+    dev = s.device
+    new_ = lambda *shp: torch.empty(shp, device=dev, dtype=torch.float32)
+    rgb, dclip, probs, raw, pred = new_(R, 3), new_(R, 1), new_(R, Cn), new_(R), new_(R, 3)
+    losses, d_spec = new_(2), new_(R, B)
+    d_acc = new_(R) if rgb_loss else None
+    sc = _tail_scratch.get(dev.index or 0)
+    if sc is None:
+        sc = _tail_scratch[dev.index or 0] = torch.zeros(_hip.lib().umhs_ray_train_tail_scratch_bytes(), dtype=torch.uint8, device=dev)
+    _hip.check(_hip.lib().umhs_ray_train_tail(ptr(s), ptr(m), ptr(E), ptr(accumulation), ptr(depth), ptr(tminmax), ptr(colors), ptr(gt_spec),
+                                              ptr(gt_rgb), ptr(bg), R, B, Cn, float(alpha), float(w_spec), float(w_rgb), int(rgb_loss),
+                                              ptr(rgb), ptr(dclip), ptr(probs), ptr(raw), ptr(pred), ptr(losses), ptr(d_spec), ptr(d_acc),
+                                              ptr(sc), sc.numel(), _hip.stream()), "umhs_ray_train_tail")
+    return rgb, dclip, probs, raw, pred, losses, d_spec, d_acc
+
+
 def loss_fwd(s, g, r, a, bg, gr, w_spec: float, w_rgb: float):
     R, B = s.shape
     losses = torch.empty(2, device=s.device, dtype=torch.float32)

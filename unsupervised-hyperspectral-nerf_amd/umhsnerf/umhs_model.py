@@ -314,18 +314,14 @@ class UMHSModel(nn.Module):
         mm = ops.tmid_minmax(t0, t1)
         spectral = comp[0]
         M = _hip.f32c(self.converter.transform_matrix)
-        rgb, depth_c, seg_probs, seg_raw, seg_pred = ops.ray_epilogue_fwd(spectral, M, f.endmembers.detach(), acc, depth, mm,
-                                                                          _hip.f32c(self.class_colors), 0.2)
         hs, image = _hip.f32c(batch["hs_image"].to(self.device)), _hip.f32c(batch["image"].to(self.device))
         both = c.method == "rgb+spectral"
-        bg = torch.rand_like(rgb) if (both and self.background_color == "random") else None
+        bg = torch.rand_like(image) if (both and self.background_color == "random") else None
         w = (5.0, float(c.rgb_loss_weight)) if both else (1.0, 0.0)
-        largs = (spectral, hs, rgb, acc, bg, image) if both else (spectral, hs, None, None, None, None)
-        losses = ops.loss_fwd(*largs, *w)
-        # backward of (spectral_loss + rgb_loss)
-        d_spec, d_rgb, d_acc = ops.loss_bwd(*largs, *w, self._ones2())
-        if both:
-            ops.spec2rgb_bwd(spectral, M, d_rgb, accumulate_into=d_spec)
+        # ray epilogue + both losses + their backward down to d_spectral / d_accumulation: one launch
+        rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(
+            spectral, M, f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), hs, image if both else None, bg, 0.2,
+            w[0], w[1], both)
         d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
                                               bool(c.use_gradient_scaling))
         left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_values[0], None)
