@@ -1163,11 +1163,12 @@ __global__ __launch_bounds__(256) void ray_train_tail_kernel(TailArgs a) {
   __shared__ bool last;
   const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4;
   const int B = a.B, C = a.C;
-  if (tid < 16) {  // 1 / max(||E_c||, 1e-12): F.normalize of the endmember rows (clusterprobe.py:20-25), once per block
+  {  // 1 / max(||E_c||, 1e-12): F.normalize of the endmember rows (clusterprobe.py:20-25), once per block, 16 lanes per class
     float ee = 0.0f;
-    if (tid < C)
-      for (int b = 0; b < B; ++b) ee += a.E[tid * B + b] * a.E[tid * B + b];
-    ee_inv[tid] = 1.0f / fmaxf(sqrtf(ee), 1e-12f);
+    if (grp < C)
+      for (int b = l; b < B; b += 16) ee += a.E[grp * B + b] * a.E[grp * B + b];
+    ee = red16(ee);
+    if (l == 0) ee_inv[grp] = 1.0f / fmaxf(sqrtf(ee), 1e-12f);
   }
   __syncthreads();
   const float cs = a.w_spec * 2.0f / ((float)a.n_rays * (float)B);
@@ -1252,13 +1253,20 @@ __global__ __launch_bounds__(256) void ray_train_tail_kernel(TailArgs a) {
     last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
   }
   __syncthreads();
-  if (last && tid == 0) {
+  if (last) {  // block-wide tree over the (<= 256) partials: fixed order, no serial chain of L2 round trips
     __threadfence();
-    float s0 = 0.0f, s1 = 0.0f;
-    for (unsigned i = 0; i < gridDim.x; ++i) s0 += a.partial[2 * i], s1 += a.partial[2 * i + 1];
-    a.losses[0] = s0 * (a.w_spec / ((float)a.n_rays * (float)B));
-    a.losses[1] = a.rgb_loss ? s1 * (a.w_rgb / ((float)a.n_rays * 3.0f)) : 0.0f;
-    *a.counter = 0u;
+    float s0 = tid < gridDim.x ? a.partial[2 * tid] : 0.0f, s1 = tid < gridDim.x ? a.partial[2 * tid + 1] : 0.0f;
+    s0 = red16(s0), s1 = red16(s1);
+    __syncthreads();
+    if (l == 0) part[0][grp] = s0, part[1][grp] = s1;
+    __syncthreads();
+    if (tid == 0) {
+      s0 = 0.0f, s1 = 0.0f;
+      for (int i = 0; i < 16; ++i) s0 += part[0][i], s1 += part[1][i];
+      a.losses[0] = s0 * (a.w_spec / ((float)a.n_rays * (float)B));
+      a.losses[1] = a.rgb_loss ? s1 * (a.w_rgb / ((float)a.n_rays * 3.0f)) : 0.0f;
+      *a.counter = 0u;
+    }
   }
 }
 
