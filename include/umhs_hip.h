@@ -79,6 +79,14 @@ size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_table
 int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
                       const float* scalings, int64_t n, int level_begin, int n_levels, int log2_table_size,
                       float* d_table, int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
+/* The partitioned backward in two halves.  prepare: bucket histogram + scan, from the positions alone (may run on a side   */
+/* stream while the forward pass is in flight).  apply: scatter + per-bucket reduction of levels [level_begin, +n_levels),  */
+/* a sub-range of the prepared [ws_level_begin, +ws_n_levels) in the same workspace; each level once per prepare.          */
+int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalings, int64_t n, int level_begin, int n_levels, int log2_T,
+                              void* workspace, size_t workspace_bytes, umhs_stream_t stream);
+int umhs_hashgrid_bwd_apply(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l, const float* scalings,
+                            int64_t n, int level_begin, int n_levels, int ws_level_begin, int ws_n_levels, int log2_T,
+                            float* d_table, int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* R3-R9, R18: fused per-sample field.  Replaces mlp_base's MLP, NeRFEncoding, SHEncoding,      */
@@ -126,7 +134,10 @@ int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
                    int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
                    int64_t n, float* sigma, float* sigma_raw, float* emb, float* spectral, float* spectral2,
                    float* specular, float* abundances, void* workspace, size_t workspace_bytes,
-                   umhs_stream_t stream);
+                   int pack_ready, umhs_stream_t stream);
+/* builds the pack image ahead of time (parameters only): then pass pack_ready = 1 with the same workspace */
+int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
+                           size_t workspace_bytes, umhs_stream_t stream);
 
 /* Backward.  Recomputes the activations per tile; the only saved forward tensors are enc, sigma_raw [N] and    */
 /* emb [N,15] (both outputs of umhs_field_fwd).  d_sigma [N] and d_spectral [N,B] are the gradients w.r.t. the   */
@@ -138,7 +149,10 @@ int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
                    int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
                    const float* sigma_raw, const float* emb, int64_t n, const float* d_sigma,
                    const float* d_spectral, const float* d_emb_ext, float* d_enc, const umhs_field_grads* grads,
-                   void* workspace, size_t workspace_bytes, umhs_stream_t stream);
+                   void* workspace, size_t workspace_bytes, int packs_ready, umhs_stream_t stream);
+/* builds the transposed packs + forward image ahead of time (parameters only): then pass packs_ready = 1, same workspace */
+int umhs_field_bwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
+                           size_t workspace_bytes, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* R11: packed transmittance/weights.  Replaces nerfacc.pack_info + render_weight_from_density, */

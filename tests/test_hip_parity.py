@@ -545,3 +545,35 @@ def test_fused_training_tail_equals_the_separate_kernels(R, B, C, both):
         if rep:
             assert torch.equal(losses, first)
         first = losses.clone()
+
+
+@pytest.mark.gpu
+def test_hashgrid_bwd_prepare_apply_equals_one_call():
+    """Histogram/scan from the positions alone (prepare) + per-group scatter/reduce (apply) == umhs_hashgrid_bwd, including rows
+    whose gradient is exactly zero (the one-call form skips them, the two-call form cannot know them yet)."""
+    from umhsnerf import ops
+
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(12)
+    n = 70001
+    pos = torch.rand(n, 3, generator=g).to(dev)
+    d_enc = torch.randn(16, n, 2, generator=g).to(dev)
+    d_enc[:, ::3] = 0.0
+    d_enc[5] = 0.0  # a whole level without gradient
+    sc = ops.hash_scalings(ops.NUM_LEVELS, 16, 2048).to(dev)
+    want = torch.empty(ops.NUM_LEVELS << 19, 2, device=dev)
+    ops.hashgrid_bwd(pos, d_enc, sc, 19, want, True, overwrite=True)
+    got = torch.full_like(want, float("nan"))
+    assert ops.hashgrid_bwd_prepare(pos, sc, 19)
+    for l0, cnt in [(12, 4), (0, 5), (5, 7)]:  # any order, any grouping, each level once
+        ops.hashgrid_bwd_apply(pos, d_enc, sc, 19, got, True, overwrite=True, level_begin=l0, level_count=cnt)
+    # not bit-equal: a zero-gradient sample now sits inside a run of its cell instead of splitting it, so the float partial
+    # sums feeding the fixed-point accumulation group differently
+    assert not torch.isnan(got).any()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
+    assert torch.equal(got[5 << 19:6 << 19], torch.zeros_like(got[5 << 19:6 << 19]))  # the gradient-free level stays exactly zero
+    acc = torch.ones_like(want)  # accumulate mode
+    assert ops.hashgrid_bwd_prepare(pos, sc, 19, level_begin=3, level_count=2)
+    ops.hashgrid_bwd_apply(pos, d_enc, sc, 19, acc, True, overwrite=False, level_begin=3, level_count=2, ws_range=(3, 2))
+    torch.testing.assert_close(acc[3 << 19:5 << 19], want[3 << 19:5 << 19] + 1.0, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
+    assert float(acc[: 3 << 19].min()) == 1.0 and float(acc[5 << 19:].max()) == 1.0

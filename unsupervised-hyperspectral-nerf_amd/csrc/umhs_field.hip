@@ -1106,11 +1106,29 @@ extern "C" size_t umhs_field_fwd_workspace_bytes(const umhs_field_cfg* cfg) {
   return (size_t)pd.total * 4 + 512;
 }
 
+// Builds the forward pack image into the workspace ahead of time (depends on the parameters only); pass pack_ready = 1 and
+// the same workspace to umhs_field_fwd afterwards.
+extern "C" int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
+                                      size_t workspace_bytes, umhs_stream_t stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!params || !workspace) return UMHS_ERR_ARG;
+  PackDesc pd;
+  int TB;
+  rc = build_pack_desc(cfg, params, &pd, &TB);
+  if (rc) return rc;
+  if (workspace_bytes < (size_t)pd.total * 4 + 512) return UMHS_ERR_WORKSPACE;
+  float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
 extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
                               int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
                               const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
                               float* spectral, float* spectral2, float* specular, float* abundances,
-                              void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
+                              void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!params || !enc || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
@@ -1136,8 +1154,10 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   if (workspace) {  // optional: prebuilt pack image (without it every workgroup gathers the image itself)
     if (workspace_bytes < (size_t)pd.total * 4 + 512) return UMHS_ERR_WORKSPACE;
     float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
-    UMHS_CHECK_LAUNCH();
+    if (!pack_ready) {  // else: umhs_field_fwd_prepare already built it in this workspace
+      hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
+      UMHS_CHECK_LAUNCH();
+    }
     image = img;
   }
   static const int one_per_cu = getenv("UMHS_FWD_ONE_PER_CU") ? atoi(getenv("UMHS_FWD_ONE_PER_CU")) : 0;  // experiment
@@ -1252,7 +1272,29 @@ static unsigned bwd_grid(int64_t n, int S) {
 }
 
 static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
-  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 16 + pl.pd_all.total) * 4 + 1024;
+  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 16 + pl.pd_all.total) * 4 + 2048;
+}
+
+// The weight images of the backward (transposed packs + forward pack image) depend on the parameters only: a caller may build
+// them ahead of time (e.g. on a side stream during the forward pass) and pass packs_ready = 1 to umhs_field_bwd with the SAME
+// workspace.  The parameters must not change in between.
+extern "C" int umhs_field_bwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
+                                      size_t workspace_bytes, umhs_stream_t stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
+  if (!params) return UMHS_ERR_ARG;
+  BwdPlan pl;
+  rc = build_bwd_plan(cfg, params, &pl);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < bwd_workspace_need(pl, 1)) return UMHS_ERR_WORKSPACE;
+  float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float* img = wT + ((pl.td.total + 63) & ~63);
+  hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
+  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all,
+                     img);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
 }
 
 extern "C" size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int64_t n) {
@@ -1270,7 +1312,7 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
                               int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
                               const float* selector, const float* sigma_raw, const float* emb, int64_t n,
                               const float* d_sigma, const float* d_spectral, const float* d_emb_ext, float* d_enc,
-                              const umhs_field_grads* grads, void* workspace, size_t workspace_bytes,
+                              const umhs_field_grads* grads, void* workspace, size_t workspace_bytes, int packs_ready,
                               umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
@@ -1286,14 +1328,17 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   if (rc) return rc;
   const unsigned grid = bwd_grid(n, pl.S);
   if (!workspace || workspace_bytes < bwd_workspace_need(pl, n)) return UMHS_ERR_WORKSPACE;
+  // workspace: [transposed packs][forward pack image] (both independent of n: umhs_field_bwd_prepare fills them) [slabs][d_bo]
   float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  float* slabs = wT + ((pl.td.total + 63) & ~63);
+  float* img = wT + ((pl.td.total + 63) & ~63);
+  float* slabs = img + ((pl.pd_all.total + 63) & ~63);
   float* d_bo = slabs + (((size_t)grid * pl.sl.total + 63) & ~(size_t)63);
-  float* img = d_bo + (((size_t)n * 16 + 63) & ~(size_t)63);
-  hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
-  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all,
-                     img);
-  UMHS_CHECK_LAUNCH();
+  if (!packs_ready) {
+    hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
+    hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all,
+                       img);
+    UMHS_CHECK_LAUNCH();
+  }
   FieldIO io = {};
   io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = pl.TB, io.temperature = cfg->temperature;

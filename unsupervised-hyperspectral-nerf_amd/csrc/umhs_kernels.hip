@@ -213,7 +213,9 @@ struct HbArgs {
   int64_t sn, sl;
   const float* scalings;
   int64_t n;
-  int log2_T, bucket_bits, nb, level0, nlev;
+  int log2_T, bucket_bits, nb, level0, nlev;  // level0: first level of the WORKSPACE range; nlev: its size
+  int lev_off;                                 // this launch covers workspace levels [lev_off, lev_off + gridDim.y)
+  int grad_mask;  // 1: samples whose gradient is exactly zero emit no records (both passes then need d_enc); 0: every sample does
   uint32_t *counts, *offsets, *cursor;  // [nlev * nb]
   uint32_t* lmax;                       // [nlev] bits of the level's max |record value|
   uint16_t* rec_idx;                    // [8 * n * nlev]
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
   __shared__ float2 recV[MAXREC];
   __shared__ uint16_t recI[MAXREC];
   __shared__ uint8_t recB[MAXREC];
-  const int tid = threadIdx.x, lane = tid & 63, lev = blockIdx.y, l = a.level0 + lev;
+  const int tid = threadIdx.x, lane = tid & 63, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
   if (tid < 64) hist[tid] = 0;
   if (tid == 0) wgmax = 0;
   __syncthreads();
@@ -278,9 +280,11 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) w[c] = 0.0f, slot[k][c] = 0;
     if (i < a.n) {
-      const float* g = a.d_enc + i * a.sn + (int64_t)l * a.sl;
-      g0 = g[0], g1 = g[1];
-      if (g0 != 0.0f || g1 != 0.0f) {
+      if (SCATTER || a.grad_mask) {  // the histogram pass of a prepare/apply pair runs before any gradient exists
+        const float* g = a.d_enc + i * a.sn + (int64_t)l * a.sl;
+        g0 = g[0], g1 = g[1];
+      }
+      if (!a.grad_mask || g0 != 0.0f || g1 != 0.0f) {
         act = true;
         const float px = a.pos01[3 * i], py = a.pos01[3 * i + 1], pz = a.pos01[3 * i + 2];
         HashCorners h = hash_corners(px, py, pz, s, mask, 0u);
@@ -385,7 +389,7 @@ __global__ void hg_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __
 
 __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __restrict__ d_table) {
   extern __shared__ __attribute__((aligned(16))) long long tile[];  // [2 << bucket_bits] int64 fixed point
-  const int tid = threadIdx.x, b = blockIdx.x, lev = blockIdx.y, l = a.level0 + lev;
+  const int tid = threadIdx.x, b = blockIdx.x, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
   const uint32_t start = a.offsets[lev * a.nb + b], cnt = a.counts[lev * a.nb + b];
   const int nsl = 2 << a.bucket_bits;
   if (cnt == 0) {  // nothing lands in this slab (uniform over the workgroup)
@@ -440,6 +444,11 @@ extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int
   return (3 * m + 64) * 4 + 256 + cap * 2 + 256 + cap * 8 + 256;
 }
 
+static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t n, int ws_begin, int ws_levels, int log2_T,
+                   void* workspace, size_t workspace_bytes);
+static int hb_run_prepare(const HbArgs& a, int n_levels, umhs_stream_t stream);
+static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stream_t stream);
+
 extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
                                  const float* scalings, int64_t n, int level_begin, int n_levels, int log2_T,
                                  float* d_table, int overwrite, void* workspace, size_t workspace_bytes,
@@ -459,35 +468,96 @@ extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t
     UMHS_CHECK_LAUNCH();
     return UMHS_OK;
   }
-  const size_t need = umhs_hashgrid_bwd_workspace_bytes(n, n_levels, log2_T);
-  if (need == 0) return UMHS_ERR_UNSUPPORTED;
-  if (workspace_bytes < need || ((uintptr_t)d_table & 15)) return UMHS_ERR_WORKSPACE;
-  if ((size_t)8 * n * n_levels >= ((size_t)1 << 32)) return UMHS_ERR_UNSUPPORTED;
+  // one-call form: the histogram pass may look at the gradient too, so zero-gradient samples are skipped in both passes
   HbArgs a;
-  a.pos01 = pos01, a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.scalings = scalings, a.n = n;
-  a.log2_T = log2_T, a.bucket_bits = hb_bucket_bits(log2_T), a.nb = 1 << (log2_T - a.bucket_bits), a.level0 = level_begin;
-  a.nlev = n_levels, a.overwrite = overwrite;
-  const size_t m = (size_t)n_levels * a.nb, cap = (size_t)8 * n * n_levels;
+  int rc = hb_args(&a, pos01, scalings, n, level_begin, n_levels, log2_T, workspace, workspace_bytes);
+  if (rc) return rc;
+  if ((uintptr_t)d_table & 15) return UMHS_ERR_WORKSPACE;
+  a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.overwrite = overwrite, a.grad_mask = 1;
+  rc = hb_run_prepare(a, n_levels, stream);
+  if (rc) return rc;
+  return hb_run_apply(a, n_levels, d_table, stream);
+}
+
+static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t n, int ws_begin, int ws_levels, int log2_T,
+                   void* workspace, size_t workspace_bytes) {
+  const size_t need = umhs_hashgrid_bwd_workspace_bytes(n, ws_levels, log2_T);
+  if (need == 0) return UMHS_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < need) return UMHS_ERR_WORKSPACE;
+  if ((size_t)8 * n * ws_levels >= ((size_t)1 << 32)) return UMHS_ERR_UNSUPPORTED;
+  a->pos01 = pos01, a->d_enc = nullptr, a->sn = 0, a->sl = 0, a->scalings = scalings, a->n = n;
+  a->log2_T = log2_T, a->bucket_bits = hb_bucket_bits(log2_T), a->nb = 1 << (log2_T - a->bucket_bits), a->level0 = ws_begin;
+  a->nlev = ws_levels, a->lev_off = 0, a->overwrite = 0, a->grad_mask = 0;
+  const size_t m = (size_t)ws_levels * a->nb, cap = (size_t)8 * n * ws_levels;
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
-  a.counts = reinterpret_cast<uint32_t*>(p), a.lmax = a.counts + m, a.offsets = a.lmax + 64, a.cursor = a.offsets + m;
+  a->counts = reinterpret_cast<uint32_t*>(p), a->lmax = a->counts + m, a->offsets = a->lmax + 64, a->cursor = a->offsets + m;
   p = (p + (3 * m + 64) * 4 + 255) & ~(uintptr_t)255;
-  a.rec_idx = reinterpret_cast<uint16_t*>(p);
+  a->rec_idx = reinterpret_cast<uint16_t*>(p);
   p = (p + cap * 2 + 255) & ~(uintptr_t)255;
-  a.rec_val = reinterpret_cast<float2*>(p);
-  if (hipMemsetAsync(a.counts, 0, (m + 64) * 4, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;  // counts + lmax
-  dim3 pgrid((unsigned)((n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
+  a->rec_val = reinterpret_cast<float2*>(p);
+  return UMHS_OK;
+}
+
+static int hb_run_prepare(const HbArgs& a, int n_levels, umhs_stream_t stream) {  // counts + lmax cleared, histogram, scan
+  const size_t m = (size_t)a.nlev * a.nb;
+  if (hipMemsetAsync(a.counts, 0, (m + 64) * 4, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
+  dim3 pgrid((unsigned)((a.n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<false>, pgrid, dim3(256), 0, umhs_s(stream), a);
-  hipLaunchKernelGGL(hg_scan_kernel, dim3(1), dim3(64), 0, umhs_s(stream), (const uint32_t*)a.counts, a.offsets,
-                     a.cursor, (int)m);
+  hipLaunchKernelGGL(hg_scan_kernel, dim3(1), dim3(64), 0, umhs_s(stream), (const uint32_t*)a.counts, a.offsets, a.cursor,
+                     (int)m);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stream_t stream) {  // scatter + bucket reduce
+  dim3 pgrid((unsigned)((a.n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<true>, pgrid, dim3(256), 0, umhs_s(stream), a);
   const size_t lds = (size_t)(2 << a.bucket_bits) * 8;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(hg_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return UMHS_ERR_LAUNCH;
-  hipLaunchKernelGGL(hg_reduce_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(1024), lds, umhs_s(stream), a,
-                     d_table);
+  hipLaunchKernelGGL(hg_reduce_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(1024), lds, umhs_s(stream), a, d_table);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
+}
+
+// Gradient-independent half of the partitioned backward (bucket histogram + exclusive scan): needs only the positions, so
+// a caller may run it on a side stream while the forward pass is still in flight.  (Every sample emits records in this
+// form; the one-call umhs_hashgrid_bwd skips samples whose gradient is exactly zero.)
+extern "C" int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalings, int64_t n, int level_begin, int n_levels,
+                                         int log2_T, void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
+  if (n < 0 || !pos01 || !scalings || level_begin < 0) return UMHS_ERR_ARG;
+  if (n_levels < 1 || level_begin + n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (n == 0) return UMHS_OK;
+  HbArgs a;
+  int rc = hb_args(&a, pos01, scalings, n, level_begin, n_levels, log2_T, workspace, workspace_bytes);
+  if (rc) return rc;
+  return hb_run_prepare(a, n_levels, stream);
+}
+
+// Gradient-dependent half: scatter the records of levels [level_begin, +n_levels) into their buckets and reduce every bucket
+// into its d_table slab.  The workspace must hold a umhs_hashgrid_bwd_prepare of [ws_level_begin, +ws_n_levels) for the SAME
+// positions, and that range must contain the levels applied; each level may be applied once per prepare.
+extern "C" int umhs_hashgrid_bwd_apply(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
+                                       const float* scalings, int64_t n, int level_begin, int n_levels, int ws_level_begin,
+                                       int ws_n_levels, int log2_T, float* d_table, int overwrite, void* workspace,
+                                       size_t workspace_bytes, umhs_stream_t stream) {
+  if (n < 0 || !pos01 || !d_enc || !scalings || !d_table || level_begin < 0) return UMHS_ERR_ARG;
+  if (n_levels < 1 || level_begin < ws_level_begin || level_begin + n_levels > ws_level_begin + ws_n_levels ||
+      ws_level_begin + ws_n_levels > 32 || log2_T < 2 || log2_T > 24)
+    return UMHS_ERR_UNSUPPORTED;
+  if ((uintptr_t)d_table & 15) return UMHS_ERR_WORKSPACE;
+  if (n == 0) {
+    if (overwrite && hipMemsetAsync(d_table + (((size_t)level_begin << log2_T) * 2), 0, ((size_t)n_levels << log2_T) * 8,
+                                    umhs_s(stream)) != hipSuccess)
+      return UMHS_ERR_LAUNCH;
+    return UMHS_OK;
+  }
+  HbArgs a;
+  int rc = hb_args(&a, pos01, scalings, n, ws_level_begin, ws_n_levels, log2_T, workspace, workspace_bytes);
+  if (rc) return rc;
+  a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.lev_off = level_begin - ws_level_begin, a.overwrite = overwrite;
+  return hb_run_apply(a, n_levels, d_table, stream);
 }
 
 // =============================================================================================

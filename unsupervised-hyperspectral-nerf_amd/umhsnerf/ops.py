@@ -160,7 +160,60 @@ def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool
                "umhs_hashgrid_bwd")
 
 
-def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True):
+def hashgrid_bwd_prepare(pos01, scalings, log2_T: int, level_begin: int = 0, level_count: int = NUM_LEVELS) -> bool:
+    """Gradient-independent half of the partitioned backward (histogram + scan) into the cached workspace.  False: this shape
+    has no partitioned path (the caller then uses hashgrid_bwd)."""
+    n = pos01.shape[0]
+    nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, level_count, log2_T)
+    if nbytes == 0:
+        return False
+    ws = _workspace(nbytes, pos01.device, slot=1)
+    _hip.check(_hip.lib().umhs_hashgrid_bwd_prepare(ptr(pos01), ptr(scalings), n, level_begin, level_count, log2_T, ptr(ws), ws.numel(),
+                                                    _hip.stream()), "umhs_hashgrid_bwd_prepare")
+    return True
+
+
+def hashgrid_bwd_apply(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, overwrite: bool = False,
+                       level_begin: int = 0, level_count: int = NUM_LEVELS, ws_range=(0, NUM_LEVELS)):
+    """Scatter + reduce of levels [level_begin, +level_count) using the workspace hashgrid_bwd_prepare filled for ws_range."""
+    n = pos01.shape[0]
+    sn, sl = enc_strides(n, level_major)
+    ws = _workspace(_hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, ws_range[1], log2_T), pos01.device, slot=1)
+    _hip.check(_hip.lib().umhs_hashgrid_bwd_apply(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, level_begin, level_count, ws_range[0],
+                                                  ws_range[1], log2_T, ptr(d_table), int(overwrite), ptr(ws), ws.numel(), _hip.stream()),
+               "umhs_hashgrid_bwd_apply")
+
+
+def reserve_step_workspaces(spec: FieldSpec, n: int, device) -> bool:
+    """Size the cached workspaces of one training step on the CURRENT stream, so that the *_prepare calls issued on a side
+    stream never allocate there (blocks handed out under another stream would need record_stream bookkeeping).
+    Returns whether the partitioned hash-grid backward is available for this n."""
+    cfg = spec.cfg(False)
+    _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), device, slot=2)
+    _workspace(_hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n), device)
+    nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, NUM_LEVELS, spec.layout.log2_hashmap_size)
+    if nbytes:
+        _workspace(nbytes, device, slot=1)
+    return nbytes != 0
+
+
+def field_fwd_prepare(spec: FieldSpec, flat):
+    """Build the forward pack image ahead of field_fwd(pack_ready=True) (same cached workspace)."""
+    cfg = spec.cfg(False)
+    pp = spec.layout.c_struct(flat, _hip.FieldParams)
+    ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), flat.device, slot=2)
+    _hip.check(_hip.lib().umhs_field_fwd_prepare(C.byref(cfg), C.byref(pp), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_fwd_prepare")
+
+
+def field_bwd_prepare(spec: FieldSpec, flat, n: int):
+    """Build the backward's weight images ahead of field_bwd(packs_ready=True); n sizes the shared workspace once."""
+    cfg = spec.cfg(False)
+    pp = spec.layout.c_struct(flat, _hip.FieldParams)
+    ws = _workspace(_hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n), flat.device)
+    _hip.check(_hip.lib().umhs_field_bwd_prepare(C.byref(cfg), C.byref(pp), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_bwd_prepare")
+
+
+def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True, pack_ready=False):
     n = sel.shape[0]
     L = spec.layout
     dev = sel.device
@@ -180,7 +233,7 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_fwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), n,
                                          ptr(sigma), ptr(sigma_raw), ptr(emb), ptr(spectral), ptr(spectral2), ptr(specular),
-                                         ptr(abund), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_fwd")
+                                         ptr(abund), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_fwd")
     return dict(sigma=sigma, sigma_raw=sigma_raw, emb=emb, spectral=spectral, spectral2=spectral2, specular=specular,
                 abundances=abund)
 
@@ -197,7 +250,8 @@ def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
     return ws
 
 
-def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat):
+def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
+              packs_ready=False):
     """Writes d_enc (returned) and the MLP / endmember gradients straight into ``d_flat`` (flat layout)."""
     n = sel.shape[0]
     L = spec.layout
@@ -211,7 +265,7 @@ def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_ra
     _hip.check(_hip.lib().umhs_field_bwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel),
                                          ptr(sigma_raw), ptr(emb), n,
                                          ptr(d_sigma), ptr(d_spectral), ptr(d_emb), ptr(d_enc), C.byref(gp), ptr(ws),
-                                         ws.numel(), _hip.stream()), "umhs_field_bwd")
+                                         ws.numel(), int(packs_ready), _hip.stream()), "umhs_field_bwd")
     return d_enc
 
 
@@ -338,8 +392,10 @@ def ssim(a, b, data_range=None):
     return part.sum() / float((h - 10) * (w - 10) * k)
 
 
-def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb):
-    """Backward of the field (field_bwd + hash-grid scatter) into the flat gradient.  With a gradient sink that owns the next
+def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb,
+                        prepared: bool = False):
+    """``prepared``: field_bwd_prepare and hashgrid_bwd_prepare (all levels) already ran for this step's parameters/positions.
+    Backward of the field (field_bwd + hash-grid scatter) into the flat gradient.  With a gradient sink that owns the next
     backward the buffer becomes ``param.grad`` directly, finished segments start their all-reduce, and None is returned;
     otherwise the freshly written flat gradient is returned (autograd accumulates it)."""
     L = spec.layout
@@ -349,13 +405,17 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
     d_flat = sink.begin() if own else torch.empty_like(flat)
     tail = L.offset("mlp_base.mlp.layers.0.weight")
     d_flat[tail:].zero_()  # MLP / endmember segments (+ alignment padding)
-    d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat)
+    d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
+                      packs_ready=prepared)
     if own:
         sink.segment_done(d_flat[tail:])
     table = L.view(d_flat, "mlp_base.encoder.hash_table")
     T = 1 << L.log2_hashmap_size
     for l0, cnt in (sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]):
-        hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
+        if prepared:  # histogram + scan of all levels were done ahead of time (hashgrid_bwd_prepare)
+            hashgrid_bwd_apply(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
+        else:
+            hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
         if own:
             sink.segment_done(table[l0 * T:(l0 + cnt) * T])
     if own:  # the buffer becomes param.grad directly (autograd gets None: nothing to accumulate or copy)
@@ -550,10 +610,10 @@ class AccumulateFn(torch.autograd.Function):
         return d_w.view(ctx.shapes[0]), d_v.view(ctx.shapes[1]), None
 
 
-def tmid_minmax(starts, ends) -> torch.Tensor:
+def tmid_minmax(starts, ends, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Encoded (min, max) of the sample mid-points over the batch; consumed by RayEpilogueFn only."""
     t0, t1 = _hip.f32c(starts).view(-1), _hip.f32c(ends).view(-1)
-    mm = torch.empty(2, device=t0.device, dtype=torch.float32)
+    mm = out if out is not None else torch.empty(2, device=t0.device, dtype=torch.float32)
     _hip.check(_hip.lib().umhs_tmid_minmax(ptr(t0), ptr(t1), t0.shape[0], ptr(mm), _hip.stream()), "umhs_tmid_minmax")
     return mm
 

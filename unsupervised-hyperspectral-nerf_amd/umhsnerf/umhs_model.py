@@ -307,11 +307,36 @@ class UMHSModel(nn.Module):
             packed_info = ops.pack_info(ray_indices, num_rays)
         # forward (FieldFn.forward -> CompositeFn.forward -> RayEpilogueFn.forward -> LossFn.forward)
         wpos, pos01, sel = ops.positions_fwd(o, d, t0, t1, spec)
+        # Everything of this step that depends on positions / parameters only -- the t_mid clip bounds, the weight pack images of
+        # the forward and the backward, the bucket histogram + scan of the hash-grid backward (~80 us of small launches) -- runs
+        # on a side stream in the shadow of the two big forward kernels.
+        side = self._side_stream() if os.environ.get("UMHS_SIDE_STREAM", "1") != "0" else None
+        prepared = False
+        if side is not None:
+            main = torch.cuda.current_stream(self.device)
+            mm = torch.empty(2, device=self.device, dtype=torch.float32)  # every allocation happens on the main stream
+            can_partition = ops.reserve_step_workspaces(spec, n, self.device)
+            ev_in, ev_pack, ev_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            ev_in.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_in)
+                ops.field_fwd_prepare(spec, flat)
+                ev_pack.record(side)
+                ops.tmid_minmax(t0, t1, out=mm)
+                if can_partition and n > 0:
+                    prepared = ops.hashgrid_bwd_prepare(pos01, spec.scalings, L.log2_hashmap_size)
+                    ops.field_bwd_prepare(spec, flat, n)
+                ev_done.record(side)
         enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
-        fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True)
+        if side is not None:
+            main.wait_event(ev_pack)
+        fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None)
         values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
         weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
-        mm = ops.tmid_minmax(t0, t1)
+        if side is not None:
+            main.wait_event(ev_done)
+        else:
+            mm = ops.tmid_minmax(t0, t1)
         spectral = comp[0]
         M = _hip.f32c(self.converter.transform_matrix)
         hs, image = _hip.f32c(batch["hs_image"].to(self.device)), _hip.f32c(batch["image"].to(self.device))
@@ -324,7 +349,8 @@ class UMHSModel(nn.Module):
             w[0], w[1], both)
         d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
                                               bool(c.use_gradient_scaling))
-        left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_values[0], None)
+        left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_values[0], None,
+                                       prepared=prepared)
         assert left is None  # direct_step_supported() guarantees the sink owned this backward
         outputs = self._assemble_outputs(acc.view(-1, 1), depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights.view(-1, 1),
                                          lazy_bands=True)
@@ -332,6 +358,12 @@ class UMHSModel(nn.Module):
         if both:
             loss_dict["rgb_loss"] = losses[1]
         return outputs, loss_dict
+
+    def _side_stream(self):
+        s = getattr(self, "_side", None)
+        if s is None or s.device != self.device:
+            s = self._side = torch.cuda.Stream(device=self.device)
+        return s
 
     def _ones2(self) -> Tensor:
         t = getattr(self, "_ones2_t", None)
