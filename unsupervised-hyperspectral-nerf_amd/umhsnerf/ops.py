@@ -134,13 +134,15 @@ def enc_strides(n: int, level_major: bool) -> Tuple[int, int]:
     return (2, 2 * n) if level_major else (2 * NUM_LEVELS, 2)
 
 
-def hashgrid_fwd(pos01, table, scalings, log2_T: int, level_major: bool = True):
+def hashgrid_fwd(pos01, table, scalings, log2_T: int, level_major: bool = True, out=None, part=None):
+    """part = (offset, count): encode only that range of samples into ``out`` (the full-size enc tensor; level-major)."""
     n = pos01.shape[0]
     shape = (NUM_LEVELS, n, 2) if level_major else (n, NUM_LEVELS * 2)
-    enc = torch.empty(shape, device=pos01.device, dtype=torch.float32)
+    enc = out if out is not None else torch.empty(shape, device=pos01.device, dtype=torch.float32)
     sn, sl = enc_strides(n, level_major)
-    _hip.check(_hip.lib().umhs_hashgrid_fwd(ptr(pos01), ptr(table), ptr(scalings), n, NUM_LEVELS, log2_T, ptr(enc), sn, sl,
-                                            _hip.stream()), "umhs_hashgrid_fwd")
+    off, cnt = part if part is not None else (0, n)
+    _hip.check(_hip.lib().umhs_hashgrid_fwd(pos01.data_ptr() + 12 * off, ptr(table), ptr(scalings), cnt, NUM_LEVELS, log2_T,
+                                            enc.data_ptr() + 4 * sn * off, sn, sl, _hip.stream()), "umhs_hashgrid_fwd")
     return enc
 
 
@@ -213,29 +215,39 @@ def field_bwd_prepare(spec: FieldSpec, flat, n: int):
     _hip.check(_hip.lib().umhs_field_bwd_prepare(C.byref(cfg), C.byref(pp), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_bwd_prepare")
 
 
-def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True, pack_ready=False):
+def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb=False, want_aux=True):
+    L = spec.layout
+    new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    out = dict(sigma=new(n), sigma_raw=new(n), emb=new(n, GEO_FEAT_DIM) if (want_emb or density_only) else None, spectral=None,
+               spectral2=None, specular=None, abundances=None)
+    if not density_only:
+        out["spectral"] = new(n, L.wavelengths)
+        if want_aux:
+            out["abundances"] = new(n, L.num_classes)
+            if L.pred_specular:
+                out["spectral2"], out["specular"] = new(n, L.wavelengths), new(n, L.wavelengths)
+    return out
+
+
+def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True, pack_ready=False,
+              out=None, part=None):
+    """part = (offset, count): evaluate only that range of samples, writing into the full-size tensors of ``out``."""
     n = sel.shape[0]
     L = spec.layout
     dev = sel.device
     cfg = spec.cfg(density_only)
     pp = L.c_struct(flat, _hip.FieldParams)
     sn, sl = enc_strides(n, level_major)
-    new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-    sigma, sigma_raw = new(n), new(n)
-    emb = new(n, GEO_FEAT_DIM) if (want_emb or density_only) else None
-    spectral = spectral2 = specular = abund = None
-    if not density_only:
-        spectral = new(n, L.wavelengths)
-        if want_aux:
-            abund = new(n, L.num_classes)
-            if L.pred_specular:
-                spectral2, specular = new(n, L.wavelengths), new(n, L.wavelengths)
+    o = out if out is not None else field_fwd_outputs(spec, n, dev, density_only, want_emb, want_aux)
+    off, cnt = part if part is not None else (0, n)
+    at = lambda t, width: (t.data_ptr() + 4 * width * off) if t is not None else None
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
-    _hip.check(_hip.lib().umhs_field_fwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), n,
-                                         ptr(sigma), ptr(sigma_raw), ptr(emb), ptr(spectral), ptr(spectral2), ptr(specular),
-                                         ptr(abund), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_fwd")
-    return dict(sigma=sigma, sigma_raw=sigma_raw, emb=emb, spectral=spectral, spectral2=spectral2, specular=specular,
-                abundances=abund)
+    _hip.check(_hip.lib().umhs_field_fwd(C.byref(cfg), C.byref(pp), at(enc, sn), sn, sl, at(wpos, 3), at(dirs, 3), at(sel, 1), cnt,
+                                         at(o["sigma"], 1), at(o["sigma_raw"], 1), at(o["emb"], GEO_FEAT_DIM), at(o["spectral"], L.wavelengths),
+                                         at(o["spectral2"], L.wavelengths), at(o["specular"], L.wavelengths),
+                                         at(o["abundances"], L.num_classes), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()),
+               "umhs_field_fwd")
+    return o
 
 
 _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
