@@ -181,8 +181,8 @@ def main():
     batch = {"image": gt_rgb, "hs_image": b["gt_spectral"]}
 
     timer = KernelTimer(ops)
-    OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "composite_fwd", "spec2rgb_fwd", "spec2rgb_bwd", "composite_bwd",
-           "field_bwd", "hashgrid_bwd", "adam_step")
+    OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "composite_fwd", "tmid_minmax", "ray_train_tail", "composite_bwd", "field_bwd",
+           "hashgrid_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "field_fwd_prepare", "field_bwd_prepare", "adam_step")
     for name in OPS:
         timer.wrap(name)
     # Inside the timed region only the dominant operator carries HIP events (2 per step): an event is a barrier packet on the
@@ -230,6 +230,7 @@ def main():
         # + the level-major feature rows (128 B) and positions (12 B) each kernel streams)
         alg = {
             "hashgrid_bwd": N * (1024 + 128 + 12),
+            "hashgrid_bwd_apply": N * (1024 + 128 + 12),
             "hashgrid_fwd": N * (1024 + 128 + 12),
             "adam_step": pipe.model.field.flat.numel() * 28,
         }
@@ -245,7 +246,8 @@ def main():
             pass
         op_kernels = {"field_bwd": ("field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce_kernel", "field_pack"),
                       "field_fwd": ("field_fwd_kernel", "field_pack_fwd"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
-                      "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"), "adam_step": ("adam_kernel",)}
+                      "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"),
+                      "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel"), "adam_step": ("adam_kernel",)}
         traffic = sum(v["hbm_traffic_bytes"] for k, v in pmc.items() if any(k.startswith(p_) for p_ in op_kernels.get(dom, ()))) or None
         busy = [v["mfma_util"] for k, v in pmc.items() if k.startswith("field_bwd_heads" if dom == "field_bwd" else "field_fwd_kernel")]
         roof = None
