@@ -38,13 +38,21 @@ class UMHSAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
                 st["step"] += 1
-                sink = getattr(p, "_umhs_grad_sink", None)
-                if sink is not None and sink.finish(p.grad):  # segments were all-reduced while the backward was still running
-                    grad_scale = 1.0 / world()[1]
-                else:
-                    grad_scale = allreduce_flat_grad(p.grad)  # one 67 MB RCCL all-reduce over xGMI (no-op at world 1)
                 lr = group["lr"]
                 if group["lr_final"] is not None:
                     lr = exp_decay_lr(st["step"] - 1, group["lr_init"], group["lr_final"], group["max_steps"])
-                ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, group["betas"], group["eps"],
-                              grad_scale=grad_scale, clamp_range=group["clamp_range"])
+                sink = getattr(p, "_umhs_grad_sink", None)
+                cb, ce = group["clamp_range"]
+                done = 0
+                if sink is not None:
+                    # Segments were all-reduced while the backward was still running: update each one as soon as ITS reduction
+                    # has landed, so the Adam pass of segment k hides under the transfer of segments k+1..
+                    for a, b in sink.reduced_segments(p.grad):
+                        clamp = (max(cb, a) - a, min(ce, b) - a) if (cb < b and ce > a) else (0, 0)
+                        ops.adam_step(p.data[a:b], p.grad[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], st["step"], lr, group["betas"],
+                                      group["eps"], grad_scale=1.0 / world()[1], clamp_range=clamp)
+                        done += b - a
+                if done == 0:
+                    grad_scale = allreduce_flat_grad(p.grad)  # one 67 MB RCCL all-reduce over xGMI (no-op at world 1)
+                    ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, group["betas"], group["eps"],
+                                  grad_scale=grad_scale, clamp_range=group["clamp_range"])

@@ -78,20 +78,31 @@ class FlatGradSink:
 
     def segment_done(self, view: torch.Tensor) -> None:
         if world()[1] > 1 and self.async_reduce:
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            off = (view.data_ptr() - self.buffer.data_ptr()) // self.buffer.element_size()
+            self.works.append((off, off + view.numel(), dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)))
 
     def commit(self) -> None:
         self.param.grad = self.buffer
         if self.works:
             self.reduced_ptr = self.buffer.data_ptr()
 
-    def finish(self, grad: torch.Tensor) -> bool:
-        """Wait for pending reductions; True if ``grad`` is already summed over the ranks."""
+    def reduced_segments(self, grad: torch.Tensor):
+        """Yields (begin, end) element ranges of ``grad`` in the order their all-reduce was started, each after the consumer stream
+        has been made to wait for that reduction -- so the optimizer can update segment k while segments k+1.. are still on the
+        wire.  Empty when nothing was reduced early (the caller then reduces the whole gradient itself)."""
         if not self.works:
-            return False
-        for w in self.works:
-            w.wait()
-        self.works.clear()
+            return
         if grad.data_ptr() != self.reduced_ptr:
             raise RuntimeError("param.grad is not the buffer that was reduced (was .grad replaced after backward?)")
-        return True
+        works, self.works = self.works, []
+        covered = 0
+        for a, b, w in works:
+            w.wait()
+            covered += b - a
+            yield a, b
+        if covered != grad.numel():
+            raise RuntimeError(f"early reduction covered {covered} of {grad.numel()} gradient elements")
+
+    def finish(self, grad: torch.Tensor) -> bool:
+        """Wait for pending reductions; True if ``grad`` is already summed over the ranks."""
+        return len(list(self.reduced_segments(grad))) > 0
