@@ -133,8 +133,10 @@ size_t umhs_field_fwd_workspace_bytes(const umhs_field_cfg* cfg);
 int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                    int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
                    int64_t n, float* sigma, float* sigma_raw, float* emb, float* spectral, float* spectral2,
-                   float* specular, float* abundances, void* workspace, size_t workspace_bytes,
+                   float* specular, float* abundances, float* feat_logits, void* workspace, size_t workspace_bytes,
                    int pack_ready, umhs_stream_t stream);
+/* feat_logits (optional, [N,16]): the feature_mlp logits, saved so that umhs_field_bwd can run its heads as two kernels   */
+/* (head MLP + directional + mixing / feature MLP) with every weight pack LDS-resident; NULL there = one fused kernel.       */
 /* builds the pack image ahead of time (parameters only): then pass pack_ready = 1 with the same workspace */
 int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
                            size_t workspace_bytes, umhs_stream_t stream);
@@ -147,7 +149,7 @@ int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* p
 size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int64_t n);
 int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                    int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
-                   const float* sigma_raw, const float* emb, int64_t n, const float* d_sigma,
+                   const float* sigma_raw, const float* emb, const float* feat_logits, int64_t n, const float* d_sigma,
                    const float* d_spectral, const float* d_emb_ext, float* d_enc, const umhs_field_grads* grads,
                    void* workspace, size_t workspace_bytes, int packs_ready, umhs_stream_t stream);
 /* builds the transposed packs + forward image ahead of time (parameters only): then pass packs_ready = 1, same workspace */

@@ -257,6 +257,17 @@ def test_field_bwd(C, B, spec, temp):
             assert float(got.abs().max()) == 0.0, k
         else:
             assert_close(f"grad {k}", got, gref, 5e-5)
+    # the split heads backward (two kernels, all packs LDS-resident; taken when the forward's feature logits are handed over and
+    # B <= 32) must give the same gradients as the fused kernel above
+    args = (fs, flat, e.to(DEV), True, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV))
+    logits = ops.field_fwd(*args, want_emb=True, want_logits=True)["feat_logits"]
+    assert logits is not None and logits.shape == (N, 16)
+    d_flat2 = torch.zeros_like(flat)
+    d_enc2 = ops.field_bwd(*args, sraw.detach().view(-1).contiguous().to(DEV), emb.detach().contiguous().to(DEV),
+                           cot_d.view(-1).to(DEV), cot_s.to(DEV), cot_e.to(DEV), d_flat2, feat_logits=logits)
+    assert_close("d_enc (split)", d_enc2.permute(1, 0, 2).reshape(N, 32), d_enc_ref, 5e-5)
+    tail = layout.offset("mlp_base.mlp.layers.0.weight")
+    assert_close("param grads (split vs fused)", d_flat2[tail:], d_flat[tail:], 2e-5)
 
 
 # --------------------------------------------------------------------------------------------- #

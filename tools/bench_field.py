@@ -27,12 +27,13 @@ for N in ([int(os.environ.get('N', 262144))] if os.environ.get('ONLY') else [163
     wpos = torch.rand(N, 3, device=dev) * 2 - 1
     dirs = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
     sel = torch.ones(N, device=dev)
-    out = ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True)
+    out = ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True, want_logits=True)
     dsig, dspec = torch.rand(N, device=dev), torch.rand(N, B, device=dev)
     dflat = torch.zeros_like(flat)
     t_f = timeit(lambda: ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True))
     t_d = timeit(lambda: ops.field_fwd(fs, flat, enc, True, None, None, sel, density_only=True))
-    t_b = timeit(lambda: ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, out["sigma_raw"], out["emb"], dsig, dspec, None, dflat))
+    t_b = timeit(lambda: ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, out["sigma_raw"], out["emb"], dsig, dspec, None, dflat,
+                                       feat_logits=out["feat_logits"]))
     pos01 = torch.rand(N, 3, device=dev)
     table = layout.view(flat, "mlp_base.encoder.hash_table")
     t_h = timeit(lambda: ops.hashgrid_fwd(pos01, table, fs.scalings, 19, True))

@@ -227,6 +227,10 @@ struct FieldIO {
   int stagger;                         // forward, 8-wave variant: waves 4-7 start this many x 4096 cycles late
   const float *emb_in, *sigma_raw_in;  // saved forward outputs (heads / base backward)
   float* d_bo;                         // [N,16] gradient w.r.t. the base MLP's outputs (heads -> base)
+  float* feat_logits;                  // forward: optional [N,16] feature_mlp logits (rows 0..C), saved for the split backward
+  const float* feat_logits_in;         // split backward, part 0
+  float* d_fl;                         // [N,16] gradient w.r.t. the feature logits (part 0 -> part 1)
+  float* d_bo2;                        // [N,16] part 1's share of d_bo (base kernel adds the two)
 };
 
 // NeRF positional encoding slots of quarter q (3 per lane) and SH slots (4 per lane)
@@ -416,6 +420,11 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
     gemm_pack<4, 16, NT, 2>(t4, a1, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
     relu_to<4, NT>(a2, t4);
     gemm_pack<1, 16, NT, 2>(fl4, a2, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    if (io.feat_logits) {  // saved for the split backward: [N,16] rows 4q..4q+3 of the logit tile, 64 B per sample
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+        if (ok[ct]) *reinterpret_cast<v4f*>(io.feat_logits + nn[ct] * 16 + 4 * q) = fl4[ct][0];
+    }
     HeadState<NT> hs;
     head_epilogue<NT, SPEC>(hs, hd4, fl4, io.C, io.temperature, lane);
     // ---- mlp_directional hidden: 28 -> 16 ---------------------------------------------------------
@@ -875,6 +884,285 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// heads, split in two (B <= 32): PART 0 = mlp_head + mlp_directional + mixing, PART 1 = feature_mlp.  The forward pass saves the
+// feature logits, so PART 0 does not need the feature MLP at all and hands PART 1 the gradient of those logits (d_fl).  Each
+// part keeps BOTH its forward packs and its transposed packs in LDS beside the staging buffers (the fused kernel reads the
+// transposed packs from L2), holds half the dW accumulators, and recomputes nothing twice.
+// ---------------------------------------------------------------------------------------------
+struct ImgSegs {
+  int n, src[6], dst[6], len[6];  // float offsets / lengths, multiples of 4
+};
+__device__ __forceinline__ void copy_segs(float* dst, const float* __restrict__ src, const ImgSegs& sg) {
+  for (int k = 0; k < sg.n; ++k)
+    for (int i = threadIdx.x; i < (sg.len[k] >> 2); i += blockDim.x)
+      reinterpret_cast<float4*>(dst + sg.dst[k])[i] = reinterpret_cast<const float4*>(src + sg.src[k])[i];
+}
+
+template <int PART, bool SPEC>
+__global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, PackDesc pd, TPackDesc td, SlabLayout sl,
+                                                                float* __restrict__ slabs, int wt_off, int stage_off, int FSd,
+                                                                const float* __restrict__ image, const float* __restrict__ wT_image,
+                                                                ImgSegs seg_f, ImgSegs seg_t) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  constexpr int WAVES = 8, NA = 1;
+  copy_segs(lds_raw, image, seg_f);             // pd / td carry offsets local to this part's LDS image
+  copy_segs(lds_raw + wt_off, wT_image, seg_t);
+  float* const lds = lds_raw;
+  const float* const wT = lds_raw + wt_off;
+  float* const st = lds_raw + stage_off;
+  constexpr int NT = 1, S = 16 * WAVES, NH0 = 8 / WAVES, NH1 = 16 / WAVES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int row = wave * 16 + j;
+  v4f aH0[NH0], aH1[NH1], aH2[1], aF0[NH0], aF1[NH1], aF2[1], aD0[1], aD1[NA], aMX[NA];
+  zero_acc(aH0), zero_acc(aH1), zero_acc(aH2), zero_acc(aF0), zero_acc(aF1), zero_acc(aF2), zero_acc(aD0);
+  zero_acc(aD1), zero_acc(aMX);
+  float dbH0 = 0.f, dbH1 = 0.f, dbH2 = 0.f, dbF0 = 0.f, dbF1 = 0.f, dbF2 = 0.f, dbD0 = 0.f, dbD1 = 0.f;
+  BSYNC();
+  const int64_t ntiles = (io.n + S - 1) / S;
+  const int C = io.C, B = io.B, TB = io.TB;
+  float* const stZ = st;            // [S][<=80]
+  float* const stX = st + S * 80;   // [S][<=80]
+  float* const stZd = st;           // [S][FSd]   dZ of mlp_directional's output layer
+  float* const stXh = st + S * FSd; // [S][16]    hidden of mlp_directional
+  float* const stXm = stXh + S * 48;  // [S][16]  mixing coefficients m   (16-wide tiles use FS = 48: 16 + 12 + pad)
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * S;
+    int64_t n = n0 + row;
+    const bool ok = n < io.n;
+    if (!ok) n = io.n - 1;
+    // =================== forward recompute of the heads (base-MLP output comes from the forward pass) ========
+    float in27[NT][7], dir28[NT][7];
+    {
+      float pe[3];
+      pe_slots(pe, io.wpos[3 * n], io.wpos[3 * n + 1], io.wpos[3 * n + 2], q);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r - 1;
+        in27[0][3 + r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) has zero weight
+      }
+      if (SPEC) {
+        float sh[4];
+        sh_slots(sh, io.dirs[3 * n], io.dirs[3 * n + 1], io.dirs[3 * n + 2], q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
+      }
+    }
+    float a1h[NT][16], a2h[NT][16];
+    v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
+    v4f dbo4[NT][1];
+    dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    // one 27->64->64->out MLP (head or feature): dW for its three layers, dX down to the base-MLP slots
+    auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f(&acc2)[1],
+                        v4f(&acc1)[NH1], v4f(&acc0)[NH0], float& db2, float& db1, float& db0, int t2, int t1,
+                        int t0) __attribute__((always_inline)) {
+      BSYNC();
+      *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
+      stage_hid<4>(stX, 80, row, q, a2[0]);
+      BSYNC();
+      dw_accum<1, WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
+      db2 += col_sum_part<WAVES>(stZ, 48, 16, tid);
+      v4f g4[NT][4];
+      gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
+      float dz1[NT][16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+      BSYNC();
+      stage_hid<4>(stZ, 80, row, q, dz1[0]);
+      stage_hid<4>(stX, 80, row, q, a1[0]);
+      BSYNC();
+      dw_accum<NH1, WAVES>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
+      db1 += col_sum_part<WAVES>(stZ, 80, 64, tid);
+      gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
+      float dz0[NT][16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+      BSYNC();
+      stage_hid<4>(stZ, 80, row, q, dz0[0]);
+      // X = [pe(12) | base-MLP output slots(16)] : 28 columns, 28..31 zero
+#pragma unroll
+      for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 3 * q + s] = in27[0][s];
+      *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
+      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      BSYNC();
+      dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
+      db0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
+      gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
+    };
+    if constexpr (PART == 0) {
+      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+      relu_to<4, NT>(a1h, t4);
+      gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+      relu_to<4, NT>(a2h, t4);
+      gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+      fl4[0][0] = *reinterpret_cast<const v4f*>(io.feat_logits_in + n * 16 + 4 * q);  // saved by the forward pass
+      HeadState<NT> hs;
+      head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
+      float hdir[NT][4];
+      if (SPEC) {
+        v4f d4[NT][1];
+        gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+        relu_to<1, NT>(hdir, d4);
+      }
+      // =================== phase A: band tiles (mixing + specular tail) ============================
+      v4f dm4[NT][1], dhd4[NT][1];
+      dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      float ds1 = 0.0f;
+      BSYNC();  // previous tile's staging reads are done
+      for (int t = 0; t < TB; ++t) {
+        float dsp[NT][4];
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = 16 * t + 4 * q + r;
+          dsp[0][r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
+        }
+        gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+        if (SPEC) {
+          v4f sc[NT][1];
+          gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+          float dzd[NT][4];
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sp = sigmoidf_(sc[0][0][r]);
+            ds1 += dsp[0][r] * sp;
+            dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
+          }
+          gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
+          *reinterpret_cast<v4f*>(stZd + row * FSd + swz(row) + 16 * t + 4 * q) = v4f{dzd[0][0], dzd[0][1], dzd[0][2], dzd[0][3]};
+        }
+      }
+      if (SPEC) *reinterpret_cast<v4f*>(stXh + row * 48 + swz(row) + 4 * q) = v4f{hdir[0][0], hdir[0][1], hdir[0][2], hdir[0][3]};
+      *reinterpret_cast<v4f*>(stXm + row * 48 + swz(row) + 4 * q) = v4f{hs.m[0][0], hs.m[0][1], hs.m[0][2], hs.m[0][3]};
+      ds1 = xq_sum(ds1);
+      BSYNC();
+      if (SPEC) {
+        dw_accum<NA, WAVES>(aD1, stZd, FSd, stXh, 48, TB, 1, wave, lane);
+        dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
+      }
+      {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: its rows are samples)
+        // Branch-free clamped addresses, U k-steps of loads in flight, one batch ahead of their MFMAs: a conditional load per
+        // MFMA made hipcc wait for global memory (s_waitcnt vmcnt(0)) 32 times per round.
+        const float* __restrict__ pm = stXm + q * 48 + j + 4 * (q >> 1);
+        constexpr int U = 8, NBAT = (4 * WAVES) / U;
+        float ga[2][U][NA], gb[2][U];
+        int bcol[NA];
+        bool bok[NA];
+  #pragma unroll
+        for (int idx = 0; idx < NA; ++idx) {
+          const int to = wave + idx * WAVES, b = 16 * to + j;
+          bok[idx] = to < TB && b < B;
+          bcol[idx] = bok[idx] ? b : 0;
+        }
+        auto fetch = [&](int batch, int slot) __attribute__((always_inline)) {
+  #pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int ks = batch * U + u;
+            const int64_t ns = n0 + 4 * ks + q;
+            const int64_t nsc = ns < io.n ? ns : io.n - 1;
+            gb[slot][u] = ns < io.n ? pm[4 * ks * 48 + 8 * (ks & 1)] : 0.0f;  // rows past the end carry zero weight
+  #pragma unroll
+            for (int idx = 0; idx < NA; ++idx) ga[slot][u][idx] = io.d_spectral[nsc * B + bcol[idx]];
+          }
+        };
+        fetch(0, 0);
+  #pragma unroll
+        for (int batch = 0; batch < NBAT; ++batch) {
+          if (batch + 1 < NBAT) fetch(batch + 1, (batch + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0x7ff & ~0x1b0);  // loads (VMEM / LDS reads) keep their place
+  #pragma unroll
+          for (int u = 0; u < U; ++u)
+  #pragma unroll
+            for (int idx = 0; idx < NA; ++idx)
+              if (wave + idx * WAVES < TB) aMX[idx] = MFMA(bok[idx] ? ga[batch & 1][u][idx] : 0.0f, gb[batch & 1][u], aMX[idx]);
+        }
+      }
+      // =================== phase B: heads ===========================================================
+      float dhs[NT][4], dfl[NT][4];
+      {
+        const float inv_t = 1.0f / io.temperature;
+        float da[4], dot = 0.0f;
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dmr = dm4[0][0][r];
+          const float dsg = dmr * hs.ab[0][r];
+          dhs[0][r] = dsg * hs.sg[0][r] * (1.0f - hs.sg[0][r]);
+          da[r] = (4 * q + r < C) ? dmr * hs.sg[0][r] : 0.0f;
+          dot += hs.ab[0][r] * da[r];
+        }
+        dot = xq_sum(dot);
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) * inv_t : 0.0f;
+          if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
+          dfl[0][r] = g;
+          if (c >= C) dhs[0][r] = 0.0f;
+        }
+      }
+      if (ok) *reinterpret_cast<v4f*>(io.d_fl + n * 16 + 4 * q) = v4f{dfl[0][0], dfl[0][1], dfl[0][2], dfl[0][3]};
+      if (SPEC) {  // mlp_directional hidden layer: dZ = d_hd * [hd > 0]; X = dir28 (staging order = reference order)
+        float dz[4];
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
+        BSYNC();
+        *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dz[0], dz[1], dz[2], dz[3]};
+        *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 4 * q) = v4f{dir28[0][0], dir28[0][1], dir28[0][2], dir28[0][3]};
+  #pragma unroll
+        for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 16 + 3 * q + s] = dir28[0][4 + s];
+        if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        BSYNC();
+        dw_accum<1, WAVES>(aD0, stZ, 48, stX, 48, 1, 2, wave, lane);
+        dbD0 += col_sum_part<WAVES>(stZ, 48, 16, tid);
+      }
+      mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
+      if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
+    } else {
+      float dfl[NT][4];
+      const v4f g = *reinterpret_cast<const v4f*>(io.d_fl + n * 16 + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dfl[0][r] = ok ? g[r] : 0.0f;  // rows past the end must not contribute
+      {
+        float a1f[NT][16], a2f[NT][16];
+        gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+        relu_to<4, NT>(a1f, t4);
+        gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+        relu_to<4, NT>(a2f, t4);
+        mlp3_bwd(dfl, a2f, a1f, aF2, aF1, aF0, dbF2, dbF1, dbF0, T_F2, T_F1, T_F0);
+      }
+      if (ok) *reinterpret_cast<v4f*>(io.d_bo2 + n * 16 + 4 * q) = dbo4[0][0];
+    }
+  }
+  float* const slab = slabs + (size_t)blockIdx.x * sl.total;
+  if constexpr (PART == 0) {
+    store_acc(aH0, slab, sl.off[L_H0], wave, lane), store_acc(aH1, slab, sl.off[L_H1], wave, lane);
+    store_acc(aH2, slab, sl.off[L_H2], wave, lane), store_acc(aD0, slab, sl.off[L_D0], wave, lane);
+    store_acc(aD1, slab, sl.off[L_D1], wave, lane), store_acc(aMX, slab, sl.off[L_MX], wave, lane);
+  } else {
+    store_acc(aF0, slab, sl.off[L_F0], wave, lane), store_acc(aF1, slab, sl.off[L_F1], wave, lane);
+    store_acc(aF2, slab, sl.off[L_F2], wave, lane);
+  }
+  BSYNC();  // staging region is free: reuse it for the bias fold
+  if constexpr (PART == 0) {
+    flush_db<WAVES>(dbH0, st, slab + sl.off_db[L_H0], sl.cols[L_H0], tid);
+    flush_db<WAVES>(dbH1, st, slab + sl.off_db[L_H1], sl.cols[L_H1], tid);
+    flush_db<WAVES>(dbH2, st, slab + sl.off_db[L_H2], sl.cols[L_H2], tid);
+    if (SPEC) {
+      flush_db<WAVES>(dbD0, st, slab + sl.off_db[L_D0], sl.cols[L_D0], tid);
+      flush_db<WAVES>(dbD1, st, slab + sl.off_db[L_D1], sl.cols[L_D1], tid);
+    }
+  } else {
+    flush_db<WAVES>(dbF0, st, slab + sl.off_db[L_F0], sl.cols[L_F0], tid);
+    flush_db<WAVES>(dbF1, st, slab + sl.off_db[L_F1], sl.cols[L_F1], tid);
+    flush_db<WAVES>(dbF2, st, slab + sl.off_db[L_F2], sl.cols[L_F2], tid);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // base
 // ---------------------------------------------------------------------------------------------
 template <int WAVES>
@@ -910,7 +1198,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     relu_to<4, NT>(h, t4);
     float dzb1[NT][4];
     {
-      const v4f g = ok ? *reinterpret_cast<const v4f*>(io.d_bo + n * 16 + 4 * q) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      v4f g = ok ? *reinterpret_cast<const v4f*>(io.d_bo + n * 16 + 4 * q) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      if (io.d_bo2 && ok) g += *reinterpret_cast<const v4f*>(io.d_bo2 + n * 16 + 4 * q);  // split heads: feature_mlp's share
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float gr = g[r];
@@ -1127,7 +1416,7 @@ extern "C" int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_fiel
 extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
                               int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
                               const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
-                              float* spectral, float* spectral2, float* specular, float* abundances,
+                              float* spectral, float* spectral2, float* specular, float* abundances, float* feat_logits,
                               void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
@@ -1144,7 +1433,7 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
-  io.specular = specular, io.abund = abundances;
+  io.specular = specular, io.abund = abundances, io.feat_logits = dens ? nullptr : feat_logits;
   io.stagger = getenv("UMHS_FWD_STAGGER") ? atoi(getenv("UMHS_FWD_STAGGER")) : 0;
   const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
   static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;  // tuning knob
@@ -1185,7 +1474,17 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   return UMHS_OK;
 }
 
+struct PartPlan {  // one half of the split heads backward: rebased descriptors + how to assemble its LDS image
+  PackDesc pd;
+  TPackDesc td;
+  ImgSegs seg_f, seg_t;
+  int wt_off, stage_off;
+  size_t lds;
+};
+
 struct BwdPlan {
+  bool split;        // B <= 32, 8 waves: the heads backward runs as two kernels with all packs LDS-resident
+  PartPlan part[2];
   int TB, waves, NA, FSd, S, first;
   PackDesc pd_all, pd_base;
   TPackDesc td;
@@ -1242,6 +1541,56 @@ static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p,
   }
   td->total = off;
 
+  // ---- split heads backward (see field_bwd_part_kernel) ----------------------------------------
+  pl->split = false;
+  if (pl->waves == 8) {
+    const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1, L_MX}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
+    const int fl1[] = {L_F0, L_F1}, tl1[] = {T_F2, T_F1, T_F0};
+    bool fits = true;
+    for (int part = 0; part < 2; ++part) {
+      PartPlan& pp = pl->part[part];
+      pp.pd = pl->pd_all, pp.td = *td;
+      pp.seg_f.n = pp.seg_t.n = 0;
+      const int* fl = part == 0 ? fl0 : fl1;
+      const int nfl = part == 0 ? 6 : 2;
+      const int* tl = part == 0 ? tl0 : tl1;
+      const int ntl = part == 0 ? 5 : 3;
+      auto add = [](ImgSegs& sg, int src, int dst, int len) {
+        if (len == 0) return;
+        if (sg.n && sg.src[sg.n - 1] + sg.len[sg.n - 1] == src && sg.dst[sg.n - 1] + sg.len[sg.n - 1] == dst) {
+          sg.len[sg.n - 1] += len;
+          return;
+        }
+        sg.src[sg.n] = src, sg.dst[sg.n] = dst, sg.len[sg.n] = len, ++sg.n;
+      };
+      int cur = 0;
+      for (int i = 0; i < nfl; ++i) {  // weights, then biases, in the kernel's own compact image
+        const LayerDesc& L = pl->pd_all.L[fl[i]];
+        const int len = L.OT * ((L.KS + 3) / 4) * 256;
+        add(pp.seg_f, L.off_w, cur, len);
+        pp.pd.L[fl[i]].off_w = cur, cur += len;
+      }
+      for (int i = 0; i < nfl; ++i) {
+        if (fl[i] == L_MX) continue;
+        const LayerDesc& L = pl->pd_all.L[fl[i]];
+        add(pp.seg_f, L.off_b, cur, 16 * L.OT);
+        pp.pd.L[fl[i]].off_b = cur, cur += 16 * L.OT;
+      }
+      pp.wt_off = (cur + 3) & ~3;
+      cur = 0;
+      for (int i = 0; i < ntl; ++i) {
+        const TDesc& T = td->L[tl[i]];
+        const int len = T.OT * ((T.KS + 3) / 4) * 256;
+        add(pp.seg_t, T.off, cur, len);
+        pp.td.L[tl[i]].off = cur, cur += len;
+      }
+      pp.stage_off = (pp.wt_off + cur + 3) & ~3;
+      pp.lds = (size_t)(pp.stage_off + stage_floats(128)) * 4;
+      if (pp.lds > 160 * 1024 || pp.seg_f.n > 6 || pp.seg_t.n > 6) fits = false;
+    }
+    pl->split = fits;
+  }
+
   SlabLayout* sl = &pl->sl;
   const int W = pl->waves;
   const int TOs[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1, 1, TB, TB};
@@ -1272,7 +1621,7 @@ static unsigned bwd_grid(int64_t n, int S) {
 }
 
 static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
-  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 16 + pl.pd_all.total) * 4 + 2048;
+  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 48 + pl.pd_all.total) * 4 + 4096;
 }
 
 // The weight images of the backward (transposed packs + forward pack image) depend on the parameters only: a caller may build
@@ -1310,8 +1659,8 @@ extern "C" size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int6
 
 extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
                               int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
-                              const float* selector, const float* sigma_raw, const float* emb, int64_t n,
-                              const float* d_sigma, const float* d_spectral, const float* d_emb_ext, float* d_enc,
+                              const float* selector, const float* sigma_raw, const float* emb, const float* feat_logits,
+                              int64_t n, const float* d_sigma, const float* d_spectral, const float* d_emb_ext, float* d_enc,
                               const umhs_field_grads* grads, void* workspace, size_t workspace_bytes, int packs_ready,
                               umhs_stream_t stream) {
   int rc = check_cfg(cfg);
@@ -1333,6 +1682,10 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   float* img = wT + ((pl.td.total + 63) & ~63);
   float* slabs = img + ((pl.pd_all.total + 63) & ~63);
   float* d_bo = slabs + (((size_t)grid * pl.sl.total + 63) & ~(size_t)63);
+  float* d_bo2 = d_bo + (((size_t)n * 16 + 63) & ~(size_t)63);
+  float* d_fl = d_bo2 + (((size_t)n * 16 + 63) & ~(size_t)63);
+  static const int no_split = getenv("UMHS_BWD_NO_SPLIT") ? atoi(getenv("UMHS_BWD_NO_SPLIT")) : 0;  // A/B knob
+  const bool split = pl.split && feat_logits != nullptr && !no_split;
   if (!packs_ready) {
     hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
     hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all,
@@ -1359,7 +1712,26 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
     else                                 \
       LAUNCH_HEADS(false, NA_, W_);      \
   } while (0)
-  if (pl.waves == 8) {
+  if (split) {
+    io.feat_logits_in = feat_logits, io.d_fl = d_fl, io.d_bo2 = d_bo2;
+#define LAUNCH_PART(P_, S_)                                                                                              \
+  do {                                                                                                                   \
+    const PartPlan& pp = pl.part[P_];                                                                                    \
+    rc = set_lds(field_bwd_part_kernel<P_, S_>, pp.lds);                                                                 \
+    if (rc) return rc;                                                                                                   \
+    hipLaunchKernelGGL((field_bwd_part_kernel<P_, S_>), dim3(grid), dim3(512), pp.lds, umhs_s(stream), io, pp.pd, pp.td, \
+                       pl.sl, slabs, pp.wt_off, pp.stage_off, pl.FSd, (const float*)img, (const float*)wT, pp.seg_f,     \
+                       pp.seg_t);                                                                                        \
+  } while (0)
+    if (spec) {
+      LAUNCH_PART(0, true);
+      LAUNCH_PART(1, true);
+    } else {
+      LAUNCH_PART(0, false);
+      LAUNCH_PART(1, false);
+    }
+#undef LAUNCH_PART
+  } else if (pl.waves == 8) {
     LAUNCH_HEADS_S(1, 8);
   } else if (pl.NA == 2) {
     LAUNCH_HEADS_S(2, 4);

@@ -215,11 +215,12 @@ def field_bwd_prepare(spec: FieldSpec, flat, n: int):
     _hip.check(_hip.lib().umhs_field_bwd_prepare(C.byref(cfg), C.byref(pp), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_bwd_prepare")
 
 
-def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb=False, want_aux=True):
+def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb=False, want_aux=True, want_logits=False):
     L = spec.layout
     new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
     out = dict(sigma=new(n), sigma_raw=new(n), emb=new(n, GEO_FEAT_DIM) if (want_emb or density_only) else None, spectral=None,
-               spectral2=None, specular=None, abundances=None)
+               spectral2=None, specular=None, abundances=None,
+               feat_logits=new(n, 16) if (want_logits and not density_only) else None)  # saved for the split heads backward
     if not density_only:
         out["spectral"] = new(n, L.wavelengths)
         if want_aux:
@@ -230,7 +231,7 @@ def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb
 
 
 def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True, pack_ready=False,
-              out=None, part=None):
+              out=None, part=None, want_logits=False):
     """part = (offset, count): evaluate only that range of samples, writing into the full-size tensors of ``out``."""
     n = sel.shape[0]
     L = spec.layout
@@ -238,14 +239,15 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
     cfg = spec.cfg(density_only)
     pp = L.c_struct(flat, _hip.FieldParams)
     sn, sl = enc_strides(n, level_major)
-    o = out if out is not None else field_fwd_outputs(spec, n, dev, density_only, want_emb, want_aux)
+    o = out if out is not None else field_fwd_outputs(spec, n, dev, density_only, want_emb, want_aux, want_logits)
     off, cnt = part if part is not None else (0, n)
     at = lambda t, width: (t.data_ptr() + 4 * width * off) if t is not None else None
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_fwd(C.byref(cfg), C.byref(pp), at(enc, sn), sn, sl, at(wpos, 3), at(dirs, 3), at(sel, 1), cnt,
                                          at(o["sigma"], 1), at(o["sigma_raw"], 1), at(o["emb"], GEO_FEAT_DIM), at(o["spectral"], L.wavelengths),
                                          at(o["spectral2"], L.wavelengths), at(o["specular"], L.wavelengths),
-                                         at(o["abundances"], L.num_classes), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()),
+                                         at(o["abundances"], L.num_classes), at(o.get("feat_logits"), 16), ptr(ws), ws.numel(), int(pack_ready),
+                                         _hip.stream()),
                "umhs_field_fwd")
     return o
 
@@ -263,7 +265,7 @@ def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
 
 
 def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
-              packs_ready=False):
+              packs_ready=False, feat_logits=None):
     """Writes d_enc (returned) and the MLP / endmember gradients straight into ``d_flat`` (flat layout)."""
     n = sel.shape[0]
     L = spec.layout
@@ -275,7 +277,7 @@ def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_ra
     nbytes = _hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n)
     ws = _workspace(nbytes, sel.device)
     _hip.check(_hip.lib().umhs_field_bwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel),
-                                         ptr(sigma_raw), ptr(emb), n,
+                                         ptr(sigma_raw), ptr(emb), ptr(feat_logits), n,
                                          ptr(d_sigma), ptr(d_spectral), ptr(d_emb), ptr(d_enc), C.byref(gp), ptr(ws),
                                          ws.numel(), int(packs_ready), _hip.stream()), "umhs_field_bwd")
     return d_enc
@@ -405,7 +407,7 @@ def ssim(a, b, data_range=None):
 
 
 def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb,
-                        prepared: bool = False):
+                        prepared: bool = False, feat_logits=None):
     """``prepared``: field_bwd_prepare and hashgrid_bwd_prepare (all levels) already ran for this step's parameters/positions.
     Backward of the field (field_bwd + hash-grid scatter) into the flat gradient.  With a gradient sink that owns the next
     backward the buffer becomes ``param.grad`` directly, finished segments start their all-reduce, and None is returned;
@@ -418,7 +420,7 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
     tail = L.offset("mlp_base.mlp.layers.0.weight")
     d_flat[tail:].zero_()  # MLP / endmember segments (+ alignment padding)
     d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
-                      packs_ready=prepared)
+                      packs_ready=prepared, feat_logits=feat_logits)
     if own:
         sink.segment_done(d_flat[tail:])
     table = L.view(d_flat, "mlp_base.encoder.hash_table")
@@ -508,9 +510,10 @@ class FieldFn(torch.autograd.Function):
         wpos, pos01, sel = positions_fwd(o, d, s, e, spec)
         table = L.view(flat.detach(), "mlp_base.encoder.hash_table")
         enc = hashgrid_fwd(pos01, table, spec.scalings, L.log2_hashmap_size, True)
-        out = field_fwd(spec, flat.detach(), enc, True, wpos, d, sel, want_emb=True)
+        out = field_fwd(spec, flat.detach(), enc, True, wpos, d, sel, want_emb=True, want_logits=flat.requires_grad)
         ctx.spec = spec
-        ctx.save_for_backward(flat, pos01, sel, wpos, d, enc, out["sigma_raw"], out["emb"])
+        ctx.has_logits = out["feat_logits"] is not None
+        ctx.save_for_backward(flat, pos01, sel, wpos, d, enc, out["sigma_raw"], out["emb"], *([out["feat_logits"]] if ctx.has_logits else []))
         n = o.shape[0]
         res = [out["sigma"].view(n, 1), out["emb"], out["spectral"], out["spectral2"], out["specular"], out["abundances"]]
         ctx.mark_non_differentiable(*[t for t in res[3:] if t is not None])
@@ -518,7 +521,8 @@ class FieldFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_sigma, d_emb, d_spectral, *_):
-        flat, pos01, sel, wpos, d, enc, sigma_raw, emb = ctx.saved_tensors
+        flat, pos01, sel, wpos, d, enc, sigma_raw, emb, *rest = ctx.saved_tensors
+        logits = rest[0] if ctx.has_logits else None
         spec: FieldSpec = ctx.spec
         L = spec.layout
         n = sel.shape[0]
@@ -526,7 +530,7 @@ class FieldFn(torch.autograd.Function):
         d_sigma = _hip.f32c(d_sigma).view(-1) if d_sigma is not None else zeros(n)
         d_spectral = _hip.f32c(d_spectral) if d_spectral is not None else zeros(n, L.wavelengths)
         d_emb = _hip.f32c(d_emb) if d_emb is not None else None
-        d_flat = field_backward_into(spec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb)
+        d_flat = field_backward_into(spec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb, feat_logits=logits)
         return d_flat, None, None, None, None, None
 
 

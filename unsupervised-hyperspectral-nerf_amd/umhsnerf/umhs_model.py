@@ -330,7 +330,7 @@ class UMHSModel(nn.Module):
         enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
         if side is not None:
             main.wait_event(ev_pack)
-        fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None)
+        fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
         values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
         weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
         if side is not None:
@@ -350,7 +350,7 @@ class UMHSModel(nn.Module):
         d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
                                               bool(c.use_gradient_scaling))
         left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_values[0], None,
-                                       prepared=prepared)
+                                       prepared=prepared, feat_logits=fo["feat_logits"])
         assert left is None  # direct_step_supported() guarantees the sink owned this backward
         outputs = self._assemble_outputs(acc.view(-1, 1), depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights.view(-1, 1),
                                          lazy_bands=True)
