@@ -573,19 +573,37 @@ __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restri
   }
 }
 
-// partial column sum of a staged tile: thread -> (column, row group); the slab reduce adds the row groups
-template <int WAVES>
+// partial column sum of a staged tile: thread -> (column, row group); the slab reduce adds the row groups.
+// COLS > 0 (split kernels, which have registers to spare): compile-time width -> the row loop is fully unrolled with 4 LDS reads
+// in flight and one base address + immediate offsets (as a runtime loop hipcc serialises read -> wait -> add, ~100 cycles a row).
+template <int WAVES, int COLS = 0>
 __device__ __forceinline__ float col_sum_part(const float* __restrict__ st, int FS, int cols, int tid) {
 #ifdef UMHS_ABL_NO_DW
   return 0.0f;
 #endif
   constexpr int S = 16 * WAVES, NTH = 64 * WAVES;
-  const int RG = NTH / cols, rg = tid / cols, col = tid - rg * cols;
-  if (rg >= RG) return 0.0f;
-  const int rpg = (S + RG - 1) / RG, r0 = rg * rpg, r1 = min(S, r0 + rpg);
-  float s = 0.0f;
-  for (int r = r0; r < r1; ++r) s += st[r * FS + swz(r) + col];
-  return s;
+  if constexpr (COLS > 0) {
+    constexpr int RG = NTH / COLS, RPG = (S + RG - 1) / RG;
+    static_assert(S % RG == 0 && (RPG % 8 == 0 || RPG == 4), "row groups must keep the swizzle phase compile-time");
+    const int rg = tid / COLS, col = tid - rg * COLS;
+    const float* __restrict__ pb = st + rg * RPG * FS + col + (RPG == 4 ? 8 * (rg & 1) : 0);
+    float s = 0.0f;
+#pragma unroll
+    for (int i0 = 0; i0 < RPG; i0 += 4) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = pb[(i0 + i) * FS + 4 * (((i0 + i) >> 1) & 3)];
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    return s;
+  } else {
+    const int RG = NTH / cols, rg = tid / cols, col = tid - rg * cols;
+    if (rg >= RG) return 0.0f;
+    const int rpg = (S + RG - 1) / RG, r0 = rg * rpg, r1 = min(S, r0 + rpg);
+    float s = 0.0f;
+    for (int r = r0; r < r1; ++r) s += st[r * FS + swz(r) + col];
+    return s;
+  }
 }
 
 // epilogue: fold a per-thread partial bias sum (thread = row group x column) over the row groups in LDS and write
@@ -964,7 +982,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       stage_hid<4>(stX, 80, row, q, a2[0]);
       BSYNC();
       dw_accum<1, WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
-      db2 += col_sum_part<WAVES>(stZ, 48, 16, tid);
+      db2 += col_sum_part<WAVES, 16>(stZ, 48, 16, tid);
       v4f g4[NT][4];
       gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
       float dz1[NT][16];
@@ -975,7 +993,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       stage_hid<4>(stX, 80, row, q, a1[0]);
       BSYNC();
       dw_accum<NH1, WAVES>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
-      db1 += col_sum_part<WAVES>(stZ, 80, 64, tid);
+      db1 += col_sum_part<WAVES, 64>(stZ, 80, 64, tid);
       gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
       float dz0[NT][16];
 #pragma unroll
@@ -989,7 +1007,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       BSYNC();
       dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
-      db0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
+      db0 += col_sum_part<WAVES, 64>(stZ, 80, 64, tid);
       gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
     };
     if constexpr (PART == 0) {
@@ -1116,7 +1134,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
         if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
         BSYNC();
         dw_accum<1, WAVES>(aD0, stZ, 48, stX, 48, 1, 2, wave, lane);
-        dbD0 += col_sum_part<WAVES>(stZ, 48, 16, tid);
+        dbD0 += col_sum_part<WAVES, 16>(stZ, 48, 16, tid);
       }
       mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
       if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
