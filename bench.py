@@ -244,12 +244,13 @@ def main():
                 pmc = json.load(f)["kernels"]
         except Exception:
             pass
-        op_kernels = {"field_bwd": ("field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce_kernel", "field_pack"),
+        op_kernels = {"field_bwd": ("field_bwd_part_kernel", "field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce_kernel"),
                       "field_fwd": ("field_fwd_kernel", "field_pack_fwd"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
                       "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"),
                       "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel"), "adam_step": ("adam_kernel",)}
         traffic = sum(v["hbm_traffic_bytes"] for k, v in pmc.items() if any(k.startswith(p_) for p_ in op_kernels.get(dom, ()))) or None
-        busy = [v["mfma_util"] for k, v in pmc.items() if k.startswith("field_bwd_heads" if dom == "field_bwd" else "field_fwd_kernel")]
+        busy = [v["mfma_util"] for k, v in pmc.items() if "mfma_util" in v and
+                k.startswith(("field_bwd_part_kernel<0", "field_bwd_heads") if dom == "field_bwd" else "field_fwd_kernel")]
         roof = None
         if dom in alg:
             ach = alg[dom] / (ksum[dom][0] * 1e-3) / 1e9
@@ -260,7 +261,7 @@ def main():
             flops = {"field_fwd": fwd_flop * N, "field_bwd": 2 * fwd_flop * N}.get(dom)  # backward = dX + dW = 2x forward
             if flops:
                 ach = flops / (ksum[dom][0] * 1e-3) / 1e12
-                roof = dict(bound="mfma", kernel=dom + " (heads+base kernels, pack, slab reduce)" if dom == "field_bwd" else dom,
+                roof = dict(bound="mfma", kernel=dom + " (two heads kernels + base kernel + slab reduce)" if dom == "field_bwd" else dom,
                             achieved=round(ach, 2), peak=157.3, unit="TFLOP/s", frac=round(ach / 157.3, 4), traffic=traffic,
                             avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1],
                             mfma_busy_frac_pmc=(busy[0] if busy else None),
