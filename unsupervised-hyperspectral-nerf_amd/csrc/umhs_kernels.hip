@@ -717,6 +717,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
                                                             const float* __restrict__ d_acc, int grad_scaling,
                                                             float* __restrict__ d_sigma) {
   const int lane = threadIdx.x & 63;
+  __shared__ float lds_tile[4][64 * 33 + 64 + 32];  // per wave: [64][33] value tile, 64 weights, 32 upstream gradients
+  float* const tile = lds_tile[threadIdx.x >> 6];
+  float* const wsl = tile + 64 * 33;
+  float* const dl = wsl + 64;
   const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (r >= n_rays) return;
   const int64_t start = pinfo[2 * r];
@@ -752,6 +756,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
       dw = dacc;
       for (int s = 0; s < gr.n; ++s) {
         const int K = gr.k[s];
+        if (K <= 32) continue;  // narrow streams go through the LDS tile below
         const float* __restrict__ vrow = gr.v[s] + nidx * (int64_t)K;
         const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
         float d0 = 0.0f, d1 = 0.0f;
@@ -764,6 +769,32 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         dw += d0 + d1;
       }
     }
+    const int nvalid = min(64, cnt - c * 64);
+    // K <= 32: the chunk's [nvalid x K] rows are ONE contiguous block -> read it with full 256-byte wave loads into an LDS
+    // tile (row stride K|1: odd, so the per-lane row walk below is bank-conflict free) instead of 64 rows x K strided dwords
+    for (int s = 0; s < gr.n; ++s) {
+      const int K = gr.k[s];
+      if (K > 32) continue;
+      const int KS = K | 1;
+      const float* __restrict__ vb = gr.v[s] + (start + c * 64) * (int64_t)K;
+      const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
+      const int tot = nvalid * K;
+      for (int e = lane; e < tot; e += 64) {
+        const int jj = e / K;
+        tile[jj * KS + (e - jj * K)] = vb[e];
+      }
+      if (lane < K) dl[lane] = drow[lane];
+      if (valid) {
+        float d0 = 0.0f, d1 = 0.0f;
+        int k = 0;
+        for (; k + 1 < K; k += 2) {
+          d0 += dl[k] * tile[lane * KS + k];
+          d1 += dl[k + 1] * tile[lane * KS + k + 1];
+        }
+        if (k < K) d0 += dl[k] * tile[lane * KS + k];
+        dw += d0 + d1;
+      }
+    }
     float p = dw * w;
     float suf = wave_inclusive_scan_rev(p, lane);
     float S = carry_after + (suf - p);
@@ -771,12 +802,21 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     carry_after += __shfl(suf, 0, 64);
     // d_values[n][k] = scale_n * w_n * d_out[r][k]   (lane = band: coalesced row stores)
     const float ws = w * scale;
-    const int nvalid = min(64, cnt - c * 64);
+    wsl[lane] = ws;
     for (int s = 0; s < gr.n; ++s) {
       if (!gr.dv[s]) continue;
       const int K = gr.k[s];
       float* __restrict__ dv = gr.dv[s] + (start + c * 64) * (int64_t)K;
       const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
+      if (K <= 32) {  // the [nvalid x K] block of d_values is contiguous too: full-wave stores
+        if (lane < K) dl[lane] = drow[lane];
+        const int tot = nvalid * K;
+        for (int e = lane; e < tot; e += 64) {
+          const int jj = e / K;
+          dv[e] = wsl[jj] * dl[e - jj * K];
+        }
+        continue;
+      }
       for (int kc = 0; kc < K; kc += 64) {
         const int k = kc + lane;
         const bool kv = k < K;
