@@ -89,6 +89,9 @@ def _sink_worker(rank, world, port, out):
         p = torch.nn.Parameter(torch.zeros(64))
         sink = parallel.FlatGradSink(p, level_groups=4)
         assert sink.groups(16) == [(0, 4), (4, 4), (8, 4), (12, 4)]
+        sink.sparse_levels = 5  # the compact message of the sparse coarse levels must fit in the first group
+        assert sink.groups(16) == [(0, 8), (8, 4), (12, 4)]
+        sink.sparse_levels = 0
         for it in range(2):  # the buffer is reused from one backward to the next
             assert sink.owns_next_backward()
             buf = sink.begin()

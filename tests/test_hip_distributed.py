@@ -32,6 +32,22 @@ def test_async_segment_reduce_is_bit_identical_to_plain_allreduce():
     assert torch.equal(parts[: 12 << 19], torch.ones_like(parts[: 12 << 19]))
     torch.testing.assert_close(parts[12 << 19:], full[12 << 19:] + 1.0, rtol=1e-6, atol=1e-7)
 
+    # coarse levels: every row outside the enumerated live set keeps an exactly zero gradient (what the compact all-reduce relies on)
+    from umhsnerf import parallel
+
+    ns, rows = parallel.live_hash_rows(sc.cpu(), 19)
+    assert ns == 5 and rows.numel() == 288066
+    big = torch.rand(200000, 3, generator=g).to(dev)
+    big[:50] = 0.0  # unselected samples sit at the origin corner
+    big[50:60] = 0.999999
+    gt = torch.empty(ops.NUM_LEVELS << 19, 2, device=dev)
+    ops.hashgrid_bwd(big, torch.randn(16, 200000, 2, generator=g).to(dev), sc, 19, gt, True, overwrite=True)
+    dead = torch.ones(ns << 19, dtype=torch.bool, device=dev)
+    dead[rows.to(dev)] = False
+    assert float(gt[: ns << 19][dead].abs().max()) == 0.0 and float(gt[: ns << 19][~dead].abs().max()) > 0
+    touched = (gt[: ns << 19].abs().sum(-1) > 0)
+    assert float(touched.sum()) > 0.95 * rows.numel()  # ...and the set is tight: random positions reach nearly all of it
+
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(HERE, "dist_async_reduce_check.py")], env=env, capture_output=True, text=True,

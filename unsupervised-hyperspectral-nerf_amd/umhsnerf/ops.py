@@ -431,7 +431,7 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
         else:
             hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
         if own:
-            sink.segment_done(table[l0 * T:(l0 + cnt) * T])
+            sink.table_levels_done(table, l0, cnt)
     if own:  # the buffer becomes param.grad directly (autograd gets None: nothing to accumulate or copy)
         sink.commit()
         return None

@@ -41,6 +41,29 @@ def broadcast_params(flat: torch.Tensor, src: int = 0) -> None:
         dist.broadcast(flat, src=src)
 
 
+def live_hash_rows(scalings, log2_T: int, max_fill: float = 0.5):
+    """Rows of the hash table that can ever receive a gradient, for the leading (coarse) levels whose (res+1)^3 grid corners
+    occupy at most ``max_fill`` of the 2^log2_T slots.  A corner (x, y, z), 0 <= x,y,z <= res = scalings[l], lives in slot
+    (x ^ y*2654435761 ^ z*805459861) mod T (nerfstudio HashEncoding.hash_fn, uint32 wrap-around); every other slot of such a level
+    keeps an exactly zero gradient on every rank, so it need not travel in the all-reduce.  -> (n_sparse_levels, int64 rows)."""
+    import numpy as np
+
+    T = 1 << log2_T
+    rows, n_sparse = [], 0
+    for l, s in enumerate([int(v) for v in scalings.tolist()]):
+        if (s + 1) ** 3 > max_fill * T:
+            break
+        c = np.arange(s + 1, dtype=np.uint64)
+        x, y, z = np.meshgrid(c, (c * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF), (c * np.uint64(805459861)) & np.uint64(0xFFFFFFFF),
+                              indexing="ij")
+        slot = np.unique((x ^ y ^ z) & np.uint64(T - 1)).astype(np.int64)
+        rows.append(slot + l * T)
+        n_sparse = l + 1
+    if not rows:
+        return 0, torch.empty(0, dtype=torch.int64)
+    return n_sparse, torch.from_numpy(np.concatenate(rows))
+
+
 class FlatGradSink:
     """Persistent flat gradient buffer for the "fields" parameter, with early reduction of finished segments.
 
@@ -59,6 +82,16 @@ class FlatGradSink:
         self.level_groups = int(level_groups if level_groups is not None else os.environ.get("UMHS_REDUCE_GROUPS", "2"))
         self.async_reduce = os.environ.get("UMHS_ASYNC_REDUCE", "1") != "0"
         self.reduced_ptr = None
+        self.sparse_levels, self.sparse_rows = 0, None  # set_sparse_levels(): coarse levels travel as their live rows only
+
+    def set_sparse_levels(self, scalings, log2_T: int) -> None:
+        """Coarse hash levels use a small, rank-independent subset of their 2^log2_T slots (4,913 of 524,288 at level 0): send the
+        live rows of those levels as one compact message instead of their whole slabs (-15 MB of 67 MB at the reference sizes)."""
+        if os.environ.get("UMHS_SPARSE_REDUCE", "1") == "0":
+            return
+        self.sparse_levels, rows = live_hash_rows(scalings, log2_T)
+        self.sparse_rows = rows.to(self.param.device) if self.sparse_levels else None
+        self.table_rows = 1 << log2_T
 
     def owns_next_backward(self) -> bool:
         return self.param.grad is None
@@ -75,12 +108,32 @@ class FlatGradSink:
         if world()[1] == 1 or not self.async_reduce:
             return [(0, n_levels)]
         g = max(1, n_levels // self.level_groups)
-        return [(l, min(g, n_levels - l)) for l in range(0, n_levels, g)]
+        out = [(l, min(g, n_levels - l)) for l in range(0, n_levels, g)]
+        while len(out) > 1 and out[0][1] < self.sparse_levels:  # the compact message needs all sparse levels in the first group
+            out[0:2] = [(0, out[0][1] + out[1][1])]
+        return out
 
     def segment_done(self, view: torch.Tensor) -> None:
         if world()[1] > 1 and self.async_reduce:
             off = (view.data_ptr() - self.buffer.data_ptr()) // self.buffer.element_size()
-            self.works.append((off, off + view.numel(), dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)))
+            self.works.append((off, off + view.numel(), dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), None))
+
+    def table_levels_done(self, table: torch.Tensor, l0: int, cnt: int) -> None:
+        """Levels [l0, l0+cnt) of the table gradient ([L*T, 2] view of the buffer) are final: start their reduction."""
+        if not (world()[1] > 1 and self.async_reduce):
+            return
+        T, ns = getattr(self, "table_rows", 0), self.sparse_levels
+        lo, hi = l0, l0 + cnt
+        if ns and lo < ns:  # the sparse levels of this group: one compact message (needs the whole sparse range in one group)
+            if lo != 0 or hi < ns:
+                raise RuntimeError("sparse hash levels must be finished by the first level group")
+            compact = table.index_select(0, self.sparse_rows)
+            off = (table.data_ptr() - self.buffer.data_ptr()) // self.buffer.element_size()
+            w = dist.all_reduce(compact, op=dist.ReduceOp.SUM, async_op=True)
+            self.works.append((off, off + ns * T * table.shape[1], w, (table, compact)))
+            lo = ns
+        if lo < hi:
+            self.segment_done(table[lo * T:hi * T])
 
     def commit(self) -> None:
         self.param.grad = self.buffer
@@ -97,8 +150,11 @@ class FlatGradSink:
             raise RuntimeError("param.grad is not the buffer that was reduced (was .grad replaced after backward?)")
         works, self.works = self.works, []
         covered = 0
-        for a, b, w in works:
+        for a, b, w, sparse in works:
             w.wait()
+            if sparse is not None:  # scatter the reduced live rows back; the other rows of these levels are zero on every rank
+                table, compact = sparse
+                table.index_copy_(0, self.sparse_rows, compact)
             covered += b - a
             yield a, b
         if covered != grad.numel():

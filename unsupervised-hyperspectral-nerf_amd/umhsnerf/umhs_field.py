@@ -128,6 +128,7 @@ class UMHSField(nn.Module):
             from .parallel import FlatGradSink
 
             self._grad_sink = FlatGradSink(self.flat)
+            self._grad_sink.set_sparse_levels(self.scalings, self.layout.log2_hashmap_size)
             self.flat._umhs_grad_sink = self._grad_sink
         c.grad_sink = self._grad_sink if self.use_grad_sink else None
         return c
