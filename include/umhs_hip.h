@@ -308,6 +308,11 @@ int umhs_ssim(const float* a, const float* b, int height, int width, int n_chann
 int umhs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, int64_t step, float grad_scale, int64_t clamp_begin,
                    int64_t clamp_end, umhs_stream_t stream);
+/* The same update on selected 2-float rows of the buffers only (rows: device int64 [n_rows], row r = elements 2r, 2r+1): the   */
+/* coarse hash levels use a small fixed subset of their slots; every other row has g = m = v = 0 for ever and is skipped.       */
+int umhs_adam_step_rows(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* rows,
+                        int64_t n_rows, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                        umhs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1453,6 +1453,46 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Adam on selected 2-float rows only (the live rows of the sparse coarse hash levels: every other row of those levels has
+// g = m = v = 0 for ever, so its update is exactly zero and it is not touched).  Same arithmetic as adam_kernel.
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, const int64_t* __restrict__ rows, int64_t n_rows,
+                                                        float lr_bc1, float b1, float b2, float eps, float sqrt_bc2, float gscale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  const int64_t o = rows[i] * 2;
+  float2 pp = *reinterpret_cast<float2*>(p + o), mm = *reinterpret_cast<float2*>(m + o), vv = *reinterpret_cast<float2*>(v + o);
+  const float2 gg = *reinterpret_cast<const float2*>(g + o);
+  float* pa = reinterpret_cast<float*>(&pp);
+  float* ma = reinterpret_cast<float*>(&mm);
+  float* va = reinterpret_cast<float*>(&vv);
+  const float ga[2] = {gg.x, gg.y};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float gk = ga[k] * gscale;
+    ma[k] = ma[k] * b1 + gk * (1.0f - b1);
+    va[k] = va[k] * b2 + gk * gk * (1.0f - b2);
+    const float denom = sqrtf(va[k]) / sqrt_bc2 + eps;
+    pa[k] = pa[k] - lr_bc1 * (ma[k] / denom);
+  }
+  *reinterpret_cast<float2*>(p + o) = pp;
+  *reinterpret_cast<float2*>(m + o) = mm;
+  *reinterpret_cast<float2*>(v + o) = vv;
+}
+
+extern "C" int umhs_adam_step_rows(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* rows,
+                                   int64_t n_rows, float lr, float beta1, float beta2, float eps, int64_t step,
+                                   float grad_scale, umhs_stream_t stream) {
+  if (n_rows < 0 || step < 1 || !params || !grads || !exp_avg || !exp_avg_sq || (n_rows > 0 && !rows)) return UMHS_ERR_ARG;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 7) return UMHS_ERR_ARG;
+  if (n_rows == 0) return UMHS_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, umhs_s(stream), params, grads,
+                     exp_avg, exp_avg_sq, rows, n_rows, (float)(lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
 extern "C" int umhs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                               float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
                               int64_t clamp_begin, int64_t clamp_end, umhs_stream_t stream) {

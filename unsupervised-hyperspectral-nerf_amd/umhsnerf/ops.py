@@ -491,6 +491,12 @@ def loss_bwd(s, g, r, a, bg, gr, w_spec: float, w_rgb: float, grad_losses):
     return d_spec, d_rgb, d_acc
 
 
+def adam_step_rows(p, g, m, v, rows, step: int, lr: float, betas=(0.9, 0.999), eps=1e-15, grad_scale=1.0):
+    """Adam on the 2-float rows ``rows`` (int64, device) of the flat buffers only."""
+    _hip.check(_hip.lib().umhs_adam_step_rows(ptr(p), ptr(g), ptr(m), ptr(v), ptr(rows), rows.numel(), lr, betas[0], betas[1], eps, step,
+                                              grad_scale, _hip.stream()), "umhs_adam_step_rows")
+
+
 # --------------------------------------------------------------------------------------------- #
 # autograd glue
 # --------------------------------------------------------------------------------------------- #

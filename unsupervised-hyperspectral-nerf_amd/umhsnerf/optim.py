@@ -43,16 +43,26 @@ class UMHSAdam(torch.optim.Optimizer):
                     lr = exp_decay_lr(st["step"] - 1, group["lr_init"], group["lr_final"], group["max_steps"])
                 sink = getattr(p, "_umhs_grad_sink", None)
                 cb, ce = group["clamp_range"]
+                sparse = getattr(p, "_umhs_live_rows", None)  # (rows int64 [n], end): elements [0, end) hold sparse hash levels
+
+                def update(a: int, b: int, scale: float) -> None:
+                    """Adam on elements [a, b) of the flat buffers; the sparse coarse levels only on their live rows."""
+                    if sparse is not None and a == 0 and b >= sparse[1] and sparse[0].device == p.device:
+                        ops.adam_step_rows(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], sparse[0], st["step"], lr, group["betas"],
+                                           group["eps"], grad_scale=scale)
+                        a = sparse[1]
+                        if a == b:
+                            return
+                    clamp = (max(cb, a) - a, min(ce, b) - a) if (cb < b and ce > a) else (0, 0)
+                    ops.adam_step(p.data[a:b], p.grad[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], st["step"], lr, group["betas"],
+                                  group["eps"], grad_scale=scale, clamp_range=clamp)
+
                 done = 0
                 if sink is not None:
                     # Segments were all-reduced while the backward was still running: update each one as soon as ITS reduction
                     # has landed, so the Adam pass of segment k hides under the transfer of segments k+1..
                     for a, b in sink.reduced_segments(p.grad):
-                        clamp = (max(cb, a) - a, min(ce, b) - a) if (cb < b and ce > a) else (0, 0)
-                        ops.adam_step(p.data[a:b], p.grad[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], st["step"], lr, group["betas"],
-                                      group["eps"], grad_scale=1.0 / world()[1], clamp_range=clamp)
+                        update(a, b, 1.0 / world()[1])
                         done += b - a
                 if done == 0:
-                    grad_scale = allreduce_flat_grad(p.grad)  # one 67 MB RCCL all-reduce over xGMI (no-op at world 1)
-                    ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, group["betas"], group["eps"],
-                                  grad_scale=grad_scale, clamp_range=group["clamp_range"])
+                    update(0, p.numel(), allreduce_flat_grad(p.grad))  # one RCCL all-reduce of the whole gradient (no-op at world 1)

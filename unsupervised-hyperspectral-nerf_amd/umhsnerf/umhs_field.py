@@ -91,6 +91,12 @@ class UMHSField(nn.Module):
             E = torch.randn(num_classes, wavelengths, generator=g)
         L.view(flat, "endmembers").copy_(E)
         self.flat = nn.Parameter(flat)
+        # coarse hash levels use a small, fixed subset of their 2^T slots: the optimizer and the gradient all-reduce skip the rest
+        from .parallel import live_hash_rows
+
+        n_sparse, rows = live_hash_rows(self.scalings, log2_hashmap_size)
+        self.register_buffer("live_rows", rows, persistent=False)
+        self._sparse_end = n_sparse * (1 << log2_hashmap_size) * ops.FEATURES_PER_LEVEL
         self._cache: Optional[Tuple] = None
         self.use_grad_sink = False  # UMHSPipeline turns this on: backward writes param.grad in place (+ early all-reduce)
         self._grad_sink = None
@@ -120,6 +126,8 @@ class UMHSField(nn.Module):
                     self.layout.view(self.flat, k).copy_(state_dict[k].to(self.flat.device))
 
     def _spec(self) -> ops.FieldSpec:
+        if self._sparse_end and os.environ.get("UMHS_SPARSE_ADAM", "1") != "0":
+            self.flat._umhs_live_rows = (self.live_rows, self._sparse_end)
         c = self._spec_cache
         if c is None or c.scalings.device != self.scalings.device or c.temperature != float(self.temperature):
             c = ops.FieldSpec(self.layout, float(self.temperature), self.spatial_distortion is not None, self._aabb_host, self.scalings)
