@@ -1079,11 +1079,17 @@ __global__ __launch_bounds__(256) void tmid_minmax_kernel(const float* __restric
   }
 }
 
+__global__ void tmid_init_kernel(uint32_t* mm) { mm[0] = 0xffffffffu, mm[1] = 0u; }
+
 extern "C" int umhs_tmid_minmax(const float* t_starts, const float* t_ends, int64_t n, float* minmax2, umhs_stream_t stream) {
   if (n < 0 || !minmax2 || (n > 0 && (!t_starts || !t_ends))) return UMHS_ERR_ARG;
-  const uint32_t init[2] = {0xffffffffu, 0u};
-  if (hipMemcpyAsync(minmax2, init, 8, hipMemcpyHostToDevice, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
-  if (n == 0) return UMHS_OK;
+  // identity of (min, max) in the ordered encoding; a 1-thread kernel, not a host-to-device copy of a stack variable (that blit
+  // queued behind whatever else the device was running: 70 us on a side stream)
+  hipLaunchKernelGGL(tmid_init_kernel, dim3(1), dim3(1), 0, umhs_s(stream), reinterpret_cast<uint32_t*>(minmax2));
+  if (n == 0) {
+    UMHS_CHECK_LAUNCH();
+    return UMHS_OK;
+  }
   int64_t blocks = (n + 2047) / 2048;
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(tmid_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, umhs_s(stream), t_starts, t_ends, n,

@@ -316,19 +316,24 @@ class UMHSModel(nn.Module):
             main = torch.cuda.current_stream(self.device)
             mm = torch.empty(2, device=self.device, dtype=torch.float32)  # every allocation happens on the main stream
             can_partition = ops.reserve_step_workspaces(spec, n, self.device)
-            ev_in, ev_pack, ev_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            ev_in, ev_pack, ev_hash, ev_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             ev_in.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_in)
                 ops.field_fwd_prepare(spec, flat)
                 ev_pack.record(side)
                 ops.tmid_minmax(t0, t1, out=mm)
+        enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
+        if side is not None:
+            # the bucket histogram is LDS-atomic / VALU heavy: under the (L2-bound) hash gather it cost more than it hid; it starts
+            # when the gather is done and runs under the field MLP
+            ev_hash.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_hash)
                 if can_partition and n > 0:
                     prepared = ops.hashgrid_bwd_prepare(pos01, spec.scalings, L.log2_hashmap_size)
                     ops.field_bwd_prepare(spec, flat, n)
                 ev_done.record(side)
-        enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
-        if side is not None:
             main.wait_event(ev_pack)
         fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
         values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
