@@ -172,6 +172,8 @@ CASES = [
     pytest.param(4, 141, False, 0.7, id="C4_B141_nospec"),
     pytest.param(4, 21, True, 0.5, id="C4_B21_spec"),
     pytest.param(15, 3, True, 0.2, id="C15_B3_spec"),
+    pytest.param(5, 21, False, 0.6, id="C5_B21_nospec"),  # B <= 32 without the specular head: split backward, no-spec variants
+    pytest.param(7, 32, True, 0.4, id="C7_B32_spec"),     # the largest band count the split backward takes
 ]
 
 
