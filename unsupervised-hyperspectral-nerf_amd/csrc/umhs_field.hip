@@ -224,7 +224,6 @@ struct FieldIO {
   // backward
   const float *d_sigma, *d_spectral, *d_emb;
   float* d_enc;
-  int stagger;                         // forward, 8-wave variant: waves 4-7 start this many x 4096 cycles late
   const float *emb_in, *sigma_raw_in;  // saved forward outputs (heads / base backward)
   float* d_bo;                         // [N,16] gradient w.r.t. the base MLP's outputs (heads -> base)
   float* feat_logits;                  // forward: optional [N,16] feature_mlp logits (rows 0..C), saved for the split backward
@@ -349,13 +348,6 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
   constexpr int TILE = 16 * NT * WAVES;  // samples per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int64_t ntiles = (io.n + TILE - 1) / TILE;
-  if (WAVES == 8 && io.stagger > 0) {
-    // Waves w and w+4 of an 8-wave workgroup share a SIMD and run the same program: left alone they move in
-    // lockstep (both in their VALU-only stretches together, matrix pipe idle).  Delay the second half once by
-    // about half an iteration so one wave's MFMA chains cover the other's encodings / epilogue / stores.
-    if (__builtin_amdgcn_readfirstlane(wave) >= 4)
-      for (int i = 0; i < io.stagger; ++i) __builtin_amdgcn_s_sleep(64);
-  }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t nn[NT];
     bool ok[NT];
@@ -1452,7 +1444,6 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances, io.feat_logits = dens ? nullptr : feat_logits;
-  io.stagger = getenv("UMHS_FWD_STAGGER") ? atoi(getenv("UMHS_FWD_STAGGER")) : 0;
   const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
   static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;  // tuning knob
   const int tile_samples = 128;  // every variant processes 128 samples per workgroup iteration
@@ -1467,10 +1458,9 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
     }
     image = img;
   }
-  static const int one_per_cu = getenv("UMHS_FWD_ONE_PER_CU") ? atoi(getenv("UMHS_FWD_ONE_PER_CU")) : 0;  // experiment
-  const int blocks_per_cu = (lds_bytes <= 78 * 1024 && !one_per_cu) ? 2 : 1;
+  const int blocks_per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
-  const size_t lds_launch = one_per_cu ? (lds_bytes > 100 * 1024 ? lds_bytes : 100 * 1024) : lds_bytes;
+  const size_t lds_launch = lds_bytes;
 #define LAUNCH_FWD(S, D, NT_, W_)                                                                               \
   do {                                                                                                          \
     rc = set_lds(field_fwd_kernel<S, D, NT_, W_>, lds_launch);                                                   \
