@@ -144,3 +144,33 @@ def test_oracle_marcher_analytic_cases():
     assert ts.min() >= 1.0 - 1e-6 and not ((ts > 2.05) & (ts < 3.8)).any() and (ts > 3.9).any()  # [-2,-1] and [1,2] only
     aabbs = T.occ_grid_aabbs(roi, 3)
     np.testing.assert_array_equal(aabbs[2], [-4, -4, -4, 4, 4, 4])
+
+
+def test_c1_rgb_plumbing_forward_on_cpu():
+    """BASELINE config C1 (scripts/rgb.sh shape: method="rgb", 256 rays x 64 samples, forward render on the CPU path).  The HIP
+    field implements the spectral methods only; C1 is the reference's CPU plumbing case and runs through the oracle: field
+    ``umhs_field.py:280-294`` (mlp_head on [SH(dir) | emb] -> 3, no activation) + packed compositing, and its loss branch."""
+    R, S = 256, 64
+    p = T.FieldParams(5, 21, False, method="rgb", table_scale=0.5, seed=1)
+    with torch.no_grad():
+        p.base_b[1][0] += 1.0
+    b = T.synthetic_batch(R, S, 21, seed=2)
+    with torch.no_grad():
+        density, emb, sigma_raw, sel = T.field_density(p, b["origins"], b["directions"], b["starts"], b["ends"])
+        fo = T.field_outputs(p, b["origins"], b["directions"], b["starts"], b["ends"], emb, 0.5)
+        assert set(fo) == {"rgb"} and fo["rgb"].shape == (R * S, 3) and density.shape == (R * S, 1) and emb.shape == (R * S, 15)
+        pinfo = T.pack_info(b["ray_indices"], R)
+        w = T.render_weight_from_density(b["starts"][..., 0], b["ends"][..., 0], density[..., 0], pinfo)[0]
+        rgb = T.accumulate_along_rays(w, fo["rgb"], b["ray_indices"], R)          # upstream NGPModel: per-ray colour
+        acc = T.accumulate_along_rays(w, None, b["ray_indices"], R)
+        assert rgb.shape == (R, 3) and acc.shape == (R, 1) and torch.isfinite(rgb).all()
+        assert float(acc.min()) >= 0 and float(acc.max()) <= 1 + 1e-6 and float(acc.mean()) > 0.05
+        # the reference calls renderer_rgb WITHOUT ray_indices/num_rays in this mode (umhs_model.py:266): a packed [N,3] input is then
+        # summed over dim -2 into ONE colour for the whole batch (latent bug, SURVEY R13) -- restated, not imitated by the build
+        quirk = torch.sum(w[:, None] * fo["rgb"], dim=-2)
+        torch.testing.assert_close(quirk, rgb.sum(0), rtol=1e-4, atol=1e-5)
+        loss = T.model_loss({"rgb": rgb, "accumulation": acc}, None, torch.rand(R, 3), b["bg_random"], "rgb")
+        assert set(loss) == {"rgb_loss"} and torch.isfinite(loss["rgb_loss"])
+    sd = p.reference_state_dict()
+    assert sd["mlp_head.layers.0.weight"].shape == (64, 31) and sd["mlp_head.layers.2.weight"].shape == (3, 64)
+    assert not any(k.startswith(("feature_mlp", "mlp_directional", "endmembers")) for k in sd)
