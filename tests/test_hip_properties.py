@@ -212,3 +212,48 @@ def test_direct_training_step_equals_the_autograd_path(method, specular, monkeyp
     with pytest.raises(KeyError):
         o1["residual_99"]
     assert set(o1.materialize().keys()) == set(o0.keys())
+
+
+@pytest.mark.parametrize("name,R,S,B,C,spec,temp", [
+    ("C3_cbox_dragon_128band", 8192, 64, 128, 9, True, 0.3),
+    ("C4_pinecone_per_gpu_share", 8192, 64, 31, 4, True, 0.5),
+    ("C5_joint_141band_nospec", 8192, 64, 141, 4, False, 0.7),
+])
+def test_full_size_training_step_other_configs(name, R, S, B, C, spec, temp, monkeypatch):
+    """BASELINE configs C3 / C4 (one GPU's share) / C5 at full size through the pipeline: the straight launch sequence and the
+    autograd path agree on losses and gradient, outputs satisfy the model's invariants, and three steps reduce the loss."""
+    from umhsnerf import ops
+    from umhsnerf._ns_compat import packed_ray_samples
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    b = T.synthetic_batch(R, S, B, seed=21)
+    b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+    rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])
+    pinfo = ops.pack_info(b["ray_indices"], R)
+    res = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("UMHS_DIRECT_STEP", direct)
+        torch.manual_seed(5)
+        cfg = UMHSConfig(method="rgb+spectral", pred_specular=spec, temperature=temp, per_band_outputs=False)
+        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": C}, seed=6)
+        with torch.no_grad():
+            pipe.model.field.layout.view(pipe.model.field.flat.data, "mlp_base.encoder.hash_table").mul_(300.0)
+            batch = {"image": pipe.model.converter(b["gt_spectral"]), "hs_image": b["gt_spectral"]}
+        out, loss = pipe.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
+        g = pipe.model.field.flat.grad.clone()
+        first = {k: float(v.detach()) for k, v in loss.items()}
+        if direct == "1":
+            assert out["spectral"].shape == (R, B) and out["abundances"].shape == (R, C) and out["rgb"].shape == (R, 3)
+            assert bool(torch.isfinite(out["spectral"]).all()) and float(out["accumulation"].max()) <= 1 + 1e-5
+            assert float((out["abundances"].sum(-1) - out["accumulation"][:, 0]).abs().max()) < 1e-4  # composited softmax rows
+            if spec:
+                torch.testing.assert_close(out["spectral"], out["spectral2"] + out["specular"], rtol=1e-5, atol=1e-6)
+            for _ in range(2):
+                out, loss = pipe.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
+            assert sum(float(v.detach()) for v in loss.values()) < sum(first.values())
+        res[direct] = (first, g)
+    (l1, g1), (l0, g0) = res["1"], res["0"]
+    for k in l0:
+        assert abs(l1[k] - l0[k]) <= 2e-6 * abs(l0[k]), (name, k, l1[k], l0[k])
+    torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-9 + 2e-6 * float(g0.abs().max()))
