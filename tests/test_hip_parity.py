@@ -590,3 +590,37 @@ def test_hashgrid_bwd_prepare_apply_equals_one_call():
     ops.hashgrid_bwd_apply(pos, d_enc, sc, 19, acc, True, overwrite=False, level_begin=3, level_count=2, ws_range=(3, 2))
     torch.testing.assert_close(acc[3 << 19:5 << 19], want[3 << 19:5 << 19] + 1.0, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
     assert float(acc[: 3 << 19].min()) == 1.0 and float(acc[5 << 19:].max()) == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,B,spec", [(6, 31, True), (4, 141, False), (5, 21, False)])
+def test_field_bwd_overwrites_every_parameter_gradient(C, B, spec):
+    """The persistent gradient buffer is not cleared between steps: every weight / bias / endmember entry must be (over)written
+    by each backward, whatever was there before (NaN here)."""
+    ops = _ops()
+    p, b, layout, flat, fs = make_case(C, B, spec, 9, 23, log2_T=12, seed=4)
+    N = b["origins"].shape[0]
+    dev_args = [t.to(DEV) for t in (b["origins"], b["directions"], b["starts"].view(-1), b["ends"].view(-1))]
+    wpos, pos01, sel = ops.positions_fwd(*dev_args, fs)
+    flat = flat.to(DEV)
+    enc = ops.hashgrid_fwd(pos01, layout.view(flat, "mlp_base.encoder.hash_table"), fs.scalings, 12, True)
+    out = ops.field_fwd(fs, flat, enc, True, wpos, dev_args[1], sel, want_emb=True, want_logits=True)
+    g = torch.Generator().manual_seed(1)
+    ds, dsp = torch.rand(N, generator=g).to(DEV), torch.rand(N, B, generator=g).to(DEV)
+    for logits in (None, out["feat_logits"]):
+        ref = torch.zeros_like(flat)
+        ops.field_bwd(fs, flat, enc, True, wpos, dev_args[1], sel, out["sigma_raw"], out["emb"], ds, dsp, None, ref, feat_logits=logits)
+        dirty = torch.full_like(flat, float("nan"))
+        ops.field_bwd(fs, flat, enc, True, wpos, dev_args[1], sel, out["sigma_raw"], out["emb"], ds, dsp, None, dirty, feat_logits=logits)
+        untouched = []
+        for name in layout.entries:
+            if name == "mlp_base.encoder.hash_table":
+                continue
+            got, want = layout.view(dirty, name), layout.view(ref, name)
+            if torch.isnan(got).any():
+                assert torch.isnan(got).all() and float(want.abs().max()) == 0.0, name  # all or nothing, and zero in a clean buffer
+                untouched.append(name)
+                continue
+            assert torch.equal(got, want), name
+        # without the specular head nothing reaches mlp_directional: the entries the reduce does not visit stay at their initial zero
+        assert all(n.startswith("mlp_directional") for n in untouched) and (not spec or not untouched), untouched

@@ -418,7 +418,8 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
     # the 64 MiB table segment is fully written by hashgrid_bwd(overwrite=True): no memset of the flat gradient
     d_flat = sink.begin() if own else torch.empty_like(flat)
     tail = L.offset("mlp_base.mlp.layers.0.weight")
-    d_flat[tail:].zero_()  # MLP / endmember segments (+ alignment padding)
+    if not own:  # field_reduce overwrites every weight / bias / endmember entry; only the alignment padding between the segments is
+        d_flat[tail:].zero_()  # never written -- the sink's persistent buffer has it zeroed once, a fresh tensor needs it now
     d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
                       packs_ready=prepared, feat_logits=feat_logits)
     if own:

@@ -98,8 +98,9 @@ class FlatGradSink:
 
     def begin(self) -> torch.Tensor:
         p = self.param
-        if self.buffer is None or self.buffer.shape != p.shape or self.buffer.device != p.device:
-            self.buffer = torch.empty_like(p.data)
+        self.fresh = self.buffer is None or self.buffer.shape != p.shape or self.buffer.device != p.device
+        if self.fresh:  # zeroed once: the backward overwrites every parameter's entry each step, never the alignment padding
+            self.buffer = torch.zeros_like(p.data)
         self.works.clear()
         self.reduced_ptr = None
         return self.buffer
