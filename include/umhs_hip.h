@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 1
+#define UMHS_ABI_VERSION 2
 
 enum {
   UMHS_OK = 0,

@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
 LIB_PATH = os.environ.get("UMHS_LIB_PATH") or os.path.join(_HERE, "libumhs_hip.so")  # override: A/B builds of tools/ab_lib.sh
 MAX_STREAMS = 4
 
@@ -109,7 +110,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.umhs_abi_version() != 1:
+        if l.umhs_abi_version() != ABI_VERSION:
             raise RuntimeError("libumhs_hip.so ABI version mismatch")
         _lib = l
     return _lib
