@@ -265,6 +265,15 @@ int umhs_march_write(const float* origins, const float* directions, int64_t n_ra
                      const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
                      float step_size, float cone_angle, const float* nears, const float* fars, const int64_t* packed_info,
                      float* t_starts, float* t_ends, int64_t* ray_indices, umhs_stream_t stream);
+/* Single pass instead of count + write: umhs_march_scratch counts AND parks the first `cap` samples of ray r in             */
+/* scratch_t0/t1[r*cap + i]; after the caller's scan, umhs_march_compact moves them to their packed places.  A count > cap     */
+/* means that ray overflowed its row: fall back to umhs_march_write for the batch.                                            */
+int umhs_march_scratch(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
+                       const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
+                       float step_size, float cone_angle, const float* nears, const float* fars, int cap, int64_t* counts,
+                       float* scratch_t0, float* scratch_t1, umhs_stream_t stream);
+int umhs_march_compact(const int64_t* packed_info, int64_t n_rays, int cap, const float* scratch_t0, const float* scratch_t1,
+                       float* t_starts, float* t_ends, int64_t* ray_indices, umhs_stream_t stream);
 int umhs_visibility(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
                     int64_t n_rays, int64_t n, float early_stop_eps, float alpha_thre, uint8_t* mask, umhs_stream_t stream);
 

@@ -54,6 +54,16 @@ def test_marcher_matches_oracle(levels, res, cone, step, far):
         ok += bool(binaries[lvl[i], idx[0], idx[1], idx[2]])
     assert ok >= 0.995 * len(lvl)  # voxel-boundary ties aside
     assert bool((s_ref[1:] >= s_ref[:-1])[ri_ref[1:] == ri_ref[:-1]].all())
+    # the three host paths -- single pass with scratch rows, overflowing rows (falls back to the second walk), two passes -- agree
+    import os
+
+    for cap in ("8", "0"):
+        os.environ["UMHS_MARCH_CAP"] = cap
+        try:
+            ri2, s2, e2, p2 = march_rays(o.to(DEV), d.to(DEV), bin_u8, roi, levels, res, 0.05, far, step, cone)
+        finally:
+            del os.environ["UMHS_MARCH_CAP"]
+        assert torch.equal(ri2, ri) and torch.equal(s2, s) and torch.equal(e2, e) and torch.equal(p2, pinfo), cap
 
 
 def test_visibility_matches_oracle():

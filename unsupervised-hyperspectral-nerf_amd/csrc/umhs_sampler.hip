@@ -19,12 +19,19 @@ struct MarchArgs {
   int64_t* counts;             // count pass
   float *t_starts, *t_ends;
   int64_t* ray_indices;
+  int cap;  // single-pass mode (count kernel with scratch): the first `cap` samples of ray r go to t_starts/t_ends[r * cap + i]
 };
 
+#ifndef MARCH_RPW
+#define MARCH_RPW 16
+#endif
 template <bool WRITE>
 __global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
 #pragma clang fp contract(off)
-  const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  // MARCH_RPW rays per wave: a batch has a few thousand rays, the chip 1024 SIMDs -- a wave of 64 rays runs as long as its slowest
+  // ray on one SIMD while 900 others idle; fewer rays per wave = less divergence, more SIMDs
+  if (threadIdx.x >= MARCH_RPW) return;
+  const int64_t r = (int64_t)blockIdx.x * MARCH_RPW + threadIdx.x;
   if (r >= a.n_rays) return;
   const float BIG = 1e30f;
   const float o[3] = {a.o[3 * r], a.o[3 * r + 1], a.o[3 * r + 2]};
@@ -45,57 +52,93 @@ __global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
   const float t_end = fminf(tf, a.fars ? a.fars[r] : a.far);
   int64_t cnt = 0;
   int64_t w = WRITE ? a.packed_info[2 * r] : 0;
+  int iters = 0;
   if (t < t_end) {
-    bool continuous = false;
+    bool continuous = false, left_grid = false;
     float t_last = t;
-    for (int guard = 0; t < t_end && guard < 100000; ++guard) {
-      const float tm = t + 1e-5f * fmaxf(1.0f, fabsf(t));
-      float p[3], m = 0.0f;
+    // The voxel sequence a ray crosses is pure geometry: it does not depend on what the occupancy grid says.  So the walk runs in
+    // batches of KB voxels -- geometry for KB steps, then KB occupancy bytes fetched together, then the sample emission -- instead
+    // of one dependent load (an L2 round trip) per voxel, which was all this latency-bound kernel (64 waves in total) waited for.
+    constexpr int KB = 8;
+    for (int guard = 0; t < t_end && guard < 100000 && !left_grid;) {
+      float vt0[KB], vtc[KB];
+      uint32_t vcell[KB];
+      uint8_t vocc[KB];
+      int nb = 0;
+      float tt = t;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        p[k] = o[k] + d[k] * tm;
-        m = fmaxf(m, fabsf(p[k] - c[k]) / h[k]);
-      }
-      if (!(m < top)) break;
-      int lvl = 0;
-      if (!(m < 1.0f)) (void)frexpf(m, &lvl);  // m in [2^(e-1), 2^e) -> level e
-      lvl = min(max(lvl, 0), a.levels - 1);
-      const float sc = (float)(1 << lvl);
-      int idx[3];
-      float t_exit = BIG;
+      for (int k = 0; k < KB; ++k) {
+        if (tt < t_end && guard < 100000 && !left_grid) {
+          ++guard, ++iters;
+          const float tm = tt + 1e-5f * fmaxf(1.0f, fabsf(tt));
+          float p[3], m = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float hl = h[k] * sc, vmin = c[k] - hl, vs = (hl * 2.0f) / (float)a.res;
-        int i = (int)floorf((p[k] - vmin) / vs);
-        i = min(max(i, 0), a.res - 1);
-        idx[k] = i;
-        const float lo = vmin + (float)i * vs, hi = vmin + (float)(i + 1) * vs;
-        const float tx = ((d[k] >= 0.0f ? hi : lo) - o[k]) * inv[k];
-        if (d[k] != 0.0f) t_exit = fminf(t_exit, tx);
-      }
-      if (!(t_exit > t)) t_exit = nextafterf(t, BIG);
-      const float t_clip = fminf(t_exit, t_end);
-      const size_t cell = (((size_t)lvl * a.res + idx[0]) * a.res + idx[1]) * a.res + idx[2];
-      if (a.bin[cell]) {
-        if (!continuous) t_last = t;
-        while (true) {
-          const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
-          if (!(t_last + dt * 0.5f < t_clip)) break;
-          if (WRITE) {
-            a.t_starts[w] = t_last, a.t_ends[w] = t_last + dt, a.ray_indices[w] = r;
-            ++w;
+          for (int q = 0; q < 3; ++q) {
+            p[q] = o[q] + d[q] * tm;
+            m = fmaxf(m, fabsf(p[q] - c[q]) / h[q]);
           }
-          ++cnt;
-          t_last = t_last + dt;
+          if (!(m < top)) {
+            left_grid = true;
+          } else {
+            int lvl = 0;
+            if (!(m < 1.0f)) (void)frexpf(m, &lvl);  // m in [2^(e-1), 2^e) -> level e
+            lvl = min(max(lvl, 0), a.levels - 1);
+            const float sc = (float)(1 << lvl);
+            int idx[3];
+            float t_exit = BIG;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const float hl = h[q] * sc, vmin = c[q] - hl, vs = (hl * 2.0f) / (float)a.res;
+              int i = (int)floorf((p[q] - vmin) / vs);
+              i = min(max(i, 0), a.res - 1);
+              idx[q] = i;
+              const float lo = vmin + (float)i * vs, hi = vmin + (float)(i + 1) * vs;
+              const float tx = ((d[q] >= 0.0f ? hi : lo) - o[q]) * inv[q];
+              if (d[q] != 0.0f) t_exit = fminf(t_exit, tx);
+            }
+            if (!(t_exit > tt)) t_exit = nextafterf(tt, BIG);
+            const float t_clip = fminf(t_exit, t_end);
+            vt0[k] = tt, vtc[k] = t_clip;
+            vcell[k] = (uint32_t)((((size_t)lvl * a.res + idx[0]) * a.res + idx[1]) * a.res + idx[2]);
+            tt = t_clip;
+            nb = k + 1;
+          }
         }
-        continuous = true;
-      } else {
-        continuous = false;
       }
-      t = t_clip;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) vocc[k] = k < nb ? a.bin[vcell[k]] : (uint8_t)0;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        if (k < nb) {
+          const float t_clip = vtc[k];
+          if (vocc[k]) {
+            if (!continuous) t_last = vt0[k];
+            while (true) {
+              const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
+              if (!(t_last + dt * 0.5f < t_clip)) break;
+              if (WRITE) {
+                a.t_starts[w] = t_last, a.t_ends[w] = t_last + dt, a.ray_indices[w] = r;
+                ++w;
+              } else if (a.cap > 0 && cnt < a.cap) {  // single pass: park the sample in the ray's scratch row
+                a.t_starts[r * a.cap + cnt] = t_last, a.t_ends[r * a.cap + cnt] = t_last + dt;
+              }
+              ++cnt;
+              t_last = t_last + dt;
+            }
+            continuous = true;
+          } else {
+            continuous = false;
+          }
+          t = t_clip;
+        }
+      }
     }
   }
+#ifdef MARCH_DEBUG_ITERS  // diagnostic build only: voxel steps instead of sample counts
+  if (!WRITE) a.counts[r] = iters;
+#else
   if (!WRITE) a.counts[r] = cnt;
+#endif
 }
 
 static int fill_march(MarchArgs* a, const float* o, const float* d, int64_t n_rays, const uint8_t* bin, const float* roi6, int levels,
@@ -106,7 +149,7 @@ static int fill_march(MarchArgs* a, const float* o, const float* d, int64_t n_ra
   a->cx = (roi6[0] + roi6[3]) / 2.0f, a->cy = (roi6[1] + roi6[4]) / 2.0f, a->cz = (roi6[2] + roi6[5]) / 2.0f;
   a->hx = (roi6[3] - roi6[0]) / 2.0f, a->hy = (roi6[4] - roi6[1]) / 2.0f, a->hz = (roi6[5] - roi6[2]) / 2.0f;
   a->near = near_plane, a->far = far_plane, a->step = step, a->cone = cone, a->nears = nears, a->fars = fars;
-  a->packed_info = nullptr, a->counts = nullptr, a->t_starts = a->t_ends = nullptr, a->ray_indices = nullptr;
+  a->packed_info = nullptr, a->counts = nullptr, a->t_starts = a->t_ends = nullptr, a->ray_indices = nullptr, a->cap = 0;
   return UMHS_OK;
 }
 
@@ -121,7 +164,7 @@ extern "C" int umhs_march_count(const float* origins, const float* directions, i
   if (!counts && n_rays > 0) return UMHS_ERR_ARG;
   if (n_rays == 0) return UMHS_OK;
   a.counts = counts;
-  hipLaunchKernelGGL(march_kernel<false>, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, umhs_s(stream), a);
+  hipLaunchKernelGGL(march_kernel<false>, dim3((unsigned)((n_rays + MARCH_RPW - 1) / MARCH_RPW)), dim3(64), 0, umhs_s(stream), a);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
@@ -138,7 +181,52 @@ extern "C" int umhs_march_write(const float* origins, const float* directions, i
   if (n_rays == 0) return UMHS_OK;
   if (!packed_info || !t_starts || !t_ends || !ray_indices) return UMHS_ERR_ARG;
   a.packed_info = packed_info, a.t_starts = t_starts, a.t_ends = t_ends, a.ray_indices = ray_indices;
-  hipLaunchKernelGGL(march_kernel<true>, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, umhs_s(stream), a);
+  hipLaunchKernelGGL(march_kernel<true>, dim3((unsigned)((n_rays + MARCH_RPW - 1) / MARCH_RPW)), dim3(64), 0, umhs_s(stream), a);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// Single-pass marching: one walk of the grid both counts the samples of every ray and parks the first `cap` of them in a scratch
+// row [R, cap]; umhs_march_compact then copies the rows to their packed places (one wave per ray, coalesced).  A ray with more
+// than `cap` samples only shows in its count: the caller falls back to umhs_march_write for that batch.
+extern "C" int umhs_march_scratch(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
+                                  const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
+                                  float step_size, float cone_angle, const float* nears, const float* fars, int cap,
+                                  int64_t* counts, float* scratch_t0, float* scratch_t1, umhs_stream_t stream) {
+  MarchArgs a;
+  int rc = fill_march(&a, origins, directions, n_rays, binaries, roi_aabb_host6, levels, resolution, near_plane, far_plane,
+                      step_size, cone_angle, nears, fars);
+  if (rc) return rc;
+  if (n_rays == 0) return UMHS_OK;
+  if (!counts || !scratch_t0 || !scratch_t1 || cap < 1) return UMHS_ERR_ARG;
+  a.counts = counts, a.t_starts = scratch_t0, a.t_ends = scratch_t1, a.cap = cap;
+  hipLaunchKernelGGL(march_kernel<false>, dim3((unsigned)((n_rays + MARCH_RPW - 1) / MARCH_RPW)), dim3(64), 0, umhs_s(stream), a);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+__global__ __launch_bounds__(256) void march_compact_kernel(const int64_t* __restrict__ pinfo, int64_t n_rays, int cap,
+                                                            const float* __restrict__ s0, const float* __restrict__ s1,
+                                                            float* __restrict__ t0, float* __restrict__ t1,
+                                                            int64_t* __restrict__ ri) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const int64_t start = pinfo[2 * r], cnt = pinfo[2 * r + 1];
+  for (int64_t i = lane; i < cnt; i += 64) {
+    t0[start + i] = s0[r * cap + i], t1[start + i] = s1[r * cap + i];
+    ri[start + i] = r;
+  }
+}
+
+extern "C" int umhs_march_compact(const int64_t* packed_info, int64_t n_rays, int cap, const float* scratch_t0,
+                                  const float* scratch_t1, float* t_starts, float* t_ends, int64_t* ray_indices,
+                                  umhs_stream_t stream) {
+  if (n_rays < 0 || cap < 1) return UMHS_ERR_ARG;
+  if (n_rays == 0) return UMHS_OK;
+  if (!packed_info || !scratch_t0 || !scratch_t1 || !t_starts || !t_ends || !ray_indices) return UMHS_ERR_ARG;
+  hipLaunchKernelGGL(march_compact_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), packed_info, n_rays, cap,
+                     scratch_t0, scratch_t1, t_starts, t_ends, ray_indices);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }

@@ -81,6 +81,8 @@ SIGNATURES = {
     "umhs_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "umhs_march_count": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "umhs_march_write": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "umhs_march_scratch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "umhs_march_compact": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "umhs_visibility": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "umhs_ray_train_tail_scratch_bytes": (C.c_size_t, []),
     "umhs_ray_train_tail": (C.c_int, [_vp] * 10 + [_i64, C.c_int, C.c_int, _f32, _f32, _f32, C.c_int] + [_vp] * 9 + [C.c_size_t, _vp]),

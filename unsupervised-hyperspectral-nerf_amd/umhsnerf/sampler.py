@@ -10,6 +10,7 @@ steps).  nerfacc's source is not available offline: behaviour is restated from i
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -18,6 +19,17 @@ from torch import Tensor, nn
 from . import _hip
 from ._hip import ptr
 from ._ns_compat import RayBundle, RaySamples, packed_ray_samples
+
+
+_scratch_cache = {}
+
+
+def _scratch(n: int, dev) -> Tuple[Tensor, Tensor]:
+    key = dev.index or 0
+    s = _scratch_cache.get(key)
+    if s is None or s[0].numel() < n:
+        s = _scratch_cache[key] = (torch.empty(n, device=dev), torch.empty(n, device=dev))
+    return s
 
 
 def march_rays(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aabb, levels: int, resolution: int, near: float,
@@ -29,18 +41,30 @@ def march_rays(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aab
     counts = torch.empty((R,), device=dev, dtype=torch.int64)
     nears = _hip.f32c(nears) if nears is not None else None
     fars = _hip.f32c(fars) if fars is not None else None
-    _hip.check(_hip.lib().umhs_march_count(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
-                                           ptr(nears), ptr(fars), ptr(counts), _hip.stream()), "umhs_march_count")
+    lib = _hip.lib()
+    cap = int(os.environ.get("UMHS_MARCH_CAP", "1024"))  # scratch row per ray of the single-pass form (0: always two passes)
+    scratch = _scratch(R * cap, dev) if (cap > 0 and R > 0) else None
+    if scratch is not None:  # one walk: counts + the samples themselves parked in [R, cap] rows
+        _hip.check(lib.umhs_march_scratch(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone, ptr(nears),
+                                          ptr(fars), cap, ptr(counts), ptr(scratch[0]), ptr(scratch[1]), _hip.stream()), "umhs_march_scratch")
+    else:
+        _hip.check(lib.umhs_march_count(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
+                                        ptr(nears), ptr(fars), ptr(counts), _hip.stream()), "umhs_march_count")
     ends_excl = torch.cumsum(counts, 0)
     packed_info = torch.stack([ends_excl - counts, counts], dim=-1).contiguous()
-    n = int(ends_excl[-1].item()) if R > 0 else 0  # the sample count sizes the outputs: one host sync per batch, as in nerfacc
+    # the sample count sizes the outputs: one host sync per batch, as in nerfacc (the row-overflow flag rides along)
+    n, cmax = (int(v) for v in torch.stack([ends_excl[-1], counts.max()]).tolist()) if R > 0 else (0, 0)
     t0 = torch.empty((n,), device=dev, dtype=torch.float32)
     t1 = torch.empty((n,), device=dev, dtype=torch.float32)
     ri = torch.empty((n,), device=dev, dtype=torch.int64)
     if n > 0:
-        _hip.check(_hip.lib().umhs_march_write(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
-                                               ptr(nears), ptr(fars), ptr(packed_info), ptr(t0), ptr(t1), ptr(ri), _hip.stream()),
-                   "umhs_march_write")
+        if scratch is not None and cmax <= cap:
+            _hip.check(lib.umhs_march_compact(ptr(packed_info), R, cap, ptr(scratch[0]), ptr(scratch[1]), ptr(t0), ptr(t1), ptr(ri),
+                                              _hip.stream()), "umhs_march_compact")
+        else:  # some ray overflowed its scratch row: second walk writing straight to the packed places
+            _hip.check(lib.umhs_march_write(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
+                                            ptr(nears), ptr(fars), ptr(packed_info), ptr(t0), ptr(t1), ptr(ri), _hip.stream()),
+                       "umhs_march_write")
     return ri, t0, t1, packed_info
 
 
