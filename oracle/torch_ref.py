@@ -607,6 +607,7 @@ def march_ray_ref(o, d, binaries: np.ndarray, roi_aabb, near, far, step, cone):
     near, far, step, cone = F32(near), F32(far), F32(step), F32(cone)
     BIG = F32(1e30)
     inv = np.where(d != 0, F32(1) / np.where(d != 0, d, F32(1)), np.where(np.signbit(d), -BIG, BIG)).astype(np.float32)
+    inv_h = (F32(1) / h).astype(np.float32)  # positions are normalised with reciprocals (one multiply per axis and voxel, not a divide)
     ho = h * F32(2 ** (levels - 1))
     t0, t1 = (c - ho - o) * inv, (c + ho - o) * inv
     tn, tf = np.max(np.minimum(t0, t1)), np.min(np.maximum(t0, t1))
@@ -620,7 +621,7 @@ def march_ray_ref(o, d, binaries: np.ndarray, roi_aabb, near, far, step, cone):
         guard += 1
         tm = t + F32(1e-5) * max(F32(1), abs(t))  # a point just inside the voxel being entered
         p = o + d * tm
-        m = np.max(np.abs(p - c) / h)
+        m = np.max(np.abs(p - c) * inv_h)
         if not (m < F32(2 ** (levels - 1))):
             break
         lvl = 0 if m < F32(1) else int(np.frexp(m)[1])  # m in [2^(e-1), 2^e) -> level e
@@ -628,7 +629,8 @@ def march_ray_ref(o, d, binaries: np.ndarray, roi_aabb, near, far, step, cone):
         hl = h * F32(2**lvl)
         vmin_l = c - hl
         vs = (hl * F32(2)) / F32(res)
-        idx = np.clip(np.floor((p - vmin_l) / vs).astype(np.int64), 0, res - 1)
+        inv_vs = F32(1) / vs
+        idx = np.clip(np.floor((p - vmin_l) * inv_vs).astype(np.int64), 0, res - 1)
         lo, hi = vmin_l + idx.astype(np.float32) * vs, vmin_l + (idx + 1).astype(np.float32) * vs
         tx = (np.where(d >= 0, hi, lo) - o) * inv
         t_exit = np.min(np.where(d != 0, tx, BIG))

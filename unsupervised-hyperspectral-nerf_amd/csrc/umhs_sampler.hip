@@ -40,6 +40,16 @@ __global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
   float inv[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) inv[k] = d[k] != 0.0f ? 1.0f / d[k] : (signbit(d[k]) ? -BIG : BIG);
+  // per-axis constants of level 0; level l scales them by 2^l exactly (power-of-two factors commute with rounding), so every
+  // voxel step is multiplications only: a float divide is a ~10-instruction dependent chain, and this kernel is one long
+  // dependency chain per ray (64-256 waves in all: nothing else to overlap it with)
+  float ih[3], vs0[3], ivs0[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    ih[k] = 1.0f / h[k];
+    vs0[k] = (h[k] * 2.0f) / (float)a.res;
+    ivs0[k] = 1.0f / vs0[k];
+  }
   const float top = (float)(1 << (a.levels - 1));
   float tn = -INFINITY, tf = INFINITY;
 #pragma unroll
@@ -75,21 +85,21 @@ __global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
             p[q] = o[q] + d[q] * tm;
-            m = fmaxf(m, fabsf(p[q] - c[q]) / h[q]);
+            m = fmaxf(m, fabsf(p[q] - c[q]) * ih[q]);
           }
           if (!(m < top)) {
             left_grid = true;
           } else {
             int lvl = 0;
-            if (!(m < 1.0f)) (void)frexpf(m, &lvl);  // m in [2^(e-1), 2^e) -> level e
+            if (!(m < 1.0f)) lvl = (int)((__float_as_uint(m) >> 23) & 0xffu) - 126;  // frexp exponent: m in [2^(e-1), 2^e) -> level e
             lvl = min(max(lvl, 0), a.levels - 1);
-            const float sc = (float)(1 << lvl);
+            const float sc = __uint_as_float((uint32_t)(127 + lvl) << 23), isc = __uint_as_float((uint32_t)(127 - lvl) << 23);
             int idx[3];
             float t_exit = BIG;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-              const float hl = h[q] * sc, vmin = c[q] - hl, vs = (hl * 2.0f) / (float)a.res;
-              int i = (int)floorf((p[q] - vmin) / vs);
+              const float hl = h[q] * sc, vmin = c[q] - hl, vs = vs0[q] * sc, ivs = ivs0[q] * isc;
+              int i = (int)floorf((p[q] - vmin) * ivs);
               i = min(max(i, 0), a.res - 1);
               idx[q] = i;
               const float lo = vmin + (float)i * vs, hi = vmin + (float)(i + 1) * vs;
