@@ -107,11 +107,19 @@ class OccGridEstimator(nn.Module):
         ri, t0, t1, pinfo = march_rays(rays_o, rays_d, bin_u8, self._roi, self.levels, self.res, near_plane, far_plane,
                                        render_step_size, cone_angle, nears, fars)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None and t0.numel() > 0:
-            alpha_thre = min(alpha_thre, float(self.occs.mean()))  # nerfacc: a host read per batch
+            alpha_thre = min(alpha_thre, self._occs_mean())  # nerfacc reads occs.mean() per batch; it only changes in _update()
             sigmas = sigma_fn(t0, t1, ri)
             keep = visibility_mask(sigmas, t0, t1, pinfo, early_stop_eps, alpha_thre)
-            ri, t0, t1 = ri[keep], t0[keep], t1[keep]
+            sel = torch.nonzero(keep).view(-1)  # one compaction index (one host sync) for the three packed arrays
+            ri, t0, t1 = ri.index_select(0, sel), t0.index_select(0, sel), t1.index_select(0, sel)
         return ri, t0, t1
+
+    def _occs_mean(self) -> float:
+        m = getattr(self, "_occs_mean_cache", None)
+        key = (self.occs.data_ptr(), self.occs._version)  # any in-place write to ``occs`` bumps its version counter
+        if m is None or m[0] != key:
+            m = self._occs_mean_cache = (key, float(self.occs.mean()))
+        return m[1]
 
     # ---- grid update (nerfacc OccGridEstimator._update) -----------------------------------------------------------
     @torch.no_grad()
