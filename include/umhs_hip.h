@@ -73,6 +73,10 @@ int umhs_positions_fwd(const float* origins, const float* directions, const floa
 /* ------------------------------------------------------------------------------------------ */
 int umhs_hashgrid_fwd(const float* pos01, const float* table, const float* scalings, int64_t n, int n_levels,
                       int log2_table_size, float* enc, int64_t stride_n, int64_t stride_l, umhs_stream_t stream);
+/* Level-major feature compaction enc_out[l][i] = enc_in[l][index[i]] ([L][M][2] -> [L][N][2]): lets a caller that has already  */
+/* encoded a superset of the samples (the sampler's density query) reuse those features instead of encoding the survivors again.  */
+int umhs_enc_gather(const float* enc_in, const int64_t* index, int64_t m, int64_t n, int n_levels, float* enc_out,
+                    umhs_stream_t stream);
 size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_table_size);
 /* Levels [level_begin, level_begin + n_levels) are processed (d_enc / d_table / scalings are indexed with the     */
 /* absolute level): callers may run the backward per level group, e.g. to all-reduce finished slabs early.          */

@@ -137,3 +137,44 @@ def test_short_training_run_with_occupancy_sampler():
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     E = model.field.endmembers
     assert float(E.min()) >= 0.0 and float(E.max()) <= 1.0  # clamp_endmembers fused in the optimizer step
+
+
+def test_training_forward_reuses_the_samplers_hash_features(monkeypatch):
+    """The sampler's density query already hash-encodes every marched candidate; the training forward gathers the survivors' rows
+    instead of encoding them again.  Same positions, same table -> bit-identical features, losses and gradients."""
+    import sys, os
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_hip_data import _split
+    from umhsnerf import ops
+    from umhsnerf.data.umhs_datamanager import UMHSDataManager, UMHSDataManagerConfig
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    res = {}
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("UMHS_REUSE_ENC", reuse)
+        torch.manual_seed(3)
+        B = 8
+        split, _, _, _ = _split(n=4, B=B, const=0.5)
+        dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=2048), device=DEV, seed=4, train=split)
+        cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="black")
+        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=5, datamanager=dm)
+        for step in range(20):
+            pipe.get_train_loss_dict(step)
+        rb, batch = dm.next_train(20)
+        rs, ri = pipe.model.sample(rb)
+        cached = (rs.metadata or {}).get("umhs_enc") if reuse == "1" else None
+        assert (cached is not None) == (reuse == "1")
+        if cached is not None:  # the gathered rows ARE the encoding of the surviving samples
+            fr = rs.frustums
+            n = ri.numel()
+            _, pos01, _ = ops.positions_fwd(fr.origins.view(n, 3), fr.directions.view(n, 3), fr.starts.view(-1), fr.ends.view(-1), pipe.model.field._spec())
+            L = pipe.model.field.layout
+            fresh = ops.hashgrid_fwd(pos01, L.view(pipe.model.field.flat.detach(), "mlp_base.encoder.hash_table"), pipe.model.field.scalings, 19, True)
+            assert cached[0].shape[1] >= n and torch.equal(ops.enc_gather(*cached), fresh)
+        pipe.optimizer.zero_grad(set_to_none=True)
+        out, loss = pipe.model.forward_backward_from_samples(rs, ri, len(rb), batch)
+        res[reuse] = ({k: float(v) for k, v in loss.items()}, pipe.model.field.flat.grad.clone(), ri.numel())
+    (l1, g1, n1), (l0, g0, n0) = res["1"], res["0"]
+    assert n1 == n0 and l1 == l0 and torch.equal(g1, g0)

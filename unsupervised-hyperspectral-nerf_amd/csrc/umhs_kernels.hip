@@ -560,6 +560,30 @@ extern "C" int umhs_hashgrid_bwd_apply(const float* pos01, const float* d_enc, i
   return hb_run_apply(a, n_levels, d_table, stream);
 }
 
+// Compaction of level-major hash features: out[l][i] = in[l][idx[i]].  The sampler already encoded every candidate sample for
+// its density query; the survivors' features are gathered (128 B per sample, near-sequential: idx ascends) instead of hashed
+// and gathered again from the table (1 KiB per sample, random).
+__global__ __launch_bounds__(256) void enc_gather_kernel(const float2* __restrict__ in, const int64_t* __restrict__ idx, int64_t m,
+                                                         int64_t n, float2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int64_t j = idx[i];
+  j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+  const int l = blockIdx.y;
+  out[(int64_t)l * n + i] = in[(int64_t)l * m + j];
+}
+
+extern "C" int umhs_enc_gather(const float* enc_in, const int64_t* index, int64_t m, int64_t n, int n_levels, float* enc_out,
+                               umhs_stream_t stream) {
+  if (m < 0 || n < 0 || n_levels < 1 || n_levels > 64) return UMHS_ERR_ARG;
+  if (n == 0) return UMHS_OK;
+  if (m < 1 || !enc_in || !index || !enc_out || (((uintptr_t)enc_in | (uintptr_t)enc_out) & 7)) return UMHS_ERR_ARG;
+  hipLaunchKernelGGL(enc_gather_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n_levels), dim3(256), 0, umhs_s(stream),
+                     reinterpret_cast<const float2*>(enc_in), index, m, n, reinterpret_cast<float2*>(enc_out));
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
 // =============================================================================================
 // R11: pack_info  (ray_indices sorted ascending -> (start, count) per ray, by binary search)
 // =============================================================================================

@@ -86,6 +86,7 @@ SIGNATURES = {
     "umhs_visibility": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "umhs_ray_train_tail_scratch_bytes": (C.c_size_t, []),
     "umhs_ray_train_tail": (C.c_int, [_vp] * 10 + [_i64, C.c_int, C.c_int, _f32, _f32, _f32, C.c_int] + [_vp] * 9 + [C.c_size_t, _vp]),
+    "umhs_enc_gather": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     "umhs_pixel_indices": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "umhs_raygen": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "umhs_pixel_gather": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _i64, _vp, _vp]),

@@ -44,6 +44,7 @@ except Exception:  # ModuleNotFoundError offline
         frustums: Frustums
         camera_indices: Optional[Tensor] = None
         deltas: Optional[Tensor] = None
+        metadata: Optional[dict] = None
 
     @dataclass
     class RayBundle:

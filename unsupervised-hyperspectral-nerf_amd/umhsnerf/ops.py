@@ -146,6 +146,15 @@ def hashgrid_fwd(pos01, table, scalings, log2_T: int, level_major: bool = True, 
     return enc
 
 
+def enc_gather(enc, index):
+    """Level-major features of the samples ``index`` (int64 [N], ascending) out of an encoded superset ``enc`` [L, M, 2]."""
+    L_, m = enc.shape[0], enc.shape[1]
+    n = index.shape[0]
+    out = torch.empty((L_, n, 2), device=enc.device, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_enc_gather(ptr(enc), ptr(index), m, n, L_, ptr(out), _hip.stream()), "umhs_enc_gather")
+    return out
+
+
 def hashgrid_bwd(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, method: str = "auto",
                  overwrite: bool = False, level_begin: int = 0, level_count: int = NUM_LEVELS):
     """d_table (+)= scatter(d_enc) for levels [level_begin, level_begin+level_count).  method: "partition" (atomics-free,
@@ -542,15 +551,18 @@ class FieldFn(torch.autograd.Function):
 
 
 class DensityFn(torch.autograd.Function):
-    """density_fn / get_density forward only (no-grad users: occupancy grid, sampler; umhs_model.py:208,553)."""
+    """density_fn / get_density forward only (no-grad users: occupancy grid, sampler; umhs_model.py:208,553).
+    ``keep``: a dict that receives the level-major hash features of the queried positions (``keep["enc"]``)."""
 
     @staticmethod
-    def forward(ctx, flat, positions, spec: FieldSpec):
+    def forward(ctx, flat, positions, spec: FieldSpec, keep=None):
         L = spec.layout
         p = _hip.f32c(positions).view(-1, 3)
         _, pos01, sel = positions_fwd(None, None, None, None, spec, world_pos_in=p)
         enc = hashgrid_fwd(pos01, L.view(flat.detach(), "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
         out = field_fwd(spec, flat.detach(), enc, True, None, None, sel, density_only=True)
+        if keep is not None:
+            keep["enc"] = enc
         ctx.mark_non_differentiable(out["sigma"], out["emb"])
         return out["sigma"].view(-1, 1), out["emb"]
 

@@ -104,6 +104,7 @@ class OccGridEstimator(nn.Module):
         if stratified:
             nears = nears + torch.rand_like(nears) * render_step_size
         bin_u8 = self.binaries.view(torch.uint8)
+        self.last_keep_index = None  # index of the survivors among the marched candidates, when a density pruning pass ran
         ri, t0, t1, pinfo = march_rays(rays_o, rays_d, bin_u8, self._roi, self.levels, self.res, near_plane, far_plane,
                                        render_step_size, cone_angle, nears, fars)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None and t0.numel() > 0:
@@ -112,6 +113,7 @@ class OccGridEstimator(nn.Module):
             keep = visibility_mask(sigmas, t0, t1, pinfo, early_stop_eps, alpha_thre)
             sel = torch.nonzero(keep).view(-1)  # one compaction index (one host sync) for the three packed arrays
             ri, t0, t1 = ri.index_select(0, sel), t0.index_select(0, sel), t1.index_select(0, sel)
+            self.last_keep_index = sel
         return ri, t0, t1
 
     def _occs_mean(self) -> float:

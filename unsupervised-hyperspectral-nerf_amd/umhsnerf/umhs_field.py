@@ -98,6 +98,7 @@ class UMHSField(nn.Module):
         self.register_buffer("live_rows", rows, persistent=False)
         self._sparse_end = n_sparse * (1 << log2_hashmap_size) * ops.FEATURES_PER_LEVEL
         self._cache: Optional[Tuple] = None
+        self._enc_capture = None
         self.use_grad_sink = False  # UMHSPipeline turns this on: backward writes param.grad in place (+ early all-reduce)
         self._grad_sink = None
 
@@ -186,6 +187,7 @@ class UMHSField(nn.Module):
     def density_fn(self, positions: Tensor, times: Optional[Tensor] = None) -> Tensor:
         """Density at raw positions [*,3] (occupancy grid / sampler, umhs_model.py:208,553); no-grad path."""
         shp = positions.shape[:-1]
+        keep = self._enc_capture  # a dict while the model's sampler wants the hash features of its candidates back, else None
         with torch.no_grad():
-            sigma, _ = ops.DensityFn.apply(self.flat, positions.reshape(-1, 3), self._spec())
+            sigma, _ = ops.DensityFn.apply(self.flat, positions.reshape(-1, 3), self._spec(), keep)
         return sigma.view(*shp, 1)

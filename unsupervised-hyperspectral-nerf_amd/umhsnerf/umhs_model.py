@@ -221,6 +221,21 @@ class UMHSModel(nn.Module):
     def sample(self, ray_bundle: RayBundle):
         """The sampler call of umhs_model.py:229-237 (no-grad): packed ray samples + ray_indices."""
         c = self.config
+        reuse = self.training and isinstance(self.sampler, VolumetricSampler) and os.environ.get("UMHS_REUSE_ENC", "1") != "0"
+        self.field._enc_capture = {} if reuse else None
+        try:
+            ray_samples, ray_indices = self._sample(ray_bundle)
+            cap = self.field._enc_capture
+        finally:
+            self.field._enc_capture = None
+        keep = getattr(self.sampler.occupancy_grid, "last_keep_index", None) if reuse else None
+        if reuse and keep is not None and "enc" in cap and keep.numel() == ray_indices.numel():
+            # the sampler's density query encoded every marched candidate: the survivors' features are a row gather away
+            ray_samples.metadata = {**(getattr(ray_samples, "metadata", None) or {}), "umhs_enc": (cap["enc"], keep)}
+        return ray_samples, ray_indices
+
+    def _sample(self, ray_bundle: RayBundle):
+        c = self.config
         with torch.no_grad():
             if isinstance(self.sampler, VolumetricSampler):
                 ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
@@ -323,7 +338,11 @@ class UMHSModel(nn.Module):
                 ops.field_fwd_prepare(spec, flat)
                 ev_pack.record(side)
                 ops.tmid_minmax(t0, t1, out=mm)
-        enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
+        cached = (getattr(ray_samples, "metadata", None) or {}).get("umhs_enc")
+        if cached is not None and cached[1].numel() == n:
+            enc = ops.enc_gather(cached[0], cached[1])  # encoded once, by the sampler's density query (same positions, same table)
+        else:
+            enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
         if side is not None:
             # the bucket histogram is LDS-atomic / VALU heavy: under the (L2-bound) hash gather it cost more than it hid; it starts
             # when the gather is done and runs under the field MLP
