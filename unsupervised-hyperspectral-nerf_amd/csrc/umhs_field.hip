@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "umhs_common.h"
+#include <atomic>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -1384,12 +1385,19 @@ static int check_cfg(const umhs_field_cfg* cfg) {
   return UMHS_OK;
 }
 
+// Raises a kernel's dynamic-LDS limit; remembered per kernel instantiation and device, so the driver call (which showed up as
+// a ~6 us bubble in front of every launch it preceded) is made once, not on every step.
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return UMHS_ERR_UNSUPPORTED;
+  static std::atomic<size_t> granted[16];  // per instantiation (a function-local static of a template) x device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  if (dev >= 0 && granted[dev].load(std::memory_order_relaxed) >= bytes) return UMHS_OK;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
       hipSuccess)
     return UMHS_ERR_LAUNCH;
+  if (dev >= 0) granted[dev].store(bytes, std::memory_order_relaxed);
   return UMHS_OK;
 }
 

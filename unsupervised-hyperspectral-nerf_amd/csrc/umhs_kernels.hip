@@ -3,6 +3,7 @@
 // (R11-R13), spectrum->sRGB fwd/bwd (R14) and the fused Adam step.  The MFMA field kernels live in
 // umhs_field.hip.  Reference citations are in include/umhs_hip.h.
 #include "umhs_common.h"
+#include <atomic>
 
 // =============================================================================================
 // R1 prefix: positions
@@ -513,9 +514,17 @@ static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stre
   dim3 pgrid((unsigned)((a.n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<true>, pgrid, dim3(256), 0, umhs_s(stream), a);
   const size_t lds = (size_t)(2 << a.bucket_bits) * 8;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(hg_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return UMHS_ERR_LAUNCH;
+  {  // raise the dynamic-LDS limit once per device, not per call (the driver call is a bubble in front of the launch)
+    static std::atomic<size_t> granted[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    if (dev < 0 || granted[dev].load(std::memory_order_relaxed) < lds) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(hg_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return UMHS_ERR_LAUNCH;
+      if (dev >= 0) granted[dev].store(lds, std::memory_order_relaxed);
+    }
+  }
   hipLaunchKernelGGL(hg_reduce_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(1024), lds, umhs_s(stream), a, d_table);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
