@@ -566,6 +566,33 @@ __device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restri
   }
 }
 
+// Layers with fewer tile pairs than waves (16-wide outputs or inputs: 1, 2 or 4 pairs): instead of 1-4 waves walking all
+// 32 k-steps while the others wait at the next barrier, every wave takes pair w % np and a 1/(WAVES/np) share of the k-steps
+// (samples); the slab reduce adds the partial tiles.  np = TO*TI must divide WAVES.
+template <int WAVES>
+__device__ __forceinline__ void dw_accum_ks(v4f (&acc)[1], const float* __restrict__ stZ, int FSz, const float* __restrict__ stX,
+                                            int FSx, int TO, int TI, int wave, int lane) {
+#ifdef UMHS_ABL_NO_DW
+  return;
+#endif
+  const int j = lane & 15, q = lane >> 4;
+  const int np = TO * TI, parts = WAVES / np, pair = wave % np, part = wave / np;
+  const int to = pair / TI, ti = pair % TI;
+  const int nks = (4 * WAVES) / parts, ks0 = part * nks;  // >= 4 k-steps, a multiple of 4
+  const float* __restrict__ px = stX + q * FSx + 16 * ti + j + 4 * (q >> 1);
+  const float* __restrict__ pz = stZ + q * FSz + 16 * to + j + 4 * (q >> 1);
+  for (int kb = ks0; kb < ks0 + nks; kb += 4) {
+    float b[4], a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ks = kb + u;
+      b[u] = px[4 * ks * FSx + 8 * (ks & 1)], a[u] = pz[4 * ks * FSz + 8 * (ks & 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[0] = MFMA(a[u], b[u], acc[0]);
+  }
+}
+
 // partial column sum of a staged tile: thread -> (column, row group); the slab reduce adds the row groups.
 // COLS > 0 (split kernels, which have registers to spare): compile-time width -> the row loop is fully unrolled with 4 LDS reads
 // in flight and one base address + immediate offsets (as a runtime loop hipcc serialises read -> wait -> add, ~100 cycles a row).
@@ -629,6 +656,20 @@ __device__ __forceinline__ void zero_acc(v4f (&a)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) a[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 }
+// K-split layers (dw_accum_ks): wave w holds a partial tile of pair w % np; fold the WAVES/np partials into wave (w % np) once,
+// at the end of the launch, through the (now free) staging region -- the slab and its reduce keep the one-owner-per-tile form.
+template <int WAVES>
+__device__ __forceinline__ void fold_ksplit(v4f (&acc)[1], float* st, int np, int wave, int lane) {
+  BSYNC();
+  *reinterpret_cast<v4f*>(st + (wave * 64 + lane) * 4) = acc[0];
+  BSYNC();
+  if (wave < np) {
+    v4f s = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int w = wave; w < WAVES; w += np) s += *reinterpret_cast<const v4f*>(st + (w * 64 + lane) * 4);
+    acc[0] = s;
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void store_acc(const v4f (&a)[N], float* slab, int off, int wave, int lane) {
 #pragma unroll
@@ -974,7 +1015,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
       stage_hid<4>(stX, 80, row, q, a2[0]);
       BSYNC();
-      dw_accum<1, WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
+      dw_accum_ks<WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
       db2 += col_sum_part<WAVES, 16>(stZ, 48, 16, tid);
       v4f g4[NT][4];
       gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
@@ -1051,44 +1092,29 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       ds1 = xq_sum(ds1);
       BSYNC();
       if (SPEC) {
-        dw_accum<NA, WAVES>(aD1, stZd, FSd, stXh, 48, TB, 1, wave, lane);
+        dw_accum_ks<WAVES>(aD1, stZd, FSd, stXh, 48, TB, 1, wave, lane);
         dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
       }
       {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: its rows are samples)
-        // Branch-free clamped addresses, U k-steps of loads in flight, one batch ahead of their MFMAs: a conditional load per
-        // MFMA made hipcc wait for global memory (s_waitcnt vmcnt(0)) 32 times per round.
+        // K-split like dw_accum_ks: wave w takes band tile w % TB and a 1/(WAVES/TB) share of the 32 k-steps; clamped, branch-free
+        // addresses and all loads of the share in flight before its MFMAs.
         const float* __restrict__ pm = stXm + q * 48 + j + 4 * (q >> 1);
-        constexpr int U = 8, NBAT = (4 * WAVES) / U;
-        float ga[2][U][NA], gb[2][U];
-        int bcol[NA];
-        bool bok[NA];
-  #pragma unroll
-        for (int idx = 0; idx < NA; ++idx) {
-          const int to = wave + idx * WAVES, b = 16 * to + j;
-          bok[idx] = to < TB && b < B;
-          bcol[idx] = bok[idx] ? b : 0;
-        }
-        auto fetch = [&](int batch, int slot) __attribute__((always_inline)) {
-  #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int ks = batch * U + u;
+        const int to = wave % TB, part = wave / TB, nks = (4 * WAVES) / (WAVES / TB), ks0 = part * nks;
+        const int bcol = 16 * to + j;
+        const bool bok = bcol < B;
+        const int bc = bok ? bcol : 0;
+        for (int kb = ks0; kb < ks0 + nks; kb += 4) {
+          float ga[4], gb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ks = kb + u;
             const int64_t ns = n0 + 4 * ks + q;
             const int64_t nsc = ns < io.n ? ns : io.n - 1;
-            gb[slot][u] = ns < io.n ? pm[4 * ks * 48 + 8 * (ks & 1)] : 0.0f;  // rows past the end carry zero weight
-  #pragma unroll
-            for (int idx = 0; idx < NA; ++idx) ga[slot][u][idx] = io.d_spectral[nsc * B + bcol[idx]];
+            gb[u] = ns < io.n ? pm[4 * ks * 48 + 8 * (ks & 1)] : 0.0f;  // rows past the end carry zero weight
+            ga[u] = io.d_spectral[nsc * B + bc];
           }
-        };
-        fetch(0, 0);
-  #pragma unroll
-        for (int batch = 0; batch < NBAT; ++batch) {
-          if (batch + 1 < NBAT) fetch(batch + 1, (batch + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0x7ff & ~0x1b0);  // loads (VMEM / LDS reads) keep their place
-  #pragma unroll
-          for (int u = 0; u < U; ++u)
-  #pragma unroll
-            for (int idx = 0; idx < NA; ++idx)
-              if (wave + idx * WAVES < TB) aMX[idx] = MFMA(bok[idx] ? ga[batch & 1][u][idx] : 0.0f, gb[batch & 1][u], aMX[idx]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) aMX[0] = MFMA(bok ? ga[u] : 0.0f, gb[u], aMX[0]);
         }
       }
       // =================== phase B: heads ===========================================================
@@ -1126,7 +1152,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
         for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 16 + 3 * q + s] = dir28[0][4 + s];
         if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
         BSYNC();
-        dw_accum<1, WAVES>(aD0, stZ, 48, stX, 48, 1, 2, wave, lane);
+        dw_accum_ks<WAVES>(aD0, stZ, 48, stX, 48, 1, 2, wave, lane);
         dbD0 += col_sum_part<WAVES, 16>(stZ, 48, 16, tid);
       }
       mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
@@ -1146,6 +1172,12 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       }
       if (ok) *reinterpret_cast<v4f*>(io.d_bo2 + n * 16 + 4 * q) = dbo4[0][0];
     }
+  }
+  if constexpr (PART == 0) {
+    fold_ksplit<WAVES>(aH2, st, 4, wave, lane), fold_ksplit<WAVES>(aMX, st, TB, wave, lane);
+    if (SPEC) fold_ksplit<WAVES>(aD0, st, 2, wave, lane), fold_ksplit<WAVES>(aD1, st, TB, wave, lane);
+  } else {
+    fold_ksplit<WAVES>(aF2, st, 4, wave, lane);
   }
   float* const slab = slabs + (size_t)blockIdx.x * sl.total;
   if constexpr (PART == 0) {
@@ -1736,7 +1768,7 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
     rc = set_lds(field_bwd_part_kernel<P_, S_>, pp.lds);                                                                 \
     if (rc) return rc;                                                                                                   \
     hipLaunchKernelGGL((field_bwd_part_kernel<P_, S_>), dim3(grid), dim3(512), pp.lds, umhs_s(stream), io, pp.pd, pp.td, \
-                       pl.sl, slabs, pp.wt_off, pp.stage_off, pl.FSd, (const float*)img, (const float*)wT, pp.seg_f,     \
+                       pl.sl, slabs, pp.wt_off, pp.stage_off, pl.FSd, (const float*)img, (const float*)wT, pp.seg_f,       \
                        pp.seg_t);                                                                                        \
   } while (0)
     if (spec) {
