@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzb1[0][0], dzb1[0][1], dzb1[0][2], dzb1[0][3]};
     stage_hid<4>(stX, 80, row, q, h[0]);
     BSYNC();
-    dw_accum<1, WAVES>(aB1, stZ, 48, stX, 80, 1, 4, wave, lane);
+    dw_accum_ks<WAVES>(aB1, stZ, 48, stX, 80, 1, 4, wave, lane);  // 4 tile pairs: K-split over the waves (8-wave form)
     dbB1 += col_sum_part<WAVES>(stZ, 48, 16, tid);
     v4f g4[NT][4];
     gemm_pack<4, 4, NT, 1>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
@@ -1286,6 +1286,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
         }
     }
   }
+  fold_ksplit<WAVES>(aB1, st, 4, wave, lane);
   float* const slab = slabs + (size_t)blockIdx.x * sl.total;
   store_acc(aB0, slab, sl.off[L_B0], wave, lane), store_acc(aB1, slab, sl.off[L_B1], wave, lane);
   BSYNC();
