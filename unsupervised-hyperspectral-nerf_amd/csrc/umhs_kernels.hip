@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 // same cell are merged by a wave segmented scan before a record is emitted (2-30x fewer records there).
 // ---------------------------------------------------------------------------------------------
 #define HB_BUCKET_BITS 13
+#ifndef HB_SPT
 #define HB_SPT 2  // samples per thread -> 512 samples per workgroup (<= 4096 records staged in 44 KiB of LDS)
+#endif
 
 struct HbArgs {
   const float* pos01;
@@ -218,6 +220,8 @@ struct HbArgs {
   int lev_off;                                 // this launch covers workspace levels [lev_off, lev_off + gridDim.y)
   int grad_mask;  // 1: samples whose gradient is exactly zero emit no records (both passes then need d_enc); 0: every sample does
   uint32_t *counts, *offsets, *cursor;  // [nlev * nb]
+  uint32_t *wg_counts, *wg_prefix;      // [nlev][nwg][nb]: per-workgroup bucket histogram, and (hg_wgscan) its exclusive prefix over
+  int nwg;                              // the workgroups of the level = each workgroup's private, atomics-free place in every bucket
   uint32_t* lmax;                       // [nlev] bits of the level's max |record value|
   uint16_t* rec_idx;                    // [8 * n * nlev]
   float2* rec_val;
@@ -250,7 +254,7 @@ __device__ __forceinline__ void seg_scan_step(float2 (&val)[8], bool& f, int l16
 }
 
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
+__device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg) {  // wg: which run of 256*HB_SPT samples
   __shared__ uint32_t hist[64];
   __shared__ uint32_t base[64];
   __shared__ uint32_t lbase[65];
@@ -264,6 +268,14 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
   if (tid < 64) hist[tid] = 0;
   if (tid == 0) wgmax = 0;
+  // scatter pass: the histogram pass left this workgroup's bucket counts and hg_wgscan its place in every bucket, so nothing is
+  // counted again and no global cursor is touched -- wave 0 fetches both here and turns them into LDS offsets after the hashing
+  uint32_t my_count = 0, my_base = 0;
+  if (SCATTER && tid < a.nb) {
+    const size_t o = ((size_t)lev * a.nwg + wg) * a.nb + tid;
+    my_count = a.wg_counts[o];
+    my_base = a.offsets[lev * a.nb + tid] + a.wg_prefix[o];
+  }
   __syncthreads();
   const float s = a.scalings[l];
   const uint32_t mask = (1u << a.log2_T) - 1u;
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
   float vmax = 0.0f;
 #pragma unroll
   for (int k = 0; k < HB_SPT; ++k) {
-    const int64_t i = (int64_t)blockIdx.x * (256 * HB_SPT) + k * 256 + tid;
+    const int64_t i = (int64_t)wg * (256 * HB_SPT) + k * 256 + tid;
     bool act = false;
     float g0 = 0.0f, g1 = 0.0f;
     uint32_t kx = 0xffffffffu, ky = 0, kz = 0, kf = 0x80000000u | (uint32_t)lane;  // unique per lane when inactive
@@ -307,14 +319,18 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
     if (SCATTER) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) val[k][c] = make_float2(w[c] * g0, w[c] * g1);
-      bool f = head;  // segmented inclusive scan over the row: (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv)
-      seg_scan_step<1>(val[k], f, l16), seg_scan_step<2>(val[k], f, l16);
-      seg_scan_step<4>(val[k], f, l16), seg_scan_step<8>(val[k], f, l16);
+      // segmented inclusive scan over the row: (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv) -- skipped (wave-uniform branch) when
+      // every lane of the wave starts its own run, i.e. nothing merges: always so on the fine levels, and 64 DPP moves + adds saved
+      if (__builtin_amdgcn_ballot_w64(!head) != 0) {
+        bool f = head;
+        seg_scan_step<1>(val[k], f, l16), seg_scan_step<2>(val[k], f, l16);
+        seg_scan_step<4>(val[k], f, l16), seg_scan_step<8>(val[k], f, l16);
+      }
     }
     if (emit[k]) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        atomicAdd(&hist[slot[k][c] >> a.bucket_bits], 1u);
+        if (!SCATTER) atomicAdd(&hist[slot[k][c] >> a.bucket_bits], 1u);
         if (SCATTER) vmax = fmaxf(vmax, fmaxf(fabsf(val[k][c].x), fabsf(val[k][c].y)));
       }
     }
@@ -324,13 +340,13 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
     for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
     if (lane == 0 && vmax > 0.0f) atomicMax(&wgmax, __float_as_uint(vmax));
   }
-  __syncthreads();
   if (!SCATTER) {
-    if (tid < a.nb && hist[tid]) atomicAdd(&a.counts[lev * a.nb + tid], hist[tid]);
+    __syncthreads();
+    if (tid < a.nb) a.wg_counts[((size_t)lev * a.nwg + wg) * a.nb + tid] = hist[tid];
     return;
   }
-  if (tid < 64) {  // wave 0: local exclusive prefix of the bucket counts + one global reservation per bucket
-    const uint32_t c = tid < a.nb ? hist[tid] : 0u;
+  if (tid < 64) {  // wave 0: local exclusive prefix of the bucket counts
+    const uint32_t c = my_count;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -339,13 +355,12 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
     }
     lbase[tid] = incl - c;
     if (tid == 63) lbase[64] = incl;
-    if (tid < a.nb) {
-      base[tid] = c ? atomicAdd(&a.cursor[lev * a.nb + tid], c) : 0u;
-      hist[tid] = 0;
-    }
+    // this workgroup's slice of bucket tid: bucket start + the records of the workgroups before it -- no cursor atomics (512
+    // workgroups x 64 buckets hammering 1024 counters made the returning atomic the longest step of the workgroup)
+    base[tid] = my_base;
   }
-  if (tid == 0 && wgmax) atomicMax(&a.lmax[lev], wgmax);
   __syncthreads();
+  if (tid == 0 && wgmax) atomicMax(&a.lmax[lev], wgmax);
   const uint32_t lowmask = (1u << a.bucket_bits) - 1u;
 #pragma unroll
   for (int k = 0; k < HB_SPT; ++k) {
@@ -367,6 +382,53 @@ __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
     const uint32_t g = base[b] + (i - lbase[b]);
     a.rec_idx[g] = recI[i];
     a.rec_val[g] = recV[i];
+  }
+}
+
+// Scatter pass: one workgroup per run of samples.  Histogram pass: gridDim.x workgroups per level walk the runs -- a caller that
+// hides the pass under other kernels (umhs_hashgrid_bwd_prepare on a side stream) launches few, so that it takes a small, steady
+// share of the CUs instead of flooding the dispatcher in front of the kernels it overlaps with.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
+  if (SCATTER) {
+    hg_partition_body<true>(a, (int)blockIdx.x);
+  } else {
+    for (int wg = blockIdx.x; wg < a.nwg; wg += gridDim.x) hg_partition_body<false>(a, wg);
+  }
+}
+
+// Per (level, bucket): exclusive prefix of the per-workgroup bucket counts over the level's workgroups, and the bucket total.
+// One 256-thread workgroup per (bucket, level): a thread sums its run of consecutive workgroups, the runs are scanned across the
+// block, and the thread writes its run's prefixes.  Also clears the level's max-|value| word for the scatter pass.
+__global__ __launch_bounds__(256) void hg_wgscan_kernel(HbArgs a) {
+  __shared__ uint32_t wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x, lev = blockIdx.y;
+  const int per = (a.nwg + 255) / 256, w0 = min(a.nwg, tid * per), w1 = min(a.nwg, w0 + per);
+  const uint32_t* __restrict__ col = a.wg_counts + (size_t)lev * a.nwg * a.nb + b;
+  uint32_t* __restrict__ pre = a.wg_prefix + (size_t)lev * a.nwg * a.nb + b;
+  uint32_t sum = 0;
+  for (int w = w0; w < w1; ++w) sum += col[(size_t)w * a.nb];
+  uint32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t run = incl - sum, total = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < wv) run += wsum[k];
+    total += wsum[k];
+  }
+  for (int w = w0; w < w1; ++w) {
+    pre[(size_t)w * a.nb] = run;
+    run += col[(size_t)w * a.nb];
+  }
+  if (tid == 0) {
+    a.counts[lev * a.nb + b] = total;
+    if (b == 0) a.lmax[lev] = 0u;
   }
 }
 
@@ -442,12 +504,13 @@ extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int
   const int nb = 1 << (log2_T - hb_bucket_bits(log2_T));
   if (nb > 64) return 0;  // log2_T > 19: only the atomic path is available
   const size_t m = (size_t)n_levels * nb, cap = (size_t)8 * n * n_levels;
-  return (3 * m + 64) * 4 + 256 + cap * 2 + 256 + cap * 8 + 256;
+  const size_t nwg = (size_t)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
+  return (3 * m + 64) * 4 + 256 + 2 * ((size_t)n_levels * nwg * nb * 4 + 256) + cap * 2 + 256 + cap * 8 + 256;
 }
 
 static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t n, int ws_begin, int ws_levels, int log2_T,
                    void* workspace, size_t workspace_bytes);
-static int hb_run_prepare(const HbArgs& a, int n_levels, umhs_stream_t stream);
+static int hb_run_prepare(const HbArgs& a, int n_levels, int count_wgs, umhs_stream_t stream);
 static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stream_t stream);
 
 extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
@@ -475,7 +538,7 @@ extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t
   if (rc) return rc;
   if ((uintptr_t)d_table & 15) return UMHS_ERR_WORKSPACE;
   a.d_enc = d_enc, a.sn = stride_n, a.sl = stride_l, a.overwrite = overwrite, a.grad_mask = 1;
-  rc = hb_run_prepare(a, n_levels, stream);
+  rc = hb_run_prepare(a, n_levels, 0, stream);
   if (rc) return rc;
   return hb_run_apply(a, n_levels, d_table, stream);
 }
@@ -493,17 +556,23 @@ static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
   a->counts = reinterpret_cast<uint32_t*>(p), a->lmax = a->counts + m, a->offsets = a->lmax + 64, a->cursor = a->offsets + m;
   p = (p + (3 * m + 64) * 4 + 255) & ~(uintptr_t)255;
+  a->nwg = (int)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
+  a->wg_counts = reinterpret_cast<uint32_t*>(p);
+  p = (p + (size_t)ws_levels * a->nwg * a->nb * 4 + 255) & ~(uintptr_t)255;
+  a->wg_prefix = reinterpret_cast<uint32_t*>(p);
+  p = (p + (size_t)ws_levels * a->nwg * a->nb * 4 + 255) & ~(uintptr_t)255;
   a->rec_idx = reinterpret_cast<uint16_t*>(p);
   p = (p + cap * 2 + 255) & ~(uintptr_t)255;
   a->rec_val = reinterpret_cast<float2*>(p);
   return UMHS_OK;
 }
 
-static int hb_run_prepare(const HbArgs& a, int n_levels, umhs_stream_t stream) {  // counts + lmax cleared, histogram, scan
+// histogram (count_wgs workgroups per level; 0 = one per run of samples), per-workgroup prefix, bucket scan
+static int hb_run_prepare(const HbArgs& a, int n_levels, int count_wgs, umhs_stream_t stream) {
   const size_t m = (size_t)a.nlev * a.nb;
-  if (hipMemsetAsync(a.counts, 0, (m + 64) * 4, umhs_s(stream)) != hipSuccess) return UMHS_ERR_LAUNCH;
-  dim3 pgrid((unsigned)((a.n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
+  dim3 pgrid((unsigned)(count_wgs > 0 && count_wgs < a.nwg ? count_wgs : a.nwg), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<false>, pgrid, dim3(256), 0, umhs_s(stream), a);
+  hipLaunchKernelGGL(hg_wgscan_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(256), 0, umhs_s(stream), a);
   hipLaunchKernelGGL(hg_scan_kernel, dim3(1), dim3(64), 0, umhs_s(stream), (const uint32_t*)a.counts, a.offsets, a.cursor,
                      (int)m);
   UMHS_CHECK_LAUNCH();
@@ -541,7 +610,11 @@ extern "C" int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalin
   HbArgs a;
   int rc = hb_args(&a, pos01, scalings, n, level_begin, n_levels, log2_T, workspace, workspace_bytes);
   if (rc) return rc;
-  return hb_run_prepare(a, n_levels, stream);
+  static const int throttle = [] {  // workgroups per level of the hidden histogram pass (0 = unthrottled)
+    const char* e = getenv("UMHS_HB_COUNT_WGS");
+    return e ? atoi(e) : 16;
+  }();
+  return hb_run_prepare(a, n_levels, throttle, stream);
 }
 
 // Gradient-dependent half: scatter the records of levels [level_begin, +n_levels) into their buckets and reduce every bucket

@@ -416,8 +416,10 @@ def ssim(a, b, data_range=None):
 
 
 def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb,
-                        prepared: bool = False, feat_logits=None):
-    """``prepared``: field_bwd_prepare and hashgrid_bwd_prepare (all levels) already ran for this step's parameters/positions.
+                        prepared: bool = False, feat_logits=None, hash_ready=None):
+    """``prepared``: field_bwd_prepare and hashgrid_bwd_prepare (all levels) already ran for this step's parameters/positions;
+    ``hash_ready``: event of the stream hashgrid_bwd_prepare was issued on -- waited for only in front of the scatter pass, so the
+    histogram may still be running under the field backward.
     Backward of the field (field_bwd + hash-grid scatter) into the flat gradient.  With a gradient sink that owns the next
     backward the buffer becomes ``param.grad`` directly, finished segments start their all-reduce, and None is returned;
     otherwise the freshly written flat gradient is returned (autograd accumulates it)."""
@@ -435,6 +437,8 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
         sink.segment_done(d_flat[tail:])
     table = L.view(d_flat, "mlp_base.encoder.hash_table")
     T = 1 << L.log2_hashmap_size
+    if prepared and hash_ready is not None:
+        torch.cuda.current_stream(flat.device).wait_event(hash_ready)
     for l0, cnt in (sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]):
         if prepared:  # histogram + scan of all levels were done ahead of time (hashgrid_bwd_prepare)
             hashgrid_bwd_apply(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
