@@ -331,38 +331,36 @@ class UMHSModel(nn.Module):
             main = torch.cuda.current_stream(self.device)
             mm = torch.empty(2, device=self.device, dtype=torch.float32)  # every allocation happens on the main stream
             can_partition = ops.reserve_step_workspaces(spec, n, self.device)
-            ev_in, ev_pack, ev_mm, ev_hash, ev_bpack, ev_done = (torch.cuda.Event() for _ in range(6))
+            ev_in, ev_ready, ev_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             ev_in.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_in)
                 ops.field_fwd_prepare(spec, flat)
-                ev_pack.record(side)
                 ops.tmid_minmax(t0, t1, out=mm)
-                ev_mm.record(side)
+                if can_partition and n > 0:
+                    ops.field_bwd_prepare(spec, flat, n)
+                ev_ready.record(side)  # one event for all three: every cross-stream wait is a barrier packet (~5 us) on main
         cached = (getattr(ray_samples, "metadata", None) or {}).get("umhs_enc")
         if cached is not None and cached[1].numel() == n:
             enc = ops.enc_gather(cached[0], cached[1])  # encoded once, by the sampler's density query (same positions, same table)
         else:
             enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
         if side is not None:
-            # the bucket histogram is LDS-atomic / VALU heavy: under the (L2-bound) hash gather it cost more than it hid; it starts
-            # when the gather is done and, throttled to a few workgroups per level, trickles along under everything up to the
-            # scatter pass of the hash-grid backward, the first kernel that needs it
+            # The bucket histogram is LDS-atomic / VALU heavy: under the (L2-bound) hash gather it cost more than it hid, even
+            # throttled.  It starts when the gather is done and, a few workgroups per level, trickles along under everything up
+            # to the scatter pass of the hash-grid backward, the first kernel that needs it.
+            ev_hash = torch.cuda.Event()
             ev_hash.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_hash)
                 if can_partition and n > 0:
-                    ops.field_bwd_prepare(spec, flat, n)
-                    ev_bpack.record(side)
                     prepared = ops.hashgrid_bwd_prepare(pos01, spec.scalings, L.log2_hashmap_size)
                 ev_done.record(side)
-            main.wait_event(ev_pack)
+            main.wait_event(ev_ready)
         fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
         values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
         weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
-        if side is not None:
-            main.wait_event(ev_mm)
-        else:
+        if side is None:
             mm = ops.tmid_minmax(t0, t1)
         spectral = comp[0]
         M = _hip.f32c(self.converter.transform_matrix)
@@ -376,8 +374,6 @@ class UMHSModel(nn.Module):
             w[0], w[1], both)
         d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
                                               bool(c.use_gradient_scaling))
-        if side is not None:
-            main.wait_event(ev_bpack if prepared else ev_done)
         left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_values[0], None,
                                        prepared=prepared, feat_logits=fo["feat_logits"], hash_ready=ev_done if side is not None else None)
         assert left is None  # direct_step_supported() guarantees the sink owned this backward
