@@ -178,3 +178,43 @@ def test_training_forward_reuses_the_samplers_hash_features(monkeypatch):
         res[reuse] = ({k: float(v) for k, v in loss.items()}, pipe.model.field.flat.grad.clone(), ri.numel())
     (l1, g1, n1), (l0, g0, n0) = res["1"], res["0"]
     assert n1 == n0 and l1 == l0 and torch.equal(g1, g0)
+
+
+def test_march_prefetched_one_step_ahead_is_the_same_training_run(monkeypatch):
+    """UMHSPipeline issues the next batch's occupancy march on a side stream under the current step's forward/backward.  Same rays,
+    same grid (steps that rewrite the grid are not prefetched), same order of generator draws -> the very same training run."""
+    import sys, os
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_hip_data import _split
+    from umhsnerf._ns_compat import RayBundle
+    from umhsnerf.data.umhs_datamanager import UMHSDataManager, UMHSDataManagerConfig
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    res = {}
+    for pre in ("1", "0"):
+        monkeypatch.setenv("UMHS_PREFETCH_MARCH", pre)
+        torch.manual_seed(7)
+        B = 8
+        split, _, _, _ = _split(n=4, B=B, const=0.5)
+        dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=1024), device=DEV, seed=4, train=split)
+        cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="random")
+        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=5, datamanager=dm)
+        used, losses = 0, []
+        for step in range(40):  # crosses the grid updates at steps 16 and 32
+            ahead = getattr(pipe, "_ahead", None)
+            used += int(ahead is not None and ahead[0] == step)
+            _, loss, _ = pipe.get_train_loss_dict(step)
+            losses.append(tuple(float(v) for v in loss.values()))
+            if step == 20:  # an eval-time march in between must not disturb the march that is in flight
+                pipe.model.eval()
+                full = dm.train_split.image_rays(0)
+                with torch.no_grad():
+                    pipe.model.sample(RayBundle(origins=full.origins.view(-1, 3), directions=full.directions.view(-1, 3)))
+                pipe.model.train()
+        torch.cuda.synchronize()
+        res[pre] = (losses, pipe.model.field.flat.detach().clone(), used)
+    assert res["1"][2] >= 35 and res["0"][2] == 0  # every step but the first and the grid-update steps ran on a prefetched march
+    assert res["1"][0] == res["0"][0]
+    assert torch.equal(res["1"][1], res["0"][1])

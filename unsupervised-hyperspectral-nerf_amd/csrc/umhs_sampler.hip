@@ -66,16 +66,16 @@ __global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
   if (t < t_end) {
     bool continuous = false, left_grid = false;
     float t_last = t;
-    // The voxel sequence a ray crosses is pure geometry: it does not depend on what the occupancy grid says.  So the walk runs in
-    // batches of KB voxels -- geometry for KB steps, then KB occupancy bytes fetched together, then the sample emission -- instead
-    // of one dependent load (an L2 round trip) per voxel, which was all this latency-bound kernel (64 waves in total) waited for.
     constexpr int KB = 8;
-    for (int guard = 0; t < t_end && guard < 100000 && !left_grid;) {
-      float vt0[KB], vtc[KB];
-      uint32_t vcell[KB];
-      uint8_t vocc[KB];
+    float tt = t;
+    int guard = 0;
+    // geometry of the next KB voxels from tt on: entry / clipped exit parameters and the cell index of each (slots past the end
+    // of the walk keep cell 0, so that every occupancy fetch is unconditional: a load under "k < nb" compiles to a branch +
+    // s_waitcnt vmcnt(0) each, KB serial L2 round trips -- exactly what the batch exists to avoid)
+    auto walk = [&](float (&vt0)[KB], float (&vtc)[KB], uint32_t (&vcell)[KB]) -> int {
       int nb = 0;
-      float tt = t;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) vcell[k] = 0;
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
         if (tt < t_end && guard < 100000 && !left_grid) {
@@ -115,14 +115,25 @@ __global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
           }
         }
       }
+      return nb;
+    };
+    // The voxel sequence a ray crosses is pure geometry: it does not depend on what the occupancy grid says.  So the walk runs in
+    // batches of KB voxels, software-pipelined: while the KB occupancy bytes of batch i are in flight (an L2 / MALL round trip,
+    // 1-2 us) the geometry of batch i+1 is computed; then the samples of batch i are emitted and the fetches of batch i+1 issued.
+    float at0[KB], atc[KB], bt0[KB], btc[KB];
+    uint32_t acell[KB], bcell[KB];
+    uint32_t aocc[KB];  // one register each: a uint8_t array is byte-packed by the compiler, which consumes (waits for) every fetch at once
+    int na = walk(at0, atc, acell);
 #pragma unroll
-      for (int k = 0; k < KB; ++k) vocc[k] = k < nb ? a.bin[vcell[k]] : (uint8_t)0;
+    for (int k = 0; k < KB; ++k) aocc[k] = a.bin[acell[k]];
+    while (na > 0) {
+      const int nb = walk(bt0, btc, bcell);
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
-        if (k < nb) {
-          const float t_clip = vtc[k];
-          if (vocc[k]) {
-            if (!continuous) t_last = vt0[k];
+        if (k < na) {
+          const float t_clip = atc[k];
+          if (aocc[k]) {
+            if (!continuous) t_last = at0[k];
             while (true) {
               const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
               if (!(t_last + dt * 0.5f < t_clip)) break;
@@ -139,9 +150,11 @@ __global__ __launch_bounds__(64) void march_kernel(MarchArgs a) {
           } else {
             continuous = false;
           }
-          t = t_clip;
         }
       }
+      na = nb;
+#pragma unroll
+      for (int k = 0; k < KB; ++k) at0[k] = bt0[k], atc[k] = btc[k], aocc[k] = a.bin[bcell[k]];
     }
   }
 #ifdef MARCH_DEBUG_ITERS  // diagnostic build only: voxel steps instead of sample counts

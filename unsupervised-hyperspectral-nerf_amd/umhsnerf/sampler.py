@@ -21,51 +21,113 @@ from ._hip import ptr
 from ._ns_compat import RayBundle, RaySamples, packed_ray_samples
 
 
-_scratch_cache = {}
+_scratch_pool = {}  # device index -> [(t_starts rows, t_ends rows, event of the last reader)]
 
 
-def _scratch(n: int, dev) -> Tuple[Tensor, Tensor]:
-    key = dev.index or 0
-    s = _scratch_cache.get(key)
-    if s is None or s[0].numel() < n:
-        s = _scratch_cache[key] = (torch.empty(n, device=dev), torch.empty(n, device=dev))
-    return s
+def _scratch_acquire(n: int, dev) -> Tuple[Tensor, Tensor]:
+    """[R, cap] scratch rows of the single-pass march.  A march in flight owns its pair (a prefetched march and an eval-time march
+    may be outstanding together); ``_scratch_release`` hands it back once the compaction that read it has been issued."""
+    pool = _scratch_pool.setdefault(dev.index or 0, [])
+    cur = torch.cuda.current_stream(dev)
+    for i, (a, b, ev) in enumerate(pool):
+        if a.numel() >= n:
+            pool.pop(i)
+            cur.wait_event(ev)
+            _use_on(cur, a, b)
+            return a, b
+    pool.clear()  # too small for this batch size: let them go
+    return torch.empty(n, device=dev), torch.empty(n, device=dev)
+
+
+def _scratch_release(pair, dev) -> None:
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _scratch_pool.setdefault(dev.index or 0, []).append((pair[0], pair[1], ev))
+
+
+class MarchHandle:
+    """A ray march in flight (``march_begin``): the walk has been issued, the sample count is on its way to the host."""
+
+    __slots__ = ("o", "d", "R", "bin", "args", "nears", "fars", "cap", "scratch", "counts", "packed_info", "host", "event", "stream")
+
+
+def _use_on(stream, *tensors) -> None:
+    """Tensors produced on another stream are about to be used on ``stream``: keep the allocator from recycling them early."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(stream)
+
+
+def march_begin(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aabb, levels: int, resolution: int, near: float,
+                far: float, step: float, cone: float, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None) -> MarchHandle:
+    """First half of ``march_rays`` -- everything before the host sync: the walk (single pass, samples parked in the [R, cap]
+    scratch rows), the per-ray prefix and an asynchronous copy of (total, longest row) to pinned host memory.  Issued on the
+    current stream; a trainer may issue it one step ahead on a side stream (``OccGridEstimator.prefetch_march``), provided
+    that stream is ordered after the previous ``march_finish`` (both use the one scratch buffer of the device)."""
+    h = MarchHandle()
+    h.o, h.d = _hip.f32c(origins), _hip.f32c(directions)
+    h.R, dev = h.o.shape[0], h.o.device
+    h.bin = binaries_u8
+    h.args = ((C.c_float * 6)(*[float(v) for v in roi_aabb]), levels, resolution, near, far, step, cone)
+    h.nears = _hip.f32c(nears) if nears is not None else None
+    h.fars = _hip.f32c(fars) if fars is not None else None
+    h.counts = torch.empty((h.R,), device=dev, dtype=torch.int64)
+    h.cap = int(os.environ.get("UMHS_MARCH_CAP", "1024"))  # scratch row per ray of the single-pass form (0: always two passes)
+    h.stream = torch.cuda.current_stream(dev)
+    h.scratch = _scratch_acquire(h.R * h.cap, dev) if (h.cap > 0 and h.R > 0) else None
+    lib = _hip.lib()
+    roi = h.args[0]
+    if h.scratch is not None:  # one walk: counts + the samples themselves parked in [R, cap] rows
+        _hip.check(lib.umhs_march_scratch(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone, ptr(h.nears),
+                                          ptr(h.fars), h.cap, ptr(h.counts), ptr(h.scratch[0]), ptr(h.scratch[1]), _hip.stream()),
+                   "umhs_march_scratch")
+    else:
+        _hip.check(lib.umhs_march_count(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone,
+                                        ptr(h.nears), ptr(h.fars), ptr(h.counts), _hip.stream()), "umhs_march_count")
+    ends_excl = torch.cumsum(h.counts, 0)
+    h.packed_info = torch.stack([ends_excl - h.counts, h.counts], dim=-1).contiguous()
+    # the sample count sizes the outputs: one host sync per batch, as in nerfacc (the row-overflow flag rides along)
+    h.host = torch.zeros(2, dtype=torch.int64).pin_memory()
+    if h.R > 0:
+        h.host.copy_(torch.stack([ends_excl[-1], h.counts.max()]), non_blocking=True)
+    h.event = torch.cuda.Event()
+    h.event.record(h.stream)
+    return h
+
+
+def march_finish(h: MarchHandle):
+    """Second half of ``march_rays``: wait for the count, size the outputs, move the samples from the scratch rows to their
+    packed places.  -> (ray_indices int64 [N], t_starts [N], t_ends [N], packed_info [R,2]) on the current stream."""
+    dev = h.o.device
+    h.event.synchronize()
+    n, cmax = (int(v) for v in h.host.tolist())
+    cur = torch.cuda.current_stream(dev)
+    if cur != h.stream:  # marched ahead of time on another stream
+        cur.wait_event(h.event)
+        _use_on(cur, h.o, h.d, h.nears, h.fars, h.counts, h.packed_info, *(h.scratch or ()))
+    t0 = torch.empty((n,), device=dev, dtype=torch.float32)
+    t1 = torch.empty((n,), device=dev, dtype=torch.float32)
+    ri = torch.empty((n,), device=dev, dtype=torch.int64)
+    if n > 0:
+        lib = _hip.lib()
+        roi, levels, resolution, near, far, step, cone = h.args
+        if h.scratch is not None and cmax <= h.cap:
+            _hip.check(lib.umhs_march_compact(ptr(h.packed_info), h.R, h.cap, ptr(h.scratch[0]), ptr(h.scratch[1]), ptr(t0), ptr(t1), ptr(ri),
+                                              _hip.stream()), "umhs_march_compact")
+        else:  # some ray overflowed its scratch row: second walk writing straight to the packed places
+            _hip.check(lib.umhs_march_write(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone,
+                                            ptr(h.nears), ptr(h.fars), ptr(h.packed_info), ptr(t0), ptr(t1), ptr(ri), _hip.stream()),
+                       "umhs_march_write")
+    if h.scratch is not None:
+        _scratch_release(h.scratch, dev)
+        h.scratch = None
+    return ri, t0, t1, h.packed_info
 
 
 def march_rays(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aabb, levels: int, resolution: int, near: float,
                far: float, step: float, cone: float, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None):
     """-> (ray_indices int64 [N], t_starts [N], t_ends [N], packed_info [R,2]) on the device."""
-    o, d = _hip.f32c(origins), _hip.f32c(directions)
-    R, dev = o.shape[0], o.device
-    roi = (C.c_float * 6)(*[float(v) for v in roi_aabb])
-    counts = torch.empty((R,), device=dev, dtype=torch.int64)
-    nears = _hip.f32c(nears) if nears is not None else None
-    fars = _hip.f32c(fars) if fars is not None else None
-    lib = _hip.lib()
-    cap = int(os.environ.get("UMHS_MARCH_CAP", "1024"))  # scratch row per ray of the single-pass form (0: always two passes)
-    scratch = _scratch(R * cap, dev) if (cap > 0 and R > 0) else None
-    if scratch is not None:  # one walk: counts + the samples themselves parked in [R, cap] rows
-        _hip.check(lib.umhs_march_scratch(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone, ptr(nears),
-                                          ptr(fars), cap, ptr(counts), ptr(scratch[0]), ptr(scratch[1]), _hip.stream()), "umhs_march_scratch")
-    else:
-        _hip.check(lib.umhs_march_count(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
-                                        ptr(nears), ptr(fars), ptr(counts), _hip.stream()), "umhs_march_count")
-    ends_excl = torch.cumsum(counts, 0)
-    packed_info = torch.stack([ends_excl - counts, counts], dim=-1).contiguous()
-    # the sample count sizes the outputs: one host sync per batch, as in nerfacc (the row-overflow flag rides along)
-    n, cmax = (int(v) for v in torch.stack([ends_excl[-1], counts.max()]).tolist()) if R > 0 else (0, 0)
-    t0 = torch.empty((n,), device=dev, dtype=torch.float32)
-    t1 = torch.empty((n,), device=dev, dtype=torch.float32)
-    ri = torch.empty((n,), device=dev, dtype=torch.int64)
-    if n > 0:
-        if scratch is not None and cmax <= cap:
-            _hip.check(lib.umhs_march_compact(ptr(packed_info), R, cap, ptr(scratch[0]), ptr(scratch[1]), ptr(t0), ptr(t1), ptr(ri),
-                                              _hip.stream()), "umhs_march_compact")
-        else:  # some ray overflowed its scratch row: second walk writing straight to the packed places
-            _hip.check(lib.umhs_march_write(ptr(o), ptr(d), R, ptr(binaries_u8), roi, levels, resolution, near, far, step, cone,
-                                            ptr(nears), ptr(fars), ptr(packed_info), ptr(t0), ptr(t1), ptr(ri), _hip.stream()),
-                       "umhs_march_write")
-    return ri, t0, t1, packed_info
+    return march_finish(march_begin(origins, directions, binaries_u8, roi_aabb, levels, resolution, near, far, step, cone, nears, fars))
 
 
 def visibility_mask(sigma: Tensor, t_starts: Tensor, t_ends: Tensor, packed_info: Tensor, early_stop_eps: float, alpha_thre: float):
@@ -99,14 +161,14 @@ class OccGridEstimator(nn.Module):
                  far_plane: float = 1e10, t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None,
                  render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
                  cone_angle: float = 0.0) -> Tuple[Tensor, Tensor, Tensor]:
-        nears = t_min if t_min is not None else torch.full_like(rays_o[..., 0], near_plane)
-        fars = t_max if t_max is not None else torch.full_like(rays_o[..., 0], far_plane)
-        if stratified:
-            nears = nears + torch.rand_like(nears) * render_step_size
-        bin_u8 = self.binaries.view(torch.uint8)
         self.last_keep_index = None  # index of the survivors among the marched candidates, when a density pruning pass ran
-        ri, t0, t1, pinfo = march_rays(rays_o, rays_d, bin_u8, self._roi, self.levels, self.res, near_plane, far_plane,
-                                       render_step_size, cone_angle, nears, fars)
+        pre = getattr(self, "_prefetched", None)
+        key = self._march_key(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
+        if pre is not None and pre[0] == key and pre[1] is self.binaries and pre[2] == self.binaries._version:
+            h, self._prefetched = pre[3], None  # this very march was issued ahead of time: same rays, same grid, jitter drawn
+        else:
+            h = self._march_begin(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
+        ri, t0, t1, pinfo = march_finish(h)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None and t0.numel() > 0:
             alpha_thre = min(alpha_thre, self._occs_mean())  # nerfacc reads occs.mean() per batch; it only changes in _update()
             sigmas = sigma_fn(t0, t1, ri)
@@ -115,6 +177,32 @@ class OccGridEstimator(nn.Module):
             ri, t0, t1 = ri.index_select(0, sel), t0.index_select(0, sel), t1.index_select(0, sel)
             self.last_keep_index = sel
         return ri, t0, t1
+
+    @staticmethod
+    def _march_key(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle):
+        return (rays_o.data_ptr(), rays_d.data_ptr(), tuple(rays_o.shape), float(near_plane), float(far_plane),
+                None if t_min is None else t_min.data_ptr(), None if t_max is None else t_max.data_ptr(), float(render_step_size),
+                bool(stratified), float(cone_angle))
+
+    def _march_begin(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle) -> MarchHandle:
+        nears = t_min if t_min is not None else torch.full_like(rays_o[..., 0], near_plane)
+        fars = t_max if t_max is not None else torch.full_like(rays_o[..., 0], far_plane)
+        if stratified:
+            nears = nears + torch.rand_like(nears) * render_step_size
+        return march_begin(rays_o, rays_d, self.binaries.view(torch.uint8), self._roi, self.levels, self.res, near_plane, far_plane,
+                           render_step_size, cone_angle, nears, fars)
+
+    def prefetch_march(self, rays_o: Tensor, rays_d: Tensor, near_plane: float = 0.0, far_plane: float = 1e10,
+                       t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
+                       stratified: bool = False, cone_angle: float = 0.0) -> None:
+        """Issue the ray march of a coming ``sampling()`` call now, on the current stream (a trainer's side stream, while the
+        previous step is still computing): the walk depends on the rays and the grid only, not on the field.  ``sampling()``
+        picks the result up when it is called with the same rays and arguments and the grid has not changed since; otherwise
+        the prefetched march is dropped.  The stratified jitter is drawn here, i.e. in the same order as without prefetch as
+        long as nothing else draws from the device generator in between."""
+        key = self._march_key(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
+        h = self._march_begin(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
+        self._prefetched = (key, self.binaries, self.binaries._version, h)
 
     def _occs_mean(self) -> float:
         m = getattr(self, "_occs_mean_cache", None)
@@ -182,12 +270,23 @@ class VolumetricSampler(nn.Module):
 
         return sigma_fn
 
-    def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane: Optional[float] = None,
-                alpha_thre: float = 0.01, cone_angle: float = 0.0) -> Tuple[RaySamples, Tensor]:
+    @staticmethod
+    def _march_inputs(ray_bundle: RayBundle, far_plane: Optional[float]):
         rays_o, rays_d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
         t_min = ray_bundle.nears.contiguous().reshape(-1) if ray_bundle.nears is not None and ray_bundle.fars is not None else None
         t_max = ray_bundle.fars.contiguous().reshape(-1) if t_min is not None else None
-        far_plane = 1e10 if far_plane is None else far_plane
+        return rays_o, rays_d, t_min, t_max, (1e10 if far_plane is None else far_plane)
+
+    def prefetch(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane: Optional[float] = None,
+                 alpha_thre: float = 0.01, cone_angle: float = 0.0) -> None:
+        """Start the march of a coming ``forward(ray_bundle, ...)`` on the current stream (see OccGridEstimator.prefetch_march)."""
+        rays_o, rays_d, t_min, t_max, far_plane = self._march_inputs(ray_bundle, far_plane)
+        self.occupancy_grid.prefetch_march(rays_o, rays_d, near_plane=near_plane, far_plane=far_plane, t_min=t_min, t_max=t_max,
+                                           render_step_size=render_step_size, stratified=self.training, cone_angle=cone_angle)
+
+    def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane: Optional[float] = None,
+                alpha_thre: float = 0.01, cone_angle: float = 0.0) -> Tuple[RaySamples, Tensor]:
+        rays_o, rays_d, t_min, t_max, far_plane = self._march_inputs(ray_bundle, far_plane)
         ri, t0, t1 = self.occupancy_grid.sampling(rays_o, rays_d, sigma_fn=self.get_sigma_fn(rays_o, rays_d), near_plane=near_plane,
                                                   far_plane=far_plane, t_min=t_min, t_max=t_max, render_step_size=render_step_size,
                                                   stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre)

@@ -234,6 +234,21 @@ class UMHSModel(nn.Module):
             ray_samples.metadata = {**(getattr(ray_samples, "metadata", None) or {}), "umhs_enc": (cap["enc"], keep)}
         return ray_samples, ray_indices
 
+    def prefetch_sample(self, ray_bundle: RayBundle) -> bool:
+        """Start the occupancy-grid march of a coming ``sample(ray_bundle)`` on the current stream (it depends on the rays and
+        the grid only).  The trainer calls this one step ahead on a side stream; ``sample`` picks the result up."""
+        c = self.config
+        if not isinstance(self.sampler, VolumetricSampler):
+            return False
+        with torch.no_grad():
+            self.sampler.prefetch(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
+                                  render_step_size=c.render_step_size, alpha_thre=c.alpha_thre, cone_angle=c.cone_angle)
+        return True
+
+    def occupancy_update_due(self, step: int) -> bool:
+        """Will ``update_occupancy_grid(step)`` rewrite the grid (OccGridEstimator.update_every_n_steps, n=16)?"""
+        return step % 16 == 0
+
     def _sample(self, ray_bundle: RayBundle):
         c = self.config
         with torch.no_grad():

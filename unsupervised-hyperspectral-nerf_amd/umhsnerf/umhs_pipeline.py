@@ -5,6 +5,7 @@
 Data managers / parsers / checkpoint I/O are nerfstudio's and out of scope for the hot path."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -22,6 +23,7 @@ class UMHSPipeline(torch.nn.Module):
                  seed: Optional[int] = 42, scene_box=None, datamanager=None):
         super().__init__()
         self.world_size, self.local_rank = world_size, local_rank
+        self.device = torch.device(device)
         self.datamanager = datamanager  # data.umhs_datamanager.UMHSDataManager (umhs_pipeline.py:87-94) or None (packed-sample callers)
         if datamanager is not None:
             metadata = {**(datamanager.metadata or {}), **(metadata or {})}
@@ -52,11 +54,15 @@ class UMHSPipeline(torch.nn.Module):
         """One ``Trainer.train_iteration``: BEFORE callbacks (occupancy grid), next_train, forward, loss, backward, Adam (+ gradient
         reduction), AFTER callbacks (clamp_endmembers, fused into the Adam kernel).  Returns (outputs, loss_dict, metrics_dict)."""
         self._model.update_occupancy_grid(step)
-        ray_bundle, batch = self.datamanager.next_train(step)
+        ray_bundle, batch = self._next_train(step)
         self.optimizer.zero_grad(set_to_none=True)
         if self._model.direct_step_supported(batch):
             ray_samples, ray_indices = self._model.sample(ray_bundle)
+            sampled = torch.cuda.Event() if self.device.type == "cuda" else None
+            if sampled is not None:
+                sampled.record(torch.cuda.current_stream(self.device))  # the grid is final for this step and the scratch rows of this step's march have been read
             outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch)
+            self._prefetch_next(step + 1, sampled)  # enqueued behind this step's launches, executed under them
             metrics_dict = self._model.get_metrics_dict(outputs, batch)
         else:
             outputs = self._model(ray_bundle)
@@ -65,6 +71,39 @@ class UMHSPipeline(torch.nn.Module):
             sum(loss_dict.values()).backward()
         self.optimizer.step()
         return outputs, loss_dict, metrics_dict
+
+    # ---- one-step-ahead ray batch + occupancy march -------------------------------------------------------------------
+    # The march of a batch needs the rays and the occupancy grid only -- not the field -- and it is one latency-bound
+    # dependency chain per ray (a few hundred waves, ~0.8 ms): issued on its own stream right after the current step's
+    # launches, it runs in the shadow of this step's forward/backward instead of in front of the next one.  Skipped when the
+    # next step rewrites the grid.  The batch is drawn from the data manager's own generator and the stratified jitter from
+    # the device generator in the same order as without prefetch (nothing else draws between the two), so the training
+    # trajectory is bit-identical either way (tests/test_hip_sampler.py).
+    def _next_train(self, step: int):
+        pre, self._ahead = getattr(self, "_ahead", None), None
+        if pre is None or pre[0] != step:
+            return self.datamanager.next_train(step)
+        _, ray_bundle, batch, ready = pre
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ready)
+        for t in _tensors_of(ray_bundle) + _tensors_of(batch):
+            t.record_stream(main)
+        return ray_bundle, batch
+
+    def _prefetch_next(self, step: int, sampled) -> None:
+        if (sampled is None or self.device.type != "cuda" or os.environ.get("UMHS_PREFETCH_MARCH", "1") == "0" or not self._model.training
+                or self._model.occupancy_update_due(step)):
+            return
+        side = getattr(self, "_ahead_stream", None)
+        if side is None:
+            side = self._ahead_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(side):
+            side.wait_event(sampled)
+            ray_bundle, batch = self.datamanager.next_train(step)
+            self._model.prefetch_sample(ray_bundle)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        self._ahead = (step, ray_bundle, batch, ready)
 
     @torch.no_grad()
     def get_eval_loss_dict(self, step: int):
@@ -85,6 +124,19 @@ class UMHSPipeline(torch.nn.Module):
         metrics_dict["num_rays"] = int(camera_ray_bundle.origins.shape[0] * camera_ray_bundle.origins.shape[1])
         self.train()
         return metrics_dict, images_dict
+
+
+def _tensors_of(obj) -> list:
+    """Every CUDA tensor reachable from a batch dict / RayBundle (for stream bookkeeping)."""
+    if torch.is_tensor(obj):
+        return [obj] if obj.is_cuda else []
+    if isinstance(obj, dict):
+        return [t for v in obj.values() for t in _tensors_of(v)]
+    if isinstance(obj, (list, tuple)):
+        return [t for v in obj for t in _tensors_of(v)]
+    if hasattr(obj, "__dict__"):
+        return [t for v in vars(obj).values() for t in _tensors_of(v)]
+    return []
 
 
 def make_nerfstudio_trainer_config(defaults):  # pragma: no cover - needs nerfstudio
