@@ -117,3 +117,28 @@ def test_oracle_ray_generator_analytic_cases():
     assert idx.tolist() == [[0, 3, 7], [9, 0, 2]]
     stack = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).view(2, 3, 4, 5)
     assert T.gather_pixels(torch.tensor([[1, 2, 3]]), stack).tolist() == [stack[1, 2, 3].tolist()]
+
+
+def test_lazy_training_metrics_behave_like_the_dict_they_replace():
+    """UMHSModel.get_metrics_dict hands the trainer a dict whose values are computed when read (host logic only)."""
+    import torch
+    from umhsnerf.umhs_model import LazyMetrics
+
+    calls = []
+
+    def thunk(name, v):
+        def f():
+            calls.append(name)
+            return torch.tensor(v)
+        return f
+
+    m = LazyMetrics({"psnr": thunk("psnr", 30.0), "rmse": thunk("rmse", 0.1)})
+    assert "psnr" in m and "nope" not in m and calls == []
+    assert float(m["psnr"]) == 30.0 and calls == ["psnr"]
+    assert float(m["psnr"]) == 30.0 and calls == ["psnr"]  # computed once
+    assert m.get("nope") is None and float(m.get("rmse")) == pytest.approx(0.1) and calls == ["psnr", "rmse"]
+    with pytest.raises(KeyError):
+        m["nope"]
+    m2 = LazyMetrics({"a": thunk("a", 1.0), "b": thunk("b", 2.0)})
+    assert sorted(m2.keys()) == ["a", "b"] and len(m2) == 2 and {k: float(v) for k, v in m2.items()} == {"a": 1.0, "b": 2.0}
+    assert dict(LazyMetrics({"a": thunk("a", 1.0)})) == {"a": torch.tensor(1.0)}

@@ -13,7 +13,7 @@ from __future__ import annotations
 import os
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Literal, Optional, Tuple, Union
+from typing import Callable, Dict, List, Literal, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -122,6 +122,49 @@ class BandOutputs(dict):
         return self
 
     # anything that enumerates the dict sees the full key set of the reference
+    def __iter__(self):
+        return dict.__iter__(self.materialize())
+
+    def __len__(self):
+        return dict.__len__(self.materialize())
+
+    def keys(self):
+        return dict.keys(self.materialize())
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def values(self):
+        return dict.values(self.materialize())
+
+
+class LazyMetrics(dict):
+    """Metrics dict whose entries are computed on first access.  nerfstudio's trainer reads the training metrics every
+    ``steps_per_log`` steps only; the ~15 small reduction kernels behind them (1.4 % of a sampler-driven step) then run only when
+    somebody looks.  The thunks hold the step's outputs / batch tensors, which nothing modifies in place afterwards."""
+
+    def __init__(self, thunks: Dict[str, Callable[[], Tensor]]):
+        super().__init__()
+        self._thunks = dict(thunks)
+
+    def __missing__(self, key):
+        fn = self._thunks.pop(key, None)
+        if fn is None:
+            raise KeyError(key)
+        v = self[key] = fn()
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._thunks
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def materialize(self) -> "LazyMetrics":
+        for k in list(self._thunks):
+            self[k]
+        return self
+
     def __iter__(self):
         return dict.__iter__(self.materialize())
 
@@ -452,16 +495,15 @@ class UMHSModel(nn.Module):
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
         """umhs_model.py:385-405.  Values stay device tensors (the reference's ``.item()`` calls would sync the stream)."""
-        md = {}
-        gt_rgb = batch["image"].to(self.device)[..., :3]
-        md["psnr"] = self.psnr(outputs["rgb"], gt_rgb)
-        md["rmse"] = torch.sqrt(torch.nn.functional.mse_loss(outputs["rgb"], gt_rgb))
+        rgb, gt_rgb, nspr = outputs["rgb"].detach(), batch["image"].to(self.device)[..., :3], outputs["num_samples_per_ray"]
+        md = {"psnr": lambda: self.psnr(rgb, gt_rgb), "rmse": lambda: torch.sqrt(torch.nn.functional.mse_loss(rgb, gt_rgb))}
         if "spectral" in self.config.method:
-            gt = batch["hs_image"].to(self.device)
-            md["psnr_spectral"] = self.psnr(outputs["spectral"], gt)
-            md["rmse_spectral"] = torch.sqrt(torch.nn.functional.mse_loss(outputs["spectral"], gt))
-        md["num_samples_per_batch"] = outputs["num_samples_per_ray"].sum()
-        return md
+            spec, gt = outputs["spectral"].detach(), batch["hs_image"].to(self.device)
+            md["psnr_spectral"] = lambda: self.psnr(spec, gt)
+            md["rmse_spectral"] = lambda: torch.sqrt(torch.nn.functional.mse_loss(spec, gt))
+        md["num_samples_per_batch"] = lambda: nspr.sum()
+        lazy = LazyMetrics(md)
+        return lazy if (self.training and os.environ.get("UMHS_LAZY_METRICS", "1") != "0") else dict(lazy.materialize())
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
