@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 2
+#define UMHS_ABI_VERSION 3
 
 enum {
   UMHS_OK = 0,
@@ -263,23 +263,43 @@ int umhs_ray_train_tail(const float* spectral, const float* M, const float* endm
 /* ------------------------------------------------------------------------------------------ */
 int umhs_march_count(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
                      const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
-                     float step_size, float cone_angle, const float* nears, const float* fars, int64_t* counts,
-                     umhs_stream_t stream);
+                     float step_size, float cone_angle, const float* nears, const float* fars, const float* jitter,
+                     float jitter_step, int64_t* counts, umhs_stream_t stream);
 int umhs_march_write(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
                      const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
-                     float step_size, float cone_angle, const float* nears, const float* fars, const int64_t* packed_info,
-                     float* t_starts, float* t_ends, int64_t* ray_indices, umhs_stream_t stream);
+                     float step_size, float cone_angle, const float* nears, const float* fars, const float* jitter,
+                     float jitter_step, const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,
+                     umhs_stream_t stream);
 /* Single pass instead of count + write: umhs_march_scratch counts AND parks the first `cap` samples of ray r in             */
 /* scratch_t0/t1[r*cap + i]; after the caller's scan, umhs_march_compact moves them to their packed places.  A count > cap     */
 /* means that ray overflowed its row: fall back to umhs_march_write for the batch.                                            */
 int umhs_march_scratch(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
                        const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
-                       float step_size, float cone_angle, const float* nears, const float* fars, int cap, int64_t* counts,
-                       float* scratch_t0, float* scratch_t1, umhs_stream_t stream);
+                       float step_size, float cone_angle, const float* nears, const float* fars, const float* jitter,
+                       float jitter_step, int cap, int64_t* counts, float* scratch_t0, float* scratch_t1, umhs_stream_t stream);
 int umhs_march_compact(const int64_t* packed_info, int64_t n_rays, int cap, const float* scratch_t0, const float* scratch_t1,
                        float* t_starts, float* t_ends, int64_t* ray_indices, umhs_stream_t stream);
 int umhs_visibility(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
                     int64_t n_rays, int64_t n, float early_stop_eps, float alpha_thre, uint8_t* mask, umhs_stream_t stream);
+/* `jitter` [R] or NULL (all three march entry points): the near plane of ray r is nears[r] (or near_plane) + jitter[r] *      */
+/* jitter_step -- nerfacc's stratified start, folded into the walk instead of two fills, a multiply and an add in front of it.  */
+/* umhs_visibility_count also returns kept[R], the survivors per ray; umhs_ray_prefix turns per-ray counts into packed_info     */
+/* [R,2] = (exclusive prefix, count) and stats[2] = (total, longest) -- used for the marched candidates and for the survivors;   */
+/* umhs_sample_midpoints = origins[ri] + directions[ri] * (t_starts + t_ends) / 2 (VolumetricSampler's sigma_fn positions);     */
+/* umhs_compact_samples moves the survivors (order within the ray kept) to their packed places and gathers their ray's origin,   */
+/* direction and camera index (camera_indices / out_camera_indices both NULL or both set); out_sel[j] = candidate index of       */
+/* survivor j.  Together: the sampler's torch.nonzero + 3 index_select + 3 gathers + pack_info as one launch after its host sync. */
+int umhs_visibility_count(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                          int64_t n_rays, int64_t n, float early_stop_eps, float alpha_thre, uint8_t* mask, int64_t* kept,
+                          umhs_stream_t stream);
+int umhs_ray_prefix(const int64_t* counts, int64_t n_rays, int64_t* packed_info, int64_t* stats, umhs_stream_t stream);
+int umhs_sample_midpoints(const float* origins, const float* directions, const int64_t* ray_indices, const float* t_starts,
+                          const float* t_ends, int64_t n, float* positions, umhs_stream_t stream);
+int umhs_compact_samples(const uint8_t* mask, const int64_t* packed_in, const int64_t* packed_out, int64_t n_rays,
+                         const float* t_starts, const float* t_ends, const float* origins, const float* directions,
+                         const int64_t* camera_indices, int64_t* out_ray_indices, float* out_t_starts, float* out_t_ends,
+                         float* out_origins, float* out_directions, int64_t* out_camera_indices, int64_t* out_sel,
+                         umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* pixel sampler, ray generator and ground-truth gather (images resident in HBM, --images-on-gpu).    */

@@ -218,3 +218,56 @@ def test_march_prefetched_one_step_ahead_is_the_same_training_run(monkeypatch):
     assert res["1"][2] >= 35 and res["0"][2] == 0  # every step but the first and the grid-update steps ran on a prefetched march
     assert res["1"][0] == res["0"][0]
     assert torch.equal(res["1"][1], res["0"][1])
+
+
+def test_fused_sampler_steps_match_the_torch_ops_they_replace():
+    """ray_prefix / in-walk jitter / sample_midpoints / visibility_count + compact_samples vs cumsum, nears + rand * step, the
+    sigma_fn expression, nonzero + index_select + gathers + pack_info: every one bit for bit."""
+    from umhsnerf.sampler import compact_samples, march_rays, ray_prefix, sample_midpoints, visibility_mask
+
+    g = torch.Generator().manual_seed(5)
+    for R in (1, 7, 1024, 2500):
+        counts = torch.randint(0, 300, (R,), generator=g)
+        counts[torch.rand(R, generator=g) < 0.2] = 0
+        pinfo, stats = ray_prefix(counts.to(DEV))
+        ends = torch.cumsum(counts, 0)
+        assert torch.equal(pinfo.cpu(), torch.stack([ends - counts, counts], -1))
+        assert stats.tolist() == [int(ends[-1]), int(counts.max())]
+    # stratified start inside the walk == per-ray near planes prepared by torch
+    levels, res, step = 3, 16, 0.02
+    binaries = np.random.default_rng(3).random((levels, res, res, res)) < 0.3
+    bin_u8 = torch.from_numpy(binaries.astype(np.uint8)).to(DEV)
+    R = 300
+    o, d = (t.to(DEV) for t in _rays(R, seed=9))
+    roi = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+    jit = torch.rand(R, generator=g).to(DEV)
+    nears = torch.full((R,), 0.05, device=DEV) + jit * step
+    a = march_rays(o, d, bin_u8, roi, levels, res, 0.05, 1e3, step, 0.004, jitter=jit, jitter_step=step)
+    b = march_rays(o, d, bin_u8, roi, levels, res, 0.05, 1e3, step, 0.004, nears=nears, fars=torch.full((R,), 1e3, device=DEV))
+    assert a[0].numel() > 2000 and all(torch.equal(x, y) for x, y in zip(a, b))
+    ri, t0, t1, pinfo = a
+    # midpoints
+    pos = sample_midpoints(o, d, ri, t0, t1)
+    assert torch.equal(pos, o[ri] + d[ri] * (t0 + t1)[:, None] / 2.0)
+    # pruning + compaction
+    sigma = (torch.rand(ri.numel(), generator=g) * 40).to(DEV)
+    sigma[torch.rand(ri.numel(), generator=g).to(DEV) < 0.3] = 0.0
+    cam = torch.randint(0, 5, (R, 1), generator=g).to(DEV)
+    keep = visibility_mask(sigma, t0, t1, pinfo, 1e-4, 0.01)
+    mask, kept = visibility_mask(sigma, t0, t1, pinfo, 1e-4, 0.01, with_counts=True)
+    assert torch.equal(mask.bool(), keep)
+    sel = torch.nonzero(keep).view(-1)
+    assert 0 < sel.numel() < ri.numel()
+    pinfo2, stats = ray_prefix(kept)
+    assert int(stats[0]) == sel.numel() and torch.equal(pinfo2.cpu(), T.pack_info(ri[sel].cpu(), R))
+    for c in (cam, None):
+        out = compact_samples(mask, pinfo, pinfo2, sel.numel(), t0, t1, o, d, c)
+        assert torch.equal(out["sel"], sel) and torch.equal(out["ray_indices"], ri[sel])
+        assert torch.equal(out["t_starts"], t0[sel]) and torch.equal(out["t_ends"], t1[sel])
+        assert torch.equal(out["origins"], o[ri[sel]]) and torch.equal(out["directions"], d[ri[sel]])
+        assert (out["camera_indices"] is None) if c is None else torch.equal(out["camera_indices"], cam[ri[sel]])
+    # nothing survives / nothing marched
+    none = compact_samples(torch.zeros_like(mask), pinfo, torch.zeros_like(pinfo2), 0, t0, t1, o, d, cam)
+    assert none["ray_indices"].numel() == 0 and none["origins"].shape == (0, 3)
+    p0, s0 = ray_prefix(torch.zeros(0, dtype=torch.int64, device=DEV))
+    assert p0.shape == (0, 2) and s0.tolist() == [0, 0]

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
+ABI_VERSION = 3  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
 LIB_PATH = os.environ.get("UMHS_LIB_PATH") or os.path.join(_HERE, "libumhs_hip.so")  # override: A/B builds of tools/ab_lib.sh
 MAX_STREAMS = 4
 
@@ -79,11 +79,15 @@ SIGNATURES = {
     "umhs_ray_epilogue_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "umhs_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp]),
     "umhs_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "umhs_march_count": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
-    "umhs_march_write": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "umhs_march_scratch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "umhs_march_count": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "umhs_march_write": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "umhs_march_scratch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, C.c_int, _vp, _vp, _vp, _vp]),
     "umhs_march_compact": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "umhs_visibility": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "umhs_visibility_count": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp, _vp]),
+    "umhs_ray_prefix": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "umhs_sample_midpoints": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "umhs_compact_samples": (C.c_int, [_vp] * 3 + [_i64] + [_vp] * 13),
     "umhs_ray_train_tail_scratch_bytes": (C.c_size_t, []),
     "umhs_ray_train_tail": (C.c_int, [_vp] * 10 + [_i64, C.c_int, C.c_int, _f32, _f32, _f32, C.c_int] + [_vp] * 9 + [C.c_size_t, _vp]),
     "umhs_enc_gather": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, _vp, _vp]),

@@ -48,7 +48,8 @@ def _scratch_release(pair, dev) -> None:
 class MarchHandle:
     """A ray march in flight (``march_begin``): the walk has been issued, the sample count is on its way to the host."""
 
-    __slots__ = ("o", "d", "R", "bin", "args", "nears", "fars", "cap", "scratch", "counts", "packed_info", "host", "event", "stream")
+    __slots__ = ("o", "d", "R", "bin", "args", "nears", "fars", "jitter", "cap", "scratch", "counts", "packed_info", "stats", "host",
+                 "event", "stream")
 
 
 def _use_on(stream, *tensors) -> None:
@@ -58,8 +59,28 @@ def _use_on(stream, *tensors) -> None:
             t.record_stream(stream)
 
 
+def ray_prefix(counts: Tensor) -> Tuple[Tensor, Tensor]:
+    """Per-ray counts [R] int64 -> (packed_info [R,2] = (exclusive prefix, count), stats [2] = (total, longest)); one launch."""
+    R = counts.shape[0]
+    packed_info = torch.empty((R, 2), device=counts.device, dtype=torch.int64)
+    stats = torch.empty((2,), device=counts.device, dtype=torch.int64)
+    _hip.check(_hip.lib().umhs_ray_prefix(ptr(counts), R, ptr(packed_info), ptr(stats), _hip.stream()), "umhs_ray_prefix")
+    return packed_info, stats
+
+
+def sample_midpoints(origins: Tensor, directions: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor) -> Tensor:
+    """origins[ray_indices] + directions[ray_indices] * (t_starts + t_ends)[:, None] / 2.0 (same bits), one launch."""
+    n = ray_indices.shape[0]
+    pos = torch.empty((n, 3), device=origins.device, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_sample_midpoints(ptr(_hip.f32c(origins)), ptr(_hip.f32c(directions)), ptr(ray_indices.contiguous()),
+                                                ptr(_hip.f32c(t_starts)), ptr(_hip.f32c(t_ends)), n, ptr(pos), _hip.stream()),
+               "umhs_sample_midpoints")
+    return pos
+
+
 def march_begin(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aabb, levels: int, resolution: int, near: float,
-                far: float, step: float, cone: float, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None) -> MarchHandle:
+                far: float, step: float, cone: float, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None,
+                jitter: Optional[Tensor] = None, jitter_step: float = 0.0) -> MarchHandle:
     """First half of ``march_rays`` -- everything before the host sync: the walk (single pass, samples parked in the [R, cap]
     scratch rows), the per-ray prefix and an asynchronous copy of (total, longest row) to pinned host memory.  Issued on the
     current stream; a trainer may issue it one step ahead on a side stream (``OccGridEstimator.prefetch_march``), provided
@@ -71,6 +92,7 @@ def march_begin(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aa
     h.args = ((C.c_float * 6)(*[float(v) for v in roi_aabb]), levels, resolution, near, far, step, cone)
     h.nears = _hip.f32c(nears) if nears is not None else None
     h.fars = _hip.f32c(fars) if fars is not None else None
+    h.jitter = (_hip.f32c(jitter), float(jitter_step)) if jitter is not None else (None, 0.0)
     h.counts = torch.empty((h.R,), device=dev, dtype=torch.int64)
     h.cap = int(os.environ.get("UMHS_MARCH_CAP", "1024"))  # scratch row per ray of the single-pass form (0: always two passes)
     h.stream = torch.cuda.current_stream(dev)
@@ -79,17 +101,16 @@ def march_begin(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aa
     roi = h.args[0]
     if h.scratch is not None:  # one walk: counts + the samples themselves parked in [R, cap] rows
         _hip.check(lib.umhs_march_scratch(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone, ptr(h.nears),
-                                          ptr(h.fars), h.cap, ptr(h.counts), ptr(h.scratch[0]), ptr(h.scratch[1]), _hip.stream()),
+                                          ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], h.cap, ptr(h.counts), ptr(h.scratch[0]), ptr(h.scratch[1]), _hip.stream()),
                    "umhs_march_scratch")
     else:
         _hip.check(lib.umhs_march_count(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone,
-                                        ptr(h.nears), ptr(h.fars), ptr(h.counts), _hip.stream()), "umhs_march_count")
-    ends_excl = torch.cumsum(h.counts, 0)
-    h.packed_info = torch.stack([ends_excl - h.counts, h.counts], dim=-1).contiguous()
+                                        ptr(h.nears), ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], ptr(h.counts), _hip.stream()),
+                   "umhs_march_count")
+    h.packed_info, h.stats = ray_prefix(h.counts)
     # the sample count sizes the outputs: one host sync per batch, as in nerfacc (the row-overflow flag rides along)
     h.host = torch.zeros(2, dtype=torch.int64).pin_memory()
-    if h.R > 0:
-        h.host.copy_(torch.stack([ends_excl[-1], h.counts.max()]), non_blocking=True)
+    h.host.copy_(h.stats, non_blocking=True)
     h.event = torch.cuda.Event()
     h.event.record(h.stream)
     return h
@@ -104,7 +125,7 @@ def march_finish(h: MarchHandle):
     cur = torch.cuda.current_stream(dev)
     if cur != h.stream:  # marched ahead of time on another stream
         cur.wait_event(h.event)
-        _use_on(cur, h.o, h.d, h.nears, h.fars, h.counts, h.packed_info, *(h.scratch or ()))
+        _use_on(cur, h.o, h.d, h.nears, h.fars, h.jitter[0], h.counts, h.packed_info, h.stats, *(h.scratch or ()))
     t0 = torch.empty((n,), device=dev, dtype=torch.float32)
     t1 = torch.empty((n,), device=dev, dtype=torch.float32)
     ri = torch.empty((n,), device=dev, dtype=torch.int64)
@@ -116,7 +137,8 @@ def march_finish(h: MarchHandle):
                                               _hip.stream()), "umhs_march_compact")
         else:  # some ray overflowed its scratch row: second walk writing straight to the packed places
             _hip.check(lib.umhs_march_write(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone,
-                                            ptr(h.nears), ptr(h.fars), ptr(h.packed_info), ptr(t0), ptr(t1), ptr(ri), _hip.stream()),
+                                            ptr(h.nears), ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], ptr(h.packed_info), ptr(t0),
+                                            ptr(t1), ptr(ri), _hip.stream()),
                        "umhs_march_write")
     if h.scratch is not None:
         _scratch_release(h.scratch, dev)
@@ -125,17 +147,48 @@ def march_finish(h: MarchHandle):
 
 
 def march_rays(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aabb, levels: int, resolution: int, near: float,
-               far: float, step: float, cone: float, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None):
+               far: float, step: float, cone: float, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None,
+               jitter: Optional[Tensor] = None, jitter_step: float = 0.0):
     """-> (ray_indices int64 [N], t_starts [N], t_ends [N], packed_info [R,2]) on the device."""
-    return march_finish(march_begin(origins, directions, binaries_u8, roi_aabb, levels, resolution, near, far, step, cone, nears, fars))
+    return march_finish(march_begin(origins, directions, binaries_u8, roi_aabb, levels, resolution, near, far, step, cone, nears, fars,
+                                    jitter, jitter_step))
 
 
-def visibility_mask(sigma: Tensor, t_starts: Tensor, t_ends: Tensor, packed_info: Tensor, early_stop_eps: float, alpha_thre: float):
+def visibility_mask(sigma: Tensor, t_starts: Tensor, t_ends: Tensor, packed_info: Tensor, early_stop_eps: float, alpha_thre: float,
+                    with_counts: bool = False):
+    """nerfacc render_visibility_from_density -> bool mask [N]; ``with_counts``: (uint8 mask [N], survivors per ray int64 [R])."""
     s = _hip.f32c(sigma).view(-1)
     mask = torch.empty(s.shape, device=s.device, dtype=torch.uint8)
-    _hip.check(_hip.lib().umhs_visibility(ptr(s), ptr(t_starts), ptr(t_ends), ptr(packed_info), packed_info.shape[0], s.shape[0],
+    R = packed_info.shape[0]
+    if with_counts:
+        kept = torch.empty((R,), device=s.device, dtype=torch.int64)
+        _hip.check(_hip.lib().umhs_visibility_count(ptr(s), ptr(t_starts), ptr(t_ends), ptr(packed_info), R, s.shape[0], float(early_stop_eps),
+                                                    float(alpha_thre), ptr(mask), ptr(kept), _hip.stream()), "umhs_visibility_count")
+        return mask, kept
+    _hip.check(_hip.lib().umhs_visibility(ptr(s), ptr(t_starts), ptr(t_ends), ptr(packed_info), R, s.shape[0],
                                           float(early_stop_eps), float(alpha_thre), ptr(mask), _hip.stream()), "umhs_visibility")
     return mask.bool()
+
+
+def compact_samples(mask_u8: Tensor, packed_in: Tensor, packed_out: Tensor, n_out: int, t_starts: Tensor, t_ends: Tensor, origins: Tensor,
+                    directions: Tensor, camera_indices: Optional[Tensor] = None):
+    """Survivors of ``mask_u8`` in packed order -> dict(ray_indices, t_starts, t_ends, origins [n,3], directions [n,3],
+    camera_indices [n,1] | None, sel [n]); one launch instead of nonzero + index_selects + gathers."""
+    dev, R = mask_u8.device, packed_in.shape[0]
+    out = {"ray_indices": torch.empty((n_out,), device=dev, dtype=torch.int64), "t_starts": torch.empty((n_out,), device=dev),
+           "t_ends": torch.empty((n_out,), device=dev), "origins": torch.empty((n_out, 3), device=dev),
+           "directions": torch.empty((n_out, 3), device=dev), "sel": torch.empty((n_out,), device=dev, dtype=torch.int64),
+           "camera_indices": None}
+    cam = None
+    if camera_indices is not None:
+        cam = camera_indices.reshape(-1).to(torch.int64).contiguous()
+        out["camera_indices"] = torch.empty((n_out, 1), device=dev, dtype=torch.int64)
+    if n_out > 0:
+        _hip.check(_hip.lib().umhs_compact_samples(ptr(mask_u8), ptr(packed_in), ptr(packed_out), R, ptr(t_starts), ptr(t_ends),
+                                                   ptr(_hip.f32c(origins)), ptr(_hip.f32c(directions)), ptr(cam), ptr(out["ray_indices"]),
+                                                   ptr(out["t_starts"]), ptr(out["t_ends"]), ptr(out["origins"]), ptr(out["directions"]),
+                                                   ptr(out["camera_indices"]), ptr(out["sel"]), _hip.stream()), "umhs_compact_samples")
+    return out
 
 
 class OccGridEstimator(nn.Module):
@@ -160,7 +213,10 @@ class OccGridEstimator(nn.Module):
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None, near_plane: float = 0.0,
                  far_plane: float = 1e10, t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None,
                  render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
-                 cone_angle: float = 0.0) -> Tuple[Tensor, Tensor, Tensor]:
+                 cone_angle: float = 0.0, camera_indices: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+        """nerfacc ``OccGridEstimator.sampling``.  ``camera_indices`` [R(,1)] (extension): gathered per surviving sample together with
+        the ray origins / directions; the gathered rows and the survivors' packed_info are left in ``last_pruned`` /
+        ``last_packed_info`` for the caller (VolumetricSampler) so that it does not have to index them again."""
         self.last_keep_index = None  # index of the survivors among the marched candidates, when a density pruning pass ran
         pre = getattr(self, "_prefetched", None)
         key = self._march_key(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
@@ -169,13 +225,17 @@ class OccGridEstimator(nn.Module):
         else:
             h = self._march_begin(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
         ri, t0, t1, pinfo = march_finish(h)
+        self.last_packed_info, self.last_pruned = pinfo, None
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None and t0.numel() > 0:
             alpha_thre = min(alpha_thre, self._occs_mean())  # nerfacc reads occs.mean() per batch; it only changes in _update()
             sigmas = sigma_fn(t0, t1, ri)
-            keep = visibility_mask(sigmas, t0, t1, pinfo, early_stop_eps, alpha_thre)
-            sel = torch.nonzero(keep).view(-1)  # one compaction index (one host sync) for the three packed arrays
-            ri, t0, t1 = ri.index_select(0, sel), t0.index_select(0, sel), t1.index_select(0, sel)
-            self.last_keep_index = sel
+            # survivors: mask + per-ray counts -> their packed_info -> ONE host sync for the total -> one compaction launch (order kept)
+            mask, kept = visibility_mask(sigmas, t0, t1, pinfo, early_stop_eps, alpha_thre, with_counts=True)
+            pinfo2, stats = ray_prefix(kept)
+            n2 = int(stats[0])
+            out = compact_samples(mask, pinfo, pinfo2, n2, t0, t1, rays_o, rays_d, camera_indices)
+            ri, t0, t1 = out["ray_indices"], out["t_starts"], out["t_ends"]
+            self.last_keep_index, self.last_packed_info, self.last_pruned = out["sel"], pinfo2, out
         return ri, t0, t1
 
     @staticmethod
@@ -185,12 +245,10 @@ class OccGridEstimator(nn.Module):
                 bool(stratified), float(cone_angle))
 
     def _march_begin(self, rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle) -> MarchHandle:
-        nears = t_min if t_min is not None else torch.full_like(rays_o[..., 0], near_plane)
-        fars = t_max if t_max is not None else torch.full_like(rays_o[..., 0], far_plane)
-        if stratified:
-            nears = nears + torch.rand_like(nears) * render_step_size
+        # per-ray planes only when the caller has them; the stratified start (nears + rand * step) is applied inside the walk
+        jitter = torch.rand_like(rays_o[..., 0]) if stratified else None
         return march_begin(rays_o, rays_d, self.binaries.view(torch.uint8), self._roi, self.levels, self.res, near_plane, far_plane,
-                           render_step_size, cone_angle, nears, fars)
+                           render_step_size, cone_angle, t_min, t_max, jitter, render_step_size)
 
     def prefetch_march(self, rays_o: Tensor, rays_d: Tensor, near_plane: float = 0.0, far_plane: float = 1e10,
                        t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
@@ -265,8 +323,7 @@ class VolumetricSampler(nn.Module):
         density_fn = self.density_fn
 
         def sigma_fn(t_starts, t_ends, ray_indices):
-            pos = origins[ray_indices] + directions[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
-            return density_fn(pos).squeeze(-1)
+            return density_fn(sample_midpoints(origins, directions, ray_indices, t_starts, t_ends)).squeeze(-1)
 
         return sigma_fn
 
@@ -287,12 +344,19 @@ class VolumetricSampler(nn.Module):
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane: Optional[float] = None,
                 alpha_thre: float = 0.01, cone_angle: float = 0.0) -> Tuple[RaySamples, Tensor]:
         rays_o, rays_d, t_min, t_max, far_plane = self._march_inputs(ray_bundle, far_plane)
-        ri, t0, t1 = self.occupancy_grid.sampling(rays_o, rays_d, sigma_fn=self.get_sigma_fn(rays_o, rays_d), near_plane=near_plane,
-                                                  far_plane=far_plane, t_min=t_min, t_max=t_max, render_step_size=render_step_size,
-                                                  stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre)
+        g = self.occupancy_grid
+        ri, t0, t1 = g.sampling(rays_o, rays_d, sigma_fn=self.get_sigma_fn(rays_o, rays_d), near_plane=near_plane,
+                                far_plane=far_plane, t_min=t_min, t_max=t_max, render_step_size=render_step_size,
+                                stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre,
+                                camera_indices=ray_bundle.camera_indices)
+        self.last_packed_info = g.last_packed_info
         if t0.shape[0] == 0:  # nerfstudio: one fake sample so that downstream shapes stay valid
             ri = torch.zeros((1,), dtype=torch.long, device=rays_o.device)
             t0 = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
             t1 = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+            self.last_packed_info = None
+        elif g.last_pruned is not None:  # the compaction launch gathered the rays' rows along with the survivors
+            p = g.last_pruned
+            return packed_ray_samples(p["origins"], p["directions"], t0, t1, p["camera_indices"]), ri
         cam = ray_bundle.camera_indices[ri] if ray_bundle.camera_indices is not None else None
         return packed_ray_samples(rays_o[ri], rays_d[ri], t0, t1, cam), ri

@@ -275,6 +275,9 @@ class UMHSModel(nn.Module):
         if reuse and keep is not None and "enc" in cap and keep.numel() == ray_indices.numel():
             # the sampler's density query encoded every marched candidate: the survivors' features are a row gather away
             ray_samples.metadata = {**(getattr(ray_samples, "metadata", None) or {}), "umhs_enc": (cap["enc"], keep)}
+        pinfo = getattr(self.sampler, "last_packed_info", None)
+        if pinfo is not None and pinfo.shape[0] == len(ray_bundle):  # (start, count) of every ray: the sampler has it already
+            ray_samples.metadata = {**(getattr(ray_samples, "metadata", None) or {}), "umhs_packed_info": pinfo}
         return ray_samples, ray_indices
 
     def prefetch_sample(self, ray_bundle: RayBundle) -> bool:
@@ -312,6 +315,8 @@ class UMHSModel(nn.Module):
         c = self.config
         fo = self.field(ray_samples)
         fr = ray_samples.frustums
+        if packed_info is None:
+            packed_info = (getattr(ray_samples, "metadata", None) or {}).get("umhs_packed_info")
         if packed_info is None:
             packed_info = ops.pack_info(ray_indices, num_rays)
         values = [fo["spectral"]]
@@ -362,8 +367,15 @@ class UMHSModel(nn.Module):
                 and os.environ.get("UMHS_DIRECT_STEP", "1") != "0" and self.field.use_grad_sink
                 and (sink is None or sink.owns_next_backward()) and self.field.flat.grad is None)
 
+    def draw_training_background(self, batch: Dict) -> Optional[Tensor]:
+        """The random background of this step's rgb loss (RGBRenderer.blend_background_for_loss_computation), drawn by the caller
+        when it wants to fix the position of the draw in the generator's sequence (UMHSPipeline does, in front of its prefetch)."""
+        if self.config.method != "rgb+spectral" or self.background_color != "random":
+            return None
+        return torch.rand_like(_hip.f32c(batch["image"].to(self.device)))
+
     def forward_backward_from_samples(self, ray_samples: RaySamples, ray_indices: Tensor, num_rays: int, batch: Dict,
-                                      packed_info: Optional[Tensor] = None):
+                                      packed_info: Optional[Tensor] = None, background: Optional[Tensor] = None):
         """get_outputs (after the sampler) + get_loss_dict + backward of the summed loss, as one straight launch sequence with no
         autograd graph: the same kernels with the same arguments in the same order as the autograd path (which remains the general
         one), minus ~0.6 ms of host time per step.  Gradients land in the field's gradient sink (= ``field.flat.grad``).
@@ -376,6 +388,8 @@ class UMHSModel(nn.Module):
         o, d = _hip.f32c(fr.origins).view(n, 3), _hip.f32c(fr.directions).view(n, 3)
         t0, t1 = _hip.f32c(fr.starts).view(-1), _hip.f32c(fr.ends).view(-1)
         flat = f.flat.detach()
+        if packed_info is None:
+            packed_info = (getattr(ray_samples, "metadata", None) or {}).get("umhs_packed_info")
         if packed_info is None:
             packed_info = ops.pack_info(ray_indices, num_rays)
         # forward (FieldFn.forward -> CompositeFn.forward -> RayEpilogueFn.forward -> LossFn.forward)
@@ -424,7 +438,7 @@ class UMHSModel(nn.Module):
         M = _hip.f32c(self.converter.transform_matrix)
         hs, image = _hip.f32c(batch["hs_image"].to(self.device)), _hip.f32c(batch["image"].to(self.device))
         both = c.method == "rgb+spectral"
-        bg = torch.rand_like(image) if (both and self.background_color == "random") else None
+        bg = (background if background is not None else torch.rand_like(image)) if (both and self.background_color == "random") else None
         w = (5.0, float(c.rgb_loss_weight)) if both else (1.0, 0.0)
         # ray epilogue + both losses + their backward down to d_spectral / d_accumulation: one launch
         rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(

@@ -61,8 +61,9 @@ class UMHSPipeline(torch.nn.Module):
             sampled = torch.cuda.Event() if self.device.type == "cuda" else None
             if sampled is not None:
                 sampled.record(torch.cuda.current_stream(self.device))  # the grid is final for this step and the scratch rows of this step's march have been read
-            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch)
-            self._prefetch_next(step + 1, sampled)  # enqueued behind this step's launches, executed under them
+            bg = self._model.draw_training_background(batch)  # before the prefetch draws the next batch's jitter: same order as without
+            self._prefetch_next(step + 1, sampled)  # issued first, so that it runs under the forward pass (see _prefetch_next)
+            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch, background=bg)
             metrics_dict = self._model.get_metrics_dict(outputs, batch)
         else:
             outputs = self._model(ray_bundle)
@@ -74,9 +75,11 @@ class UMHSPipeline(torch.nn.Module):
 
     # ---- one-step-ahead ray batch + occupancy march -------------------------------------------------------------------
     # The march of a batch needs the rays and the occupancy grid only -- not the field -- and it is one latency-bound
-    # dependency chain per ray (a few hundred waves, ~0.8 ms): issued on its own stream right after the current step's
-    # launches, it runs in the shadow of this step's forward/backward instead of in front of the next one.  Skipped when the
-    # next step rewrites the grid.  The batch is drawn from the data manager's own generator and the stratified jitter from
+    # dependency chain per ray (a few hundred waves, ~0.7 ms): issued on its own stream right after the current step's
+    # sampling, it runs in the shadow of this step's forward pass instead of in front of the next step.  (Issued behind the
+    # step's launches it ran beside the first field-backward kernel, whose 231-VGPR waves leave no room on a SIMD for a 76-VGPR
+    # marcher wave: every CU that held one could not take a backward workgroup, and that kernel ran at half speed.  The forward
+    # and compositing kernels co-reside with it.)  Skipped when the next step rewrites the grid.  The batch is drawn from the data manager's own generator and the stratified jitter from
     # the device generator in the same order as without prefetch (nothing else draws between the two), so the training
     # trajectory is bit-identical either way (tests/test_hip_sampler.py).
     def _next_train(self, step: int):
