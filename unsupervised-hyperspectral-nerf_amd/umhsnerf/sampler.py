@@ -232,6 +232,9 @@ class OccGridEstimator(nn.Module):
             # survivors: mask + per-ray counts -> their packed_info -> ONE host sync for the total -> one compaction launch (order kept)
             mask, kept = visibility_mask(sigmas, t0, t1, pinfo, early_stop_eps, alpha_thre, with_counts=True)
             pinfo2, stats = ray_prefix(kept)
+            hook, self.pre_sync_hook = getattr(self, "pre_sync_hook", None), None
+            if hook is not None:  # host work a trainer wants done while the GPU is busy with the density query (one shot)
+                hook()
             n2 = int(stats[0])
             out = compact_samples(mask, pinfo, pinfo2, n2, t0, t1, rays_o, rays_d, camera_indices)
             ri, t0, t1 = out["ray_indices"], out["t_starts"], out["t_ends"]

@@ -57,13 +57,29 @@ class UMHSPipeline(torch.nn.Module):
         ray_bundle, batch = self._next_train(step)
         self.optimizer.zero_grad(set_to_none=True)
         if self._model.direct_step_supported(batch):
-            ray_samples, ray_indices = self._model.sample(ray_bundle)
             sampled = torch.cuda.Event() if self.device.type == "cuda" else None
             if sampled is not None:
-                sampled.record(torch.cuda.current_stream(self.device))  # the grid is final for this step and the scratch rows of this step's march have been read
-            bg = self._model.draw_training_background(batch)  # before the prefetch draws the next batch's jitter: same order as without
-            self._prefetch_next(step + 1, sampled)  # issued first, so that it runs under the forward pass (see _prefetch_next)
-            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch, background=bg)
+                sampled.record(torch.cuda.current_stream(self.device))  # the occupancy grid is final for this step
+            ahead = {}
+
+            def while_gpu_busy():
+                # Host work with no dependence on this step's samples, done while the GPU runs the sampler's density query (the host
+                # would otherwise just wait for the survivor count): this step's random background -- drawn here so that the device
+                # generator sees jitter(step), background(step), jitter(step + 1) with or without prefetch -- and the next batch.
+                ahead["bg"] = self._model.draw_training_background(batch)
+                self._prefetch_next(step + 1, sampled)
+                ahead["done"] = True
+
+            grid = getattr(getattr(self._model, "sampler", None), "occupancy_grid", None)
+            if grid is not None:
+                grid.pre_sync_hook = while_gpu_busy
+            ray_samples, ray_indices = self._model.sample(ray_bundle)
+            if grid is not None:
+                grid.pre_sync_hook = None
+            if not ahead.get("done"):  # the sampler had nothing to prune (no host sync there): same work, now
+                while_gpu_busy()
+            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch,
+                                                                           background=ahead["bg"])
             metrics_dict = self._model.get_metrics_dict(outputs, batch)
         else:
             outputs = self._model(ray_bundle)
@@ -75,11 +91,12 @@ class UMHSPipeline(torch.nn.Module):
 
     # ---- one-step-ahead ray batch + occupancy march -------------------------------------------------------------------
     # The march of a batch needs the rays and the occupancy grid only -- not the field -- and it is one latency-bound
-    # dependency chain per ray (a few hundred waves, ~0.7 ms): issued on its own stream right after the current step's
-    # sampling, it runs in the shadow of this step's forward pass instead of in front of the next step.  (Issued behind the
-    # step's launches it ran beside the first field-backward kernel, whose 231-VGPR waves leave no room on a SIMD for a 76-VGPR
-    # marcher wave: every CU that held one could not take a backward workgroup, and that kernel ran at half speed.  The forward
-    # and compositing kernels co-reside with it.)  Skipped when the next step rewrites the grid.  The batch is drawn from the data manager's own generator and the stratified jitter from
+    # dependency chain per ray (a few hundred waves, ~0.7 ms): issued on its own stream while the current step's sampler is
+    # still at its density query, it runs in the shadow of that query and of the forward pass instead of in front of the next
+    # step, and the host issues it while it would otherwise wait for the survivor count.  (Issued behind the step's launches it
+    # ran beside the first field-backward kernel, whose 231-VGPR waves leave no room on a SIMD for a 76-VGPR marcher wave: every
+    # CU that held one could not take a backward workgroup, and that kernel ran at half speed.  The density, forward and
+    # compositing kernels co-reside with it.)  Skipped when the next step rewrites the grid.  The batch is drawn from the data manager's own generator and the stratified jitter from
     # the device generator in the same order as without prefetch (nothing else draws between the two), so the training
     # trajectory is bit-identical either way (tests/test_hip_sampler.py).
     def _next_train(self, step: int):
