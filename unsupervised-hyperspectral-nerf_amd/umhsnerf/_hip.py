@@ -139,7 +139,15 @@ def ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  Called once per launch: the public
+    ``torch.cuda.current_stream().cuda_stream`` costs ~8 us of Python (40 launches = 0.3 ms of a launch-bound step), the raw getter 0.3."""
+    if _raw_stream is not None and _cur_device is not None:
+        return C.c_void_p(_raw_stream(_cur_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
