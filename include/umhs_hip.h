@@ -139,6 +139,13 @@ int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
                    int64_t n, float* sigma, float* sigma_raw, float* emb, float* spectral, float* spectral2,
                    float* specular, float* abundances, float* feat_logits, void* workspace, size_t workspace_bytes,
                    int pack_ready, umhs_stream_t stream);
+/* density_fn in ONE launch (SURVEY 8a R1-R3 for the sampler / occupancy-grid callers, umhs_model.py:208,553): the hash-grid     */
+/* gather feeds mlp_base inside the kernel, the [N,32] feature array is never written or read.  cfg->density_only must be set;  */
+/* pos01 [N,3] from umhs_positions_fwd, table [L*T,2], scalings [L]; outputs as umhs_field_fwd's (sigma_raw / emb optional).     */
+/* Same bits as umhs_hashgrid_fwd followed by umhs_field_fwd.                                                                    */
+int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* pos01, const float* table,
+                       const float* scalings, int log2_T, const float* selector, int64_t n, float* sigma, float* sigma_raw,
+                       float* emb, void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
 /* feat_logits (optional, [N,16]): the feature_mlp logits, saved so that umhs_field_bwd can run its heads as two kernels   */
 /* (head MLP + directional + mixing / feature MLP) with every weight pack LDS-resident; NULL there = one fused kernel.       */
 /* builds the pack image ahead of time (parameters only): then pass pack_ready = 1 with the same workspace */

@@ -39,3 +39,57 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
+
+// ---- multires hash grid: corner indices + offsets of one (position, level) (R2) ------------------------------------------
+#define HASH_P1 2654435761u
+#define HASH_P2 805459861u
+
+struct HashCorners {
+  uint32_t idx[8];
+  float ox, oy, oz;
+  uint32_t fx, fy, fz, eqx, eqy, eqz;  // floor coordinates and ceil == floor flags (cell identity)
+};
+
+__device__ __forceinline__ HashCorners hash_corners(float px, float py, float pz, float s, uint32_t mask,
+                                                    uint32_t base) {
+#pragma clang fp contract(off)
+  // round the scaled coordinate BEFORE subtracting its floor (as the reference's torch ops do): a fused
+  // fma(px, s, -floor) would use the unrounded product and shift the offset by up to half an ulp of ~2047.
+  // (__fmul_rn is plain '*' in HIP, so contraction is switched off here and the products are made opaque.)
+  float sx = px * s, sy = py * s, sz = pz * s;
+  asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
+  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  uint32_t xf = (uint32_t)(int)fx, yf = (uint32_t)(int)fy * HASH_P1, zf = (uint32_t)(int)fz * HASH_P2;
+  uint32_t xc = (uint32_t)(int)ceilf(sx), yc = (uint32_t)(int)ceilf(sy) * HASH_P1,
+           zc = (uint32_t)(int)ceilf(sz) * HASH_P2;
+  HashCorners h;
+  h.fx = xf, h.fy = (uint32_t)(int)fy, h.fz = (uint32_t)(int)fz;
+  h.eqx = xc == xf, h.eqy = yc == yf, h.eqz = zc == zf;
+  h.ox = sx - fx, h.oy = sy - fy, h.oz = sz - fz;
+  // corner order of nerfstudio HashEncoding.pytorch_fwd: 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
+  h.idx[0] = ((xc ^ yc ^ zc) & mask) + base;
+  h.idx[1] = ((xc ^ yf ^ zc) & mask) + base;
+  h.idx[2] = ((xf ^ yf ^ zc) & mask) + base;
+  h.idx[3] = ((xf ^ yc ^ zc) & mask) + base;
+  h.idx[4] = ((xc ^ yc ^ zf) & mask) + base;
+  h.idx[5] = ((xc ^ yf ^ zf) & mask) + base;
+  h.idx[6] = ((xf ^ yf ^ zf) & mask) + base;
+  h.idx[7] = ((xf ^ yc ^ zf) & mask) + base;
+  return h;
+}
+
+// trilinear blend of the 8 corner features (corner order above), one expression tree shared by the stand-alone gather kernel and
+// the fused density kernel so that both produce the same bits
+__device__ __forceinline__ float2 hash_trilerp(const float2 (&f)[8], float ox, float oy, float oz) {
+  const float rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
+  float out[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float f0 = k ? f[0].y : f[0].x, f1 = k ? f[1].y : f[1].x, f2 = k ? f[2].y : f[2].x, f3 = k ? f[3].y : f[3].x;
+    float f4 = k ? f[4].y : f[4].x, f5 = k ? f[5].y : f[5].x, f6 = k ? f[6].y : f[6].x, f7 = k ? f[7].y : f[7].x;
+    float f03 = f0 * ox + f3 * rx, f12 = f1 * ox + f2 * rx, f56 = f5 * ox + f6 * rx, f47 = f4 * ox + f7 * rx;
+    float f0312 = f03 * oy + f12 * ry, f4756 = f47 * oy + f56 * ry;
+    out[k] = f0312 * oz + f4756 * rz;
+  }
+  return make_float2(out[0], out[1]);
+}

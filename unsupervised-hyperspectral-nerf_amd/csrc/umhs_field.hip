@@ -216,6 +216,11 @@ __device__ __forceinline__ float sel4(const v4f& v, int r) { return r == 0 ? v[0
 struct FieldIO {
   const float* enc;
   int64_t sn, sl;
+  // fused density query (field_fwd_kernel<.., HASH = true>): the hash features are gathered by the kernel itself
+  const float* pos01;
+  const float2* table;
+  const float* scalings;
+  int log2_T;
   const float *wpos, *dirs, *sel;
   int64_t n;
   int B, C, TB;
@@ -340,7 +345,7 @@ __device__ __forceinline__ void store_density(const FieldIO& io, const v4f (&bo4
 // =============================================================================================
 // Forward
 // =============================================================================================
-template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES>
+template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES, bool HASH = false>
 __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(FieldIO io, PackDesc pd,
                                                                                const float* __restrict__ image) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -359,13 +364,39 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
       nn[ct] = ok[ct] ? n : io.n - 1;
     }
     float encf[NT][8];
+    if (HASH) {
+      // The lane's operand slots are the features of levels 4q .. 4q+3 of its sample: it gathers exactly those (8 corners x 4
+      // levels, all 32 loads of a sample in flight together) -- the [N,32] feature array never exists.  16 consecutive samples
+      // of a ray per quad and level: the same line reuse as the stand-alone gather kernel.
+      const uint32_t mask = (1u << io.log2_T) - 1u;
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
+      for (int ct = 0; ct < NT; ++ct) {
+        const float px = io.pos01[3 * nn[ct]], py = io.pos01[3 * nn[ct] + 1], pz = io.pos01[3 * nn[ct] + 2];
+        float2 f[4][8];
+        float off[4][3];
 #pragma unroll
-      for (int lv = 0; lv < 4; ++lv) {
-        const float2 v = *reinterpret_cast<const float2*>(io.enc + nn[ct] * io.sn + (int64_t)(4 * q + lv) * io.sl);
-        encf[ct][2 * lv] = v.x, encf[ct][2 * lv + 1] = v.y;
+        for (int lv = 0; lv < 4; ++lv) {
+          const int l = 4 * q + lv;
+          const HashCorners h = hash_corners(px, py, pz, io.scalings[l], mask, (uint32_t)l << io.log2_T);
+          off[lv][0] = h.ox, off[lv][1] = h.oy, off[lv][2] = h.oz;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) f[lv][c] = io.table[h.idx[c]];
+        }
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+          const float2 v = hash_trilerp(f[lv], off[lv][0], off[lv][1], off[lv][2]);
+          encf[ct][2 * lv] = v.x, encf[ct][2 * lv + 1] = v.y;
+        }
       }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+          const float2 v = *reinterpret_cast<const float2*>(io.enc + nn[ct] * io.sn + (int64_t)(4 * q + lv) * io.sl);
+          encf[ct][2 * lv] = v.x, encf[ct][2 * lv + 1] = v.y;
+        }
+    }
     // ---- encodings first (sinf's slow path and the loads branch; keep them out of the gemm chain) --------
     float pe_[NT][3], sh_[NT][4];
     if (!DENSITY_ONLY) {
@@ -1464,16 +1495,26 @@ extern "C" int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_fiel
   return UMHS_OK;
 }
 
-extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
-                              int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
-                              const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
-                              float* spectral, float* spectral2, float* specular, float* abundances, float* feat_logits,
-                              void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
+struct HashIn {  // inputs of the fused density query (instead of enc)
+  const float* pos01;
+  const float* table;
+  const float* scalings;
+  int log2_T;
+};
+
+static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, const HashIn* hash,
+                         int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
+                         const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
+                         float* spectral, float* spectral2, float* specular, float* abundances, float* feat_logits,
+                         void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
-  if (!params || !enc || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
-  if ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;
+  if (!params || (!enc && !hash) || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
+  if (enc && ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7))) return UMHS_ERR_ARG;
   const bool dens = cfg->density_only != 0, spec = cfg->pred_specular != 0;
+  if (hash && (!dens || !hash->pos01 || !hash->table || !hash->scalings || ((uintptr_t)hash->table & 7) || hash->log2_T < 1 ||
+               hash->log2_T > 24))
+    return UMHS_ERR_ARG;
   if (!dens && (!world_pos || !spectral || (spec && !directions))) return UMHS_ERR_ARG;
   if (n == 0) return UMHS_OK;
   PackDesc pd;
@@ -1482,6 +1523,9 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
   if (rc) return rc;
   FieldIO io = {};
   io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
+  if (hash)
+    io.pos01 = hash->pos01, io.table = reinterpret_cast<const float2*>(hash->table), io.scalings = hash->scalings,
+    io.log2_T = hash->log2_T;
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances, io.feat_logits = dens ? nullptr : feat_logits;
@@ -1499,17 +1543,20 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
     }
     image = img;
   }
-  const int blocks_per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
+  // the fused density query gathers from the hash table inside the kernel: it wants every wave slot its 112 VGPRs allow (4 per SIMD)
+  const int blocks_per_cu = (hash && lds_bytes <= 36 * 1024) ? 4 : (lds_bytes <= 78 * 1024 ? 2 : 1);
   const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
   const size_t lds_launch = lds_bytes;
-#define LAUNCH_FWD(S, D, NT_, W_)                                                                               \
-  do {                                                                                                          \
-    rc = set_lds(field_fwd_kernel<S, D, NT_, W_>, lds_launch);                                                   \
-    if (rc) return rc;                                                                                          \
-    hipLaunchKernelGGL((field_fwd_kernel<S, D, NT_, W_>), dim3(grid), dim3(64 * W_), lds_launch, umhs_s(stream), \
-                       io, pd, image);                                                                          \
+#define LAUNCH_FWD(S, D, NT_, W_, ...)                                                                                       \
+  do {                                                                                                                       \
+    rc = set_lds(field_fwd_kernel<S, D, NT_, W_, ##__VA_ARGS__>, lds_launch);                                                 \
+    if (rc) return rc;                                                                                                       \
+    hipLaunchKernelGGL((field_fwd_kernel<S, D, NT_, W_, ##__VA_ARGS__>), dim3(grid), dim3(64 * W_), lds_launch, umhs_s(stream), \
+                       io, pd, image);                                                                                       \
   } while (0)
-  if (dens)
+  if (dens && hash)
+    LAUNCH_FWD(false, true, 2, 4, true);
+  else if (dens)
     LAUNCH_FWD(false, true, 2, 4);
   else if (spec) {
     if (fwd_variant == 1)
@@ -1521,6 +1568,27 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
 #undef LAUNCH_FWD
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
+}
+
+extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
+                              int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
+                              const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
+                              float* spectral, float* spectral2, float* specular, float* abundances, float* feat_logits,
+                              void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
+  if (!enc) return UMHS_ERR_ARG;
+  return run_field_fwd(cfg, params, enc, nullptr, stride_n, stride_l, world_pos, directions, selector, n, sigma, sigma_raw, emb,
+                       spectral, spectral2, specular, abundances, feat_logits, workspace, workspace_bytes, pack_ready, stream);
+}
+
+// density_fn in one launch: hash-grid gather + mlp_base + trunc_exp * selector, without the [N,32] feature array in between
+// (cfg->density_only must be set).  Same bits as umhs_hashgrid_fwd followed by umhs_field_fwd.
+extern "C" int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* pos01,
+                                  const float* table, const float* scalings, int log2_T, const float* selector, int64_t n,
+                                  float* sigma, float* sigma_raw, float* emb, void* workspace, size_t workspace_bytes,
+                                  int pack_ready, umhs_stream_t stream) {
+  const HashIn hash = {pos01, table, scalings, log2_T};
+  return run_field_fwd(cfg, params, nullptr, &hash, 0, 0, nullptr, nullptr, selector, n, sigma, sigma_raw, emb, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, workspace, workspace_bytes, pack_ready, stream);
 }
 
 struct PartPlan {  // one half of the split heads backward: rebased descriptors + how to assemble its LDS image

@@ -60,6 +60,8 @@ SIGNATURES = {
     "umhs_field_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FieldCfg)]),
     "umhs_field_fwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _i64,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "umhs_field_density": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _vp, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp, _vp,
+                                     C.c_size_t, C.c_int, _vp]),
     "umhs_field_fwd_prepare": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, C.c_size_t, _vp]),
     "umhs_field_bwd_prepare": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, C.c_size_t, _vp]),
     "umhs_hashgrid_bwd_prepare": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),

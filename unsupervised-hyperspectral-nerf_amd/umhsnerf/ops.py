@@ -7,6 +7,7 @@ libumhs_hip.so.  Nothing in this module has a CPU implementation.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -258,6 +259,23 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
                                          at(o["abundances"], L.num_classes), at(o.get("feat_logits"), 16), ptr(ws), ws.numel(), int(pack_ready),
                                          _hip.stream()),
                "umhs_field_fwd")
+    return o
+
+
+def field_density(spec: FieldSpec, flat, pos01, sel, want_emb: bool = True):
+    """density_fn in one launch (hash gather inside the MLP kernel): -> {"sigma" [N], "sigma_raw" [N], "emb" [N,15] | None}."""
+    n = sel.shape[0]
+    L = spec.layout
+    dev = sel.device
+    cfg = spec.cfg(True)
+    pp = L.c_struct(flat, _hip.FieldParams)
+    o = field_fwd_outputs(spec, n, dev, True, want_emb, True, False)
+    if not want_emb:
+        o["emb"] = None
+    ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
+    _hip.check(_hip.lib().umhs_field_density(C.byref(cfg), C.byref(pp), ptr(pos01), ptr(L.view(flat, "mlp_base.encoder.hash_table")),
+                                             ptr(spec.scalings), L.log2_hashmap_size, ptr(sel), n, ptr(o["sigma"]), ptr(o["sigma_raw"]),
+                                             ptr(o["emb"]), ptr(ws), ws.numel(), 0, _hip.stream()), "umhs_field_density")
     return o
 
 
@@ -559,14 +577,19 @@ class DensityFn(torch.autograd.Function):
     ``keep``: a dict that receives the level-major hash features of the queried positions (``keep["enc"]``)."""
 
     @staticmethod
-    def forward(ctx, flat, positions, spec: FieldSpec, keep=None):
+    def forward(ctx, flat, positions, spec: FieldSpec, keep=None, want_emb=True):
         L = spec.layout
         p = _hip.f32c(positions).view(-1, 3)
         _, pos01, sel = positions_fwd(None, None, None, None, spec, world_pos_in=p)
-        enc = hashgrid_fwd(pos01, L.view(flat.detach(), "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
-        out = field_fwd(spec, flat.detach(), enc, True, None, None, sel, density_only=True)
-        if keep is not None:
-            keep["enc"] = enc
+        if keep is None and os.environ.get("UMHS_FUSED_DENSITY", "1") != "0":
+            out = field_density(spec, flat.detach(), pos01, sel, want_emb)  # one launch, no [N,32] feature array
+        else:
+            enc = hashgrid_fwd(pos01, L.view(flat.detach(), "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
+            out = field_fwd(spec, flat.detach(), enc, True, None, None, sel, density_only=True)
+            if keep is not None:
+                keep["enc"] = enc
+        if out["emb"] is None:  # density_fn callers (sampler, occupancy grid) only want sigma: 60 B per sample not written
+            out["emb"] = out["sigma"].new_empty(0)
         ctx.mark_non_differentiable(out["sigma"], out["emb"])
         return out["sigma"].view(-1, 1), out["emb"]
 

@@ -189,5 +189,5 @@ class UMHSField(nn.Module):
         shp = positions.shape[:-1]
         keep = self._enc_capture  # a dict while the model's sampler wants the hash features of its candidates back, else None
         with torch.no_grad():
-            sigma, _ = ops.DensityFn.apply(self.flat, positions.reshape(-1, 3), self._spec(), keep)
+            sigma, _ = ops.DensityFn.apply(self.flat, positions.reshape(-1, 3), self._spec(), keep, False)
         return sigma.view(*shp, 1)
