@@ -225,10 +225,12 @@ def field_bwd_prepare(spec: FieldSpec, flat, n: int):
     _hip.check(_hip.lib().umhs_field_bwd_prepare(C.byref(cfg), C.byref(pp), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_bwd_prepare")
 
 
-def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb=False, want_aux=True, want_logits=False):
+def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb=None, want_aux=True, want_logits=False):
+    """``want_emb``: None = the density-only form returns the embedding, the full form does not; True / False force it."""
     L = spec.layout
     new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-    out = dict(sigma=new(n), sigma_raw=new(n), emb=new(n, GEO_FEAT_DIM) if (want_emb or density_only) else None, spectral=None,
+    want_emb = density_only if want_emb is None else want_emb
+    out = dict(sigma=new(n), sigma_raw=new(n), emb=new(n, GEO_FEAT_DIM) if want_emb else None, spectral=None,
                spectral2=None, specular=None, abundances=None,
                feat_logits=new(n, 16) if (want_logits and not density_only) else None)  # saved for the split heads backward
     if not density_only:
@@ -240,7 +242,7 @@ def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb
     return out
 
 
-def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=False, want_aux=True, pack_ready=False,
+def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_only=False, want_emb=None, want_aux=True, pack_ready=False,
               out=None, part=None, want_logits=False):
     """part = (offset, count): evaluate only that range of samples, writing into the full-size tensors of ``out``."""
     n = sel.shape[0]
@@ -270,8 +272,6 @@ def field_density(spec: FieldSpec, flat, pos01, sel, want_emb: bool = True):
     cfg = spec.cfg(True)
     pp = L.c_struct(flat, _hip.FieldParams)
     o = field_fwd_outputs(spec, n, dev, True, want_emb, True, False)
-    if not want_emb:
-        o["emb"] = None
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_density(C.byref(cfg), C.byref(pp), ptr(pos01), ptr(L.view(flat, "mlp_base.encoder.hash_table")),
                                              ptr(spec.scalings), L.log2_hashmap_size, ptr(sel), n, ptr(o["sigma"]), ptr(o["sigma_raw"]),
@@ -585,7 +585,7 @@ class DensityFn(torch.autograd.Function):
             out = field_density(spec, flat.detach(), pos01, sel, want_emb)  # one launch, no [N,32] feature array
         else:
             enc = hashgrid_fwd(pos01, L.view(flat.detach(), "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
-            out = field_fwd(spec, flat.detach(), enc, True, None, None, sel, density_only=True)
+            out = field_fwd(spec, flat.detach(), enc, True, None, None, sel, density_only=True, want_emb=want_emb)
             if keep is not None:
                 keep["enc"] = enc
         if out["emb"] is None:  # density_fn callers (sampler, occupancy grid) only want sigma: 60 B per sample not written
