@@ -700,17 +700,31 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     dnum += w * ((a + b) / 2.0f);
     carry += __shfl(incl, 63, 64);
     const int nvalid = min(64, cnt - base);
-    for (int s = 0; s < st.n; ++s) {
-      const int K = st.k[s];
-      const float* __restrict__ v = st.v[s] + (start + base) * (int64_t)K;
-      for (int kc = 0; kc < K; kc += 64) {
-        const int k = kc + lane;
+    for (int s = 0; s < st.n;) {
+      // two streams of <= 32 values share the wave (lanes 0-31 / 32-63): at the reference's 21-31 bands a single stream would leave
+      // half the lanes idle, and this loop is latency-bound -- the number of row-load rounds is what it costs
+      const bool pair = s + 1 < st.n && st.k[s] <= 32 && st.k[s + 1] <= 32;
+      const int half = pair ? (lane >> 5) : 0;
+      const int K = half ? st.k[s + 1] : st.k[s];
+      const float* __restrict__ v = (half ? st.v[s + 1] : st.v[s]) + (start + base) * (int64_t)K;
+      float* __restrict__ outp = half ? st.out[s + 1] : st.out[s];
+      const int kspan = pair ? 32 : 64, klane = pair ? (lane & 31) : lane;
+      const int kmax = pair ? 32 : st.k[s];
+      for (int kc = 0; kc < kmax; kc += kspan) {
+        const int k = kc + klane;
         const bool kv = k < K;
-        // the per-ray sum runs in sample order: 64 dependent-free row loads, 8 of them in flight per lane
+        // the per-ray sum runs in sample order: 64 dependent-free row loads, 16 of them in flight per lane
         float p0 = 0.0f, p1 = 0.0f;
         const float* __restrict__ vk = v + (kv ? k : 0);
         int j = 0;
-        for (; j + 7 < nvalid; j += 8) {
+        for (; j + 15 < nvalid; j += 16) {
+          float x[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) x[u] = vk[(int64_t)(j + u) * K];
+#pragma unroll
+          for (int u = 0; u < 16; u += 2) p0 += __shfl(w, j + u, 64) * x[u], p1 += __shfl(w, j + u + 1, 64) * x[u + 1];
+        }
+        for (; j + 7 < nvalid; j += 8) {  // (same association of the partial sums as ever: blocks of 8 alternate p0 / p1, the tail is p0)
           float x[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) x[u] = vk[(int64_t)(j + u) * K];
@@ -720,10 +734,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
         for (; j < nvalid; ++j) p0 += __shfl(w, j, 64) * vk[(int64_t)j * K];
         if (!kv) p0 = p1 = 0.0f;
         if (kv) {
-          float* o = st.out[s] + r * K + k;
+          float* o = outp + r * K + k;
           *o = (base == 0) ? (p0 + p1) : (*o + (p0 + p1));
         }
       }
+      s += pair ? 2 : 1;
     }
     if (cnt == 0) break;
   }
