@@ -91,6 +91,15 @@ int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalings, int64_t
 int umhs_hashgrid_bwd_apply(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l, const float* scalings,
                             int64_t n, int level_begin, int n_levels, int ws_level_begin, int ws_n_levels, int log2_T,
                             float* d_table, int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
+/* umhs_hashgrid_bwd_apply in overwrite mode + the Adam step (umhs_adam_step arithmetic, grad_scale 1) of the table entries of    */
+/* levels >= adam_level_begin, executed in the epilogue of the bucket reduce where their gradient is final.  For a single-GPU      */
+/* trainer whose optimizer.step() follows the backward (UMHSAdam skips the range it is told was done): the HBM-bound update hides   */
+/* inside the LDS-bound reduce and the gradient is not read back.  d_table still receives the gradient.  n > 0.                     */
+int umhs_hashgrid_bwd_apply_adam(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l,
+                                 const float* scalings, int64_t n, int level_begin, int n_levels, int ws_level_begin,
+                                 int ws_n_levels, int log2_T, float* d_table, void* workspace, size_t workspace_bytes,
+                                 float* table_params, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                                 float eps, int64_t step, int adam_level_begin, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* R3-R9, R18: fused per-sample field.  Replaces mlp_base's MLP, NeRFEncoding, SHEncoding,      */

@@ -257,3 +257,48 @@ def test_full_size_training_step_other_configs(name, R, S, B, C, spec, temp, mon
     for k in l0:
         assert abs(l1[k] - l0[k]) <= 2e-6 * abs(l0[k]), (name, k, l1[k], l0[k])
     torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-9 + 2e-6 * float(g0.abs().max()))
+
+
+def test_adam_step_riding_in_the_reduce_pass_is_the_same_update(monkeypatch):
+    """One GPU: UMHSPipeline arms the optimizer before the backward, and the bucket reduce of the hash-grid gradient applies Adam to
+    the dense table levels in its epilogue (umhs_hashgrid_bwd_apply_adam); optimizer.step() does the rest.  Same arithmetic ->
+    the very same parameters, moments and gradients as the separate Adam launch, step after step (lr decays in between)."""
+    from umhsnerf import ops
+    from umhsnerf._ns_compat import packed_ray_samples
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    R, S, B, Cn = 512, 24, 31, 5
+    b = T.synthetic_batch(R, S, B, seed=9)
+    b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+    rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])
+    pinfo = ops.pack_info(b["ray_indices"], R)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("UMHS_FUSED_ADAM", fused)
+        torch.manual_seed(4)
+        cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.5, per_band_outputs=False)
+        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=8)
+        with torch.no_grad():
+            pipe.model.field.layout.view(pipe.model.field.flat.data, "mlp_base.encoder.hash_table").mul_(300.0)
+            batch = {"image": pipe.model.converter(b["gt_spectral"]), "hs_image": b["gt_spectral"]}
+        sink, rode = pipe.model.field._spec().grad_sink, 0
+        losses = []
+        for _ in range(6):
+            pipe.optimizer.zero_grad(set_to_none=True)
+            armed = pipe.optimizer.arm_fused()
+            assert armed == (fused == "1")
+            _, loss = pipe.model.forward_backward_from_samples(rs, b["ray_indices"], R, batch, pinfo)
+            rode += int(sink.adam_done is not None)
+            pipe.optimizer.step()
+            assert sink.adam_done is None and sink.fused_adam is None
+            losses.append([float(v) for v in loss.values()])
+        st = pipe.optimizer.state[pipe.model.field.flat]
+        res[fused] = (losses, pipe.model.field.flat.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                      pipe.model.field.flat.grad.clone(), st["step"], rode)
+    assert res["1"][6] == 6 and res["0"][6] == 0 and res["1"][5] == res["0"][5] == 6
+    assert res["1"][0] == res["0"][0]
+    for i in (1, 2, 3, 4):
+        assert torch.equal(res["1"][i], res["0"][i]), i
+    # an armed step that the next optimizer.step() does not match is refused rather than applied twice
+    pipe.optimizer.zero_grad(set_to_none=True)

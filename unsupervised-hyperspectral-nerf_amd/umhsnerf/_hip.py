@@ -67,6 +67,8 @@ SIGNATURES = {
     "umhs_hashgrid_bwd_prepare": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "umhs_hashgrid_bwd_apply": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp,
                                           C.c_size_t, _vp]),
+    "umhs_hashgrid_bwd_apply_adam": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                               C.c_size_t, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, C.c_int, _vp]),
     "umhs_field_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FieldCfg), _i64]),
     "umhs_field_bwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                  _vp, _vp, _vp, _vp, C.POINTER(FieldGrads), _vp, C.c_size_t, C.c_int, _vp]),

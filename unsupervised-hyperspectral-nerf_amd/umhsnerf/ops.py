@@ -186,11 +186,22 @@ def hashgrid_bwd_prepare(pos01, scalings, log2_T: int, level_begin: int = 0, lev
 
 
 def hashgrid_bwd_apply(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, overwrite: bool = False,
-                       level_begin: int = 0, level_count: int = NUM_LEVELS, ws_range=(0, NUM_LEVELS)):
-    """Scatter + reduce of levels [level_begin, +level_count) using the workspace hashgrid_bwd_prepare filled for ws_range."""
+                       level_begin: int = 0, level_count: int = NUM_LEVELS, ws_range=(0, NUM_LEVELS), adam=None):
+    """Scatter + reduce of levels [level_begin, +level_count) using the workspace hashgrid_bwd_prepare filled for ws_range.
+    ``adam`` (overwrite mode, n > 0): dict(table, exp_avg, exp_avg_sq [L*T,2] views, lr, betas, eps, step, level_begin) -- the Adam
+    step of the table entries of levels >= level_begin rides in the epilogue of the reduce pass."""
     n = pos01.shape[0]
     sn, sl = enc_strides(n, level_major)
     ws = _workspace(_hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, ws_range[1], log2_T), pos01.device, slot=1)
+    if adam is not None:
+        assert overwrite and n > 0
+        _hip.check(_hip.lib().umhs_hashgrid_bwd_apply_adam(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, level_begin, level_count,
+                                                           ws_range[0], ws_range[1], log2_T, ptr(d_table), ptr(ws), ws.numel(),
+                                                           ptr(adam["table"]), ptr(adam["exp_avg"]), ptr(adam["exp_avg_sq"]),
+                                                           float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]),
+                                                           float(adam["eps"]), int(adam["step"]), int(adam["level_begin"]),
+                                                           _hip.stream()), "umhs_hashgrid_bwd_apply_adam")
+        return
     _hip.check(_hip.lib().umhs_hashgrid_bwd_apply(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, level_begin, level_count, ws_range[0],
                                                   ws_range[1], log2_T, ptr(d_table), int(overwrite), ptr(ws), ws.numel(), _hip.stream()),
                "umhs_hashgrid_bwd_apply")
@@ -457,8 +468,17 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
     T = 1 << L.log2_hashmap_size
     if prepared and hash_ready is not None:
         torch.cuda.current_stream(flat.device).wait_event(hash_ready)
-    for l0, cnt in (sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]):
-        if prepared:  # histogram + scan of all levels were done ahead of time (hashgrid_bwd_prepare)
+    groups = sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]
+    # armed by the trainer (one GPU, optimizer.step() follows): the table's Adam step rides in the reduce pass (UMHSAdam.arm_fused)
+    fused = sink.take_fused_adam(flat) if (own and prepared and len(groups) == 1 and pos01.shape[0] > 0) else None
+    for l0, cnt in groups:
+        if prepared and fused is not None:
+            lv = lambda t: L.view(t, "mlp_base.encoder.hash_table")
+            hashgrid_bwd_apply(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt,
+                               adam=dict(fused, table=lv(flat.data), exp_avg=lv(fused["exp_avg"]), exp_avg_sq=lv(fused["exp_avg_sq"])))
+            tb = L.offset("mlp_base.encoder.hash_table")
+            sink.adam_done = (fused["step"], tb + fused["level_begin"] * T * FEATURES_PER_LEVEL, tb + NUM_LEVELS * T * FEATURES_PER_LEVEL)
+        elif prepared:  # histogram + scan of all levels were done ahead of time (hashgrid_bwd_prepare)
             hashgrid_bwd_apply(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
         else:
             hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)

@@ -5,6 +5,7 @@ reduction (the reference's DDP wrap, umhs_pipeline.py:110-113) as one RCCL all-r
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -25,6 +26,40 @@ class UMHSAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, clamp_range=clamp_range, lr_init=lr, lr_final=lr_final, max_steps=max_steps)
         super().__init__(params, defaults)
 
+    def _hyper(self, group, st):
+        """(learning rate, step number) of the update that follows ``st["step"]`` updates."""
+        step = st["step"] + 1
+        lr = group["lr"]
+        if group["lr_final"] is not None:
+            lr = exp_decay_lr(step - 1, group["lr_init"], group["lr_final"], group["max_steps"])
+        return lr, step
+
+    @torch.no_grad()
+    def arm_fused(self) -> bool:
+        """Called by a single-GPU trainer right before a backward that ``step()`` will follow: hands the flat parameter's gradient
+        sink the hyper-parameters and moment buffers of the coming update, so that the backward's last kernel (the bucket reduce
+        of the hash-grid gradient, LDS-bound) also applies Adam to the dense levels of the hash table (HBM-bound: it hides inside,
+        and the gradient is not read back).  ``step()`` then skips that range.  Same arithmetic, same bits (tested)."""
+        if os.environ.get("UMHS_FUSED_ADAM", "1") == "0" or world()[1] != 1:
+            return False
+        armed = False
+        for group in self.param_groups:
+            for p in group["params"]:
+                sink = getattr(p, "_umhs_grad_sink", None)
+                sparse = getattr(p, "_umhs_live_rows", None)
+                if sink is None or not p.is_cuda or p.grad is not None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                lr, step = self._hyper(group, st)
+                sink.adam_done = None
+                sink.fused_adam = dict(lr=lr, betas=group["betas"], eps=group["eps"], step=step, exp_avg=st["exp_avg"],
+                                       exp_avg_sq=st["exp_avg_sq"], level_begin=sink.sparse_levels if sparse is not None else 0)
+                armed = True
+        return armed
+
     @torch.no_grad()
     def step(self, closure=None):
         for group in self.param_groups:
@@ -37,11 +72,15 @@ class UMHSAdam(torch.optim.Optimizer):
                 if not st:
                     st["step"] = 0
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
-                st["step"] += 1
-                lr = group["lr"]
-                if group["lr_final"] is not None:
-                    lr = exp_decay_lr(st["step"] - 1, group["lr_init"], group["lr_final"], group["max_steps"])
+                lr, st["step"] = self._hyper(group, st)
                 sink = getattr(p, "_umhs_grad_sink", None)
+                done_by_backward = None  # (begin, end) elements the backward already updated (arm_fused)
+                if sink is not None:
+                    sink.fused_adam, ad, sink.adam_done = None, sink.adam_done, None
+                    if ad is not None:
+                        if ad[0] != st["step"]:
+                            raise RuntimeError("a backward applied a fused Adam step that does not belong to this optimizer step")
+                        done_by_backward = ad[1:]
                 cb, ce = group["clamp_range"]
                 sparse = getattr(p, "_umhs_live_rows", None)  # (rows int64 [n], end): elements [0, end) hold sparse hash levels
 
@@ -53,9 +92,14 @@ class UMHSAdam(torch.optim.Optimizer):
                         a = sparse[1]
                         if a == b:
                             return
-                    clamp = (max(cb, a) - a, min(ce, b) - a) if (cb < b and ce > a) else (0, 0)
-                    ops.adam_step(p.data[a:b], p.grad[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], st["step"], lr, group["betas"],
-                                  group["eps"], grad_scale=scale, clamp_range=clamp)
+                    pieces = [(a, b)]
+                    if done_by_backward is not None:  # skip what the reduce pass of the backward has updated
+                        da, db = done_by_backward
+                        pieces = [(x, y) for x, y in ((a, min(b, da)), (max(a, db), b)) if x < y]
+                    for x, y in pieces:
+                        clamp = (max(cb, x) - x, min(ce, y) - x) if (cb < y and ce > x) else (0, 0)
+                        ops.adam_step(p.data[x:y], p.grad[x:y], st["exp_avg"][x:y], st["exp_avg_sq"][x:y], st["step"], lr, group["betas"],
+                                      group["eps"], grad_scale=scale, clamp_range=clamp)
 
                 done = 0
                 if sink is not None:

@@ -83,6 +83,7 @@ class FlatGradSink:
         self.async_reduce = os.environ.get("UMHS_ASYNC_REDUCE", "1") != "0"
         self.reduced_ptr = None
         self.sparse_levels, self.sparse_rows = 0, None  # set_sparse_levels(): coarse levels travel as their live rows only
+        self.fused_adam, self.adam_done = None, None  # UMHSAdam.arm_fused() / what the backward then did (step, begin, end)
 
     def set_sparse_levels(self, scalings, log2_T: int) -> None:
         """Coarse hash levels use a small, rank-independent subset of their 2^log2_T slots (4,913 of 524,288 at level 0): send the
@@ -92,6 +93,13 @@ class FlatGradSink:
         self.sparse_levels, rows = live_hash_rows(scalings, log2_T)
         self.sparse_rows = rows.to(self.param.device) if self.sparse_levels else None
         self.table_rows = 1 << log2_T
+
+    def take_fused_adam(self, param) -> Optional[dict]:
+        """The optimizer step a trainer armed for this backward (one shot), if it is for this parameter and nothing is reduced."""
+        fa, self.fused_adam = self.fused_adam, None
+        if fa is None or world()[1] != 1 or param is not self.param:
+            return None
+        return fa
 
     def owns_next_backward(self) -> bool:
         return self.param.grad is None

@@ -41,6 +41,7 @@ class UMHSPipeline(torch.nn.Module):
     def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None):
         self.optimizer.zero_grad(set_to_none=True)
         if self._model.direct_step_supported(batch):  # straight launch sequence, no autograd graph
+            self.optimizer.arm_fused()  # optimizer.step() follows unconditionally: the table's Adam step may ride in the backward
             outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, num_rays, batch, packed_info)
         else:
             outputs = self._model.get_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
@@ -78,6 +79,7 @@ class UMHSPipeline(torch.nn.Module):
                 grid.pre_sync_hook = None
             if not ahead.get("done"):  # the sampler had nothing to prune (no host sync there): same work, now
                 while_gpu_busy()
+            self.optimizer.arm_fused()  # optimizer.step() follows unconditionally: the table's Adam step may ride in the backward
             outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch,
                                                                            background=ahead["bg"])
             metrics_dict = self._model.get_metrics_dict(outputs, batch)
