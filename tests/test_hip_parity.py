@@ -74,10 +74,12 @@ def test_positions_and_selector():
 
 @pytest.mark.parametrize("method", ["partition", "atomic"])
 @pytest.mark.parametrize("level_major", [True, False])
-@pytest.mark.parametrize("log2_T", [19, 12])
+@pytest.mark.parametrize("log2_T", [19, 12, 20])  # 20: 128 buckets per level (two per lane of the partition kernel's scan wave)
 def test_hashgrid_fwd_bwd(level_major, log2_T, method):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
+    if log2_T == 20 and (method == "atomic" or not level_major):
+        pytest.skip("the 2^20 table is only there for the 128-bucket partition path")
     N = 3000
     x = torch.rand(N, 3, generator=g)
     x[:7] = 0.0  # masked samples sit exactly on a vertex

@@ -39,12 +39,12 @@ p2 = UMHSPipeline(cfg, "cuda:0", metadata={"wavelengths": list(np.linspace(420, 
 with torch.no_grad():
     split.image = p2.model.converter(split.hs_image.view(-1, Bd)).view(*split.hs_image.shape[:3], 3).contiguous()
 t0 = time.perf_counter()
-for step in range(600):
+for step in range(2000):
     _, loss_dict, metrics = p2.get_train_loss_dict(step)
-    if step % 100 == 0 or step == 599:
+    if step % 400 == 0 or step == 1999:
         print(f"datamanager step {step}: loss {float(sum(v.detach() for v in loss_dict.values())):.5f} psnr_spectral {float(metrics['psnr_spectral']):.2f} "
               f"samples {int(metrics['num_samples_per_batch'])}", flush=True)
 torch.cuda.synchronize()
-print(f"600 sampler-driven steps in {time.perf_counter() - t0:.2f} s; params finite: {bool(torch.isfinite(p2.model.field.flat).all())}")
+print(f"2000 sampler-driven steps in {time.perf_counter() - t0:.2f} s; params finite: {bool(torch.isfinite(p2.model.field.flat).all())}")
 md, _ = p2.get_eval_image_metrics_and_images(0)
 print("eval image metrics:", {k: round(v, 4) for k, v in md.items()})

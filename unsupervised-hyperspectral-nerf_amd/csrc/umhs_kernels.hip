@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 // And consecutive samples of a ray mostly share a grid cell on the coarse/mid levels, so lanes with the
 // same cell are merged by a wave segmented scan before a record is emitted (2-30x fewer records there).
 // ---------------------------------------------------------------------------------------------
+#ifndef HB_BUCKET_BITS
 #define HB_BUCKET_BITS 13
+#endif
+#define HB_MAX_NB 128  // buckets per level the partition kernels can handle (two per lane of wave 0)
 #ifndef HB_SPT
 #define HB_SPT 2  // samples per thread -> 512 samples per workgroup (<= 4096 records staged in 44 KiB of LDS)
 #endif
@@ -227,9 +230,9 @@ __device__ __forceinline__ void seg_scan_step(float2 (&val)[8], bool& f, int l16
 
 template <bool SCATTER>
 __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg) {  // wg: which run of 256*HB_SPT samples
-  __shared__ uint32_t hist[64];
-  __shared__ uint32_t base[64];
-  __shared__ uint32_t lbase[65];
+  __shared__ uint32_t hist[HB_MAX_NB];
+  __shared__ uint32_t base[HB_MAX_NB];
+  __shared__ uint32_t lbase[HB_MAX_NB + 1];
   __shared__ uint32_t wgmax;
   // scatter pass: records are first ordered by bucket in LDS, then written out with consecutive lanes on consecutive
   // records (PMC: writing each record straight to its slot cost 288 MB of HBM writes for 146 MB of records)
@@ -238,15 +241,21 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
   __shared__ uint16_t recI[MAXREC];
   __shared__ uint8_t recB[MAXREC];
   const int tid = threadIdx.x, lane = tid & 63, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
-  if (tid < 64) hist[tid] = 0;
+  if (tid < HB_MAX_NB) hist[tid] = 0;
   if (tid == 0) wgmax = 0;
   // scatter pass: the histogram pass left this workgroup's bucket counts and hg_wgscan its place in every bucket, so nothing is
   // counted again and no global cursor is touched -- wave 0 fetches both here and turns them into LDS offsets after the hashing
-  uint32_t my_count = 0, my_base = 0;
-  if (SCATTER && tid < a.nb) {
-    const size_t o = ((size_t)lev * a.nwg + wg) * a.nb + tid;
-    my_count = a.wg_counts[o];
-    my_base = a.offsets[lev * a.nb + tid] + a.wg_prefix[o];
+  uint32_t my_count[2] = {0, 0}, my_base[2] = {0, 0};  // buckets tid and tid + 64 (wave 0)
+  if (SCATTER && tid < 64) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int bk = tid + 64 * h;
+      if (bk < a.nb) {
+        const size_t o = ((size_t)lev * a.nwg + wg) * a.nb + bk;
+        my_count[h] = a.wg_counts[o];
+        my_base[h] = a.offsets[lev * a.nb + bk] + a.wg_prefix[o];
+      }
+    }
   }
   __syncthreads();
   const float s = a.scalings[l];
@@ -317,19 +326,24 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
     if (tid < a.nb) a.wg_counts[((size_t)lev * a.nwg + wg) * a.nb + tid] = hist[tid];
     return;
   }
-  if (tid < 64) {  // wave 0: local exclusive prefix of the bucket counts
-    const uint32_t c = my_count;
-    uint32_t incl = c;
+  if (tid < 64) {  // wave 0: local exclusive prefix of the bucket counts (two buckets per lane: 0-63, then 64-127)
+    uint32_t carry = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t c = my_count[h];
+      uint32_t incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+      }
+      lbase[tid + 64 * h] = carry + incl - c;
+      carry += __shfl(incl, 63, 64);
+      // this workgroup's slice of the bucket: bucket start + the records of the workgroups before it -- no cursor atomics (512
+      // workgroups x 64 buckets hammering 1024 counters made the returning atomic the longest step of the workgroup)
+      base[tid + 64 * h] = my_base[h];
     }
-    lbase[tid] = incl - c;
-    if (tid == 63) lbase[64] = incl;
-    // this workgroup's slice of bucket tid: bucket start + the records of the workgroups before it -- no cursor atomics (512
-    // workgroups x 64 buckets hammering 1024 counters made the returning atomic the longest step of the workgroup)
-    base[tid] = my_base;
+    if (tid == 0) lbase[HB_MAX_NB] = carry;
   }
   __syncthreads();
   if (tid == 0 && wgmax) atomicMax(&a.lmax[lev], wgmax);
@@ -348,7 +362,7 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
     }
   }
   __syncthreads();
-  const uint32_t total = lbase[64];
+  const uint32_t total = lbase[HB_MAX_NB];
   for (uint32_t i = tid; i < total; i += 256) {
     const uint32_t b = recB[i];
     const uint32_t g = base[b] + (i - lbase[b]);
@@ -496,7 +510,7 @@ static inline int hb_bucket_bits(int log2_T) { return log2_T < HB_BUCKET_BITS ? 
 extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_T) {
   if (n <= 0 || n_levels < 1 || log2_T < 2) return 0;
   const int nb = 1 << (log2_T - hb_bucket_bits(log2_T));
-  if (nb > 64) return 0;  // log2_T > 19: only the atomic path is available
+  if (nb > HB_MAX_NB) return 0;  // larger tables: only the atomic path is available
   const size_t m = (size_t)n_levels * nb, cap = (size_t)8 * n * n_levels;
   const size_t nwg = (size_t)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
   return (3 * m + 64) * 4 + 256 + 2 * ((size_t)n_levels * nwg * nb * 4 + 256) + cap * 2 + 256 + cap * 8 + 256;
