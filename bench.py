@@ -20,6 +20,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver does dmabuf IPC only (RCCL between the ranks of a node)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd")):
     if _p not in sys.path:
