@@ -379,8 +379,7 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
           const int l = 4 * q + lv;
           const HashCorners h = hash_corners(px, py, pz, io.scalings[l], mask, (uint32_t)l << io.log2_T);
           off[lv][0] = h.ox, off[lv][1] = h.oy, off[lv][2] = h.oz;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) f[lv][c] = io.table[h.idx[c]];
+          hash_gather8(io.table, h, f[lv]);
         }
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
@@ -1512,7 +1511,7 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   if (!params || (!enc && !hash) || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
   if (enc && ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7))) return UMHS_ERR_ARG;
   const bool dens = cfg->density_only != 0, spec = cfg->pred_specular != 0;
-  if (hash && (!dens || !hash->pos01 || !hash->table || !hash->scalings || ((uintptr_t)hash->table & 7) || hash->log2_T < 1 ||
+  if (hash && (!dens || !hash->pos01 || !hash->table || !hash->scalings || ((uintptr_t)hash->table & 15) || hash->log2_T < 1 ||
                hash->log2_T > 24))
     return UMHS_ERR_ARG;
   if (!dens && (!world_pos || !spectral || (spec && !directions))) return UMHS_ERR_ARG;

@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
   HashCorners h = hash_corners(pos01[3 * i], pos01[3 * i + 1], pos01[3 * i + 2], s, (1u << log2_T) - 1u,
                                (uint32_t)l << log2_T);
   float2 f[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) f[c] = table[h.idx[c]];
+  hash_gather8(table, h, f);
   const float2 r = hash_trilerp(f, h.ox, h.oy, h.oz);
   const float out[2] = {r.x, r.y};
   float* o = enc + i * stride_n + (int64_t)l * stride_l;
@@ -108,7 +107,7 @@ extern "C" int umhs_hashgrid_fwd(const float* pos01, const float* table, const f
                                  umhs_stream_t stream) {
   if (n < 0 || !pos01 || !table || !scalings || !enc) return UMHS_ERR_ARG;
   if (n_levels < 1 || n_levels > 32 || log2_T < 1 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
-  if (((uintptr_t)table & 7) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;
+  if (((uintptr_t)table & 15) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;  // (16-byte slot pairs are fetched with one load)
   if (n == 0) return UMHS_OK;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
   hipLaunchKernelGGL(hashgrid_fwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01,
