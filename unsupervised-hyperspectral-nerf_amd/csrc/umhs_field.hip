@@ -1255,24 +1255,40 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
   float* const stZ = st;
   float* const stX = st + S * 80;
   const int64_t ntiles = (io.n + S - 1) / S;
+  // The inputs of a tile (hash features, upstream gradients) are requested one tile ahead: with 2 waves per SIMD and four
+  // barriers per tile every wave of the workgroup reaches these loads together, and nothing else would cover their latency.
+  struct TileIn {
+    float2 e[4];
+    v4f g, g2;
+    float raw, dsig, sel;
+  };
+  auto fetch = [&](int64_t tile, TileIn& in) {
+    int64_t n = tile * S + row;
+    if (n >= io.n) n = io.n - 1;
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv) in.e[lv] = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
+    in.g = *reinterpret_cast<const v4f*>(io.d_bo + n * 16 + 4 * q);
+    in.g2 = io.d_bo2 ? *reinterpret_cast<const v4f*>(io.d_bo2 + n * 16 + 4 * q) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    in.raw = io.sigma_raw_in[n], in.dsig = io.d_sigma[n], in.sel = io.sel[n];
+  };
+  TileIn cur, nxt;
+  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t n = tile * S + row;
     const bool ok = n < io.n;
     if (!ok) n = io.n - 1;
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
     float encf[NT][8];
 #pragma unroll
-    for (int lv = 0; lv < 4; ++lv) {
-      const float2 v = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
-      encf[0][2 * lv] = v.x, encf[0][2 * lv + 1] = v.y;
-    }
+    for (int lv = 0; lv < 4; ++lv) encf[0][2 * lv] = cur.e[lv].x, encf[0][2 * lv + 1] = cur.e[lv].y;
     v4f t4[NT][4];
     float h[NT][16];
     gemm_pack<4, 8, NT, 2>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
     relu_to<4, NT>(h, t4);
     float dzb1[NT][4];
     {
-      v4f g = ok ? *reinterpret_cast<const v4f*>(io.d_bo + n * 16 + 4 * q) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      if (io.d_bo2 && ok) g += *reinterpret_cast<const v4f*>(io.d_bo2 + n * 16 + 4 * q);  // split heads: feature_mlp's share
+      v4f g = ok ? cur.g : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      if (io.d_bo2 && ok) g += cur.g2;  // split heads: feature_mlp's share
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float gr = g[r];
@@ -1281,8 +1297,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
         dzb1[0][r] = gr;
       }
       if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
-        const float raw = io.sigma_raw_in[n];
-        dzb1[0][0] = ok ? io.d_sigma[n] * io.sel[n] * expf(fminf(fmaxf(raw, -15.0f), 15.0f)) : 0.0f;
+        dzb1[0][0] = ok ? cur.dsig * cur.sel * expf(fminf(fmaxf(cur.raw, -15.0f), 15.0f)) : 0.0f;
       }
     }
     BSYNC();
@@ -1315,6 +1330,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
               make_float2(de4[0][t][2 * rr], de4[0][t][2 * rr + 1]);
         }
     }
+    cur = nxt;
   }
   fold_ksplit<WAVES>(aB1, st, 4, wave, lane);
   float* const slab = slabs + (size_t)blockIdx.x * sl.total;
