@@ -1007,26 +1007,47 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
   float* const stZd = st;           // [S][FSd]   dZ of mlp_directional's output layer
   float* const stXh = st + S * FSd; // [S][16]    hidden of mlp_directional
   float* const stXm = stXh + S * 48;  // [S][16]  mixing coefficients m   (16-wide tiles use FS = 48: 16 + 12 + pad)
+  // per-sample inputs of a tile, requested one tile ahead (see field_bwd_base_kernel: every wave reaches these loads together)
+  struct TileIn {
+    float w[3], d[3], emb[4];
+    v4f x;  // part 0: the saved feature logits; part 1: d(feature logits) from part 0
+  };
+  auto fetch = [&](int64_t tile, TileIn& in) {
+    int64_t n = tile * S + row;
+    if (n >= io.n) n = io.n - 1;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) in.w[s] = io.wpos[3 * n + s];
+    if (SPEC) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) in.d[s] = io.dirs[3 * n + s];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = 4 * q + r - 1;
+      in.emb[r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) has zero weight
+    }
+    in.x = *reinterpret_cast<const v4f*>((PART == 0 ? io.feat_logits_in : io.d_fl) + n * 16 + 4 * q);
+  };
+  TileIn cur, nxt;
+  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t n0 = tile * S;
     int64_t n = n0 + row;
     const bool ok = n < io.n;
     if (!ok) n = io.n - 1;
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
     // =================== forward recompute of the heads (base-MLP output comes from the forward pass) ========
     float in27[NT][7], dir28[NT][7];
     {
       float pe[3];
-      pe_slots(pe, io.wpos[3 * n], io.wpos[3 * n + 1], io.wpos[3 * n + 2], q);
+      pe_slots(pe, cur.w[0], cur.w[1], cur.w[2], q);
 #pragma unroll
       for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = 4 * q + r - 1;
-        in27[0][3 + r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) has zero weight
-      }
+      for (int r = 0; r < 4; ++r) in27[0][3 + r] = cur.emb[r];
       if (SPEC) {
         float sh[4];
-        sh_slots(sh, io.dirs[3 * n], io.dirs[3 * n + 1], io.dirs[3 * n + 2], q);
+        sh_slots(sh, cur.d[0], cur.d[1], cur.d[2], q);
 #pragma unroll
         for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
 #pragma unroll
@@ -1080,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
       relu_to<4, NT>(a2h, t4);
       gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
-      fl4[0][0] = *reinterpret_cast<const v4f*>(io.feat_logits_in + n * 16 + 4 * q);  // saved by the forward pass
+      fl4[0][0] = cur.x;  // saved by the forward pass
       HeadState<NT> hs;
       head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
       float hdir[NT][4];
@@ -1189,7 +1210,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
     } else {
       float dfl[NT][4];
-      const v4f g = *reinterpret_cast<const v4f*>(io.d_fl + n * 16 + 4 * q);
+      const v4f g = cur.x;
 #pragma unroll
       for (int r = 0; r < 4; ++r) dfl[0][r] = ok ? g[r] : 0.0f;  // rows past the end must not contribute
       {
@@ -1202,6 +1223,7 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
       }
       if (ok) *reinterpret_cast<v4f*>(io.d_bo2 + n * 16 + 4 * q) = dbo4[0][0];
     }
+    cur = nxt;
   }
   if constexpr (PART == 0) {
     fold_ksplit<WAVES>(aH2, st, 4, wave, lane), fold_ksplit<WAVES>(aMX, st, TB, wave, lane);
