@@ -63,3 +63,30 @@ def test_flat_layout_names_and_alignment():
     v = L.view(flat, "endmembers")
     assert v.shape == (6, 31) and v.data_ptr() == flat.data_ptr() + 4 * L.offset("endmembers")
     assert ops.hash_scalings()[15] == 2047 and ops.hash_scalings().dtype == torch.float32
+
+
+def test_argument_errors_are_reported_before_anything_is_launched():
+    """Error behaviour of the boundary: NULL / negative / inconsistent arguments come back as negative codes from the host-side
+    checks (no HIP call is made, so this runs without a GPU); empty inputs are a success."""
+    from umhsnerf import _hip
+
+    lib = _hip.lib()
+    ARG, UNSUP = -1, -2
+    dummy = ctypes.c_void_p(4096)  # never dereferenced: every call below returns from its argument checks
+    assert lib.umhs_ray_prefix(None, 5, None, None, None) == ARG
+    assert lib.umhs_ray_prefix(dummy, -1, dummy, dummy, None) == ARG
+    assert lib.umhs_sample_midpoints(None, None, None, None, None, 3, None, None) == ARG
+    assert lib.umhs_sample_midpoints(None, None, None, None, None, 0, None, None) == 0  # nothing to do
+    assert lib.umhs_compact_samples(*([None] * 3), 4, *([None] * 13)) == ARG
+    assert lib.umhs_compact_samples(*([None] * 3), 0, *([None] * 13)) == 0
+    assert lib.umhs_visibility_count(dummy, dummy, dummy, dummy, 4, 16, 1e-4, 0.01, dummy, None, None) == ARG  # kept[] missing
+    assert lib.umhs_march_scratch(None, None, 8, None, None, 1, 16, 0.05, 1e3, 0.01, 0.0, None, None, None, 0.0, 8, None, None, None, None) == ARG
+    assert lib.umhs_hashgrid_fwd(None, None, None, 16, 16, 19, None, 2, 0, None) == ARG
+    assert lib.umhs_hashgrid_fwd(dummy, ctypes.c_void_p(4096 + 8), dummy, 16, 16, 19, dummy, 2, 0, None) == ARG  # table not 16-byte aligned
+    assert lib.umhs_hashgrid_bwd_apply_adam(dummy, dummy, 2, 0, dummy, 0, 0, 16, 0, 16, 19, dummy, dummy, 1 << 20, dummy, dummy, dummy,
+                                            1e-2, 0.9, 0.999, 1e-15, 1, 5, None) == UNSUP  # no samples: no reduce pass to ride on
+    assert lib.umhs_hashgrid_bwd_apply_adam(dummy, dummy, 2, 0, dummy, 8, 0, 16, 0, 16, 19, dummy, dummy, 1 << 20, None, dummy, dummy,
+                                            1e-2, 0.9, 0.999, 1e-15, 1, 5, None) == ARG
+    assert lib.umhs_adam_step(dummy, dummy, dummy, dummy, 16, 1e-2, 0.9, 0.999, 1e-15, 0, 1.0, 0, 0, None) == ARG  # step < 1
+    assert lib.umhs_hashgrid_bwd_workspace_bytes(1000, 16, 22) == 0  # 2^22 table: only the atomic path (more than 128 buckets)
+    assert lib.umhs_hashgrid_bwd_workspace_bytes(1000, 16, 20) > 0
