@@ -362,6 +362,13 @@ int umhs_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 int umhs_adam_step_rows(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* rows,
                         int64_t n_rows, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
                         umhs_stream_t stream);
+/* umhs_adam_step_rows on `rows` and umhs_adam_step on elements [range_begin, range_begin + range_count) of the same flat buffers  */
+/* (clamp range in absolute elements) in ONE launch: what is left for the optimizer when the dense hash levels were updated by     */
+/* umhs_hashgrid_bwd_apply_adam.                                                                                                   */
+int umhs_adam_step_rows_range(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* rows,
+                              int64_t n_rows, int64_t range_begin, int64_t range_count, float lr, float beta1, float beta2,
+                              float eps, int64_t step, float grad_scale, int64_t clamp_begin, int64_t clamp_end,
+                              umhs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 // epilogue of hg_reduce_kernel, so that the fused and the separate update give the same bits.
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, const float gk, const float lr_bc1, const float b1,
                                             const float b2, const float eps, const float sqrt_bc2) {
+#pragma clang fp contract(off)  // the same rounding in every kernel this is inlined into (and torch's mul_/add_ sequence)
   m = m * b1 + gk * (1.0f - b1);
   v = v * b2 + gk * gk * (1.0f - b2);
   const float denom = sqrtf(v) / sqrt_bc2 + eps;
@@ -1639,6 +1640,57 @@ extern "C" int umhs_adam_step_rows(float* params, const float* grads, float* exp
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, umhs_s(stream), params, grads,
                      exp_avg, exp_avg_sq, rows, n_rows, (float)(lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// adam_rows_kernel and adam_kernel in one launch: the first row_blocks workgroups take the rows, the others the dense range
+// [t0, t0 + tn) (what is left for the optimizer when the dense hash levels were updated inside the backward: the live rows of the
+// coarse levels and the MLP / endmember tail -- two ~6 us launches at the very end of the step).
+__global__ __launch_bounds__(256) void adam_rows_range_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, const int64_t* __restrict__ rows, int64_t n_rows,
+                                                              int row_blocks, int64_t t0, int64_t tn, float lr_bc1, float b1, float b2,
+                                                              float eps, float sqrt_bc2, float gscale, int64_t cb, int64_t ce) {
+  if ((int)blockIdx.x < row_blocks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    const int64_t o = rows[i] * 2;
+    float2 pp = *reinterpret_cast<float2*>(p + o), mm = *reinterpret_cast<float2*>(m + o), vv = *reinterpret_cast<float2*>(v + o);
+    const float2 gg = *reinterpret_cast<const float2*>(g + o);
+    adam_update(pp.x, mm.x, vv.x, gg.x * gscale, lr_bc1, b1, b2, eps, sqrt_bc2);
+    adam_update(pp.y, mm.y, vv.y, gg.y * gscale, lr_bc1, b1, b2, eps, sqrt_bc2);
+    *reinterpret_cast<float2*>(p + o) = pp;
+    *reinterpret_cast<float2*>(m + o) = mm;
+    *reinterpret_cast<float2*>(v + o) = vv;
+    return;
+  }
+  const int64_t nblk = (int64_t)gridDim.x - row_blocks;
+  for (int64_t j = (((int64_t)blockIdx.x - row_blocks) * 256 + threadIdx.x); j < tn; j += nblk * 256) {
+    const int64_t e = t0 + j;
+    float pk = p[e], mk = m[e], vk = v[e];
+    adam_update(pk, mk, vk, g[e] * gscale, lr_bc1, b1, b2, eps, sqrt_bc2);
+    if (e >= cb && e < ce) pk = fminf(fmaxf(pk, 0.0f), 1.0f);
+    p[e] = pk, m[e] = mk, v[e] = vk;
+  }
+}
+
+extern "C" int umhs_adam_step_rows_range(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* rows,
+                                         int64_t n_rows, int64_t range_begin, int64_t range_count, float lr, float beta1, float beta2,
+                                         float eps, int64_t step, float grad_scale, int64_t clamp_begin, int64_t clamp_end,
+                                         umhs_stream_t stream) {
+  if (n_rows < 0 || range_begin < 0 || range_count < 0 || step < 1 || !params || !grads || !exp_avg || !exp_avg_sq ||
+      (n_rows > 0 && !rows))
+    return UMHS_ERR_ARG;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 7) return UMHS_ERR_ARG;
+  if (n_rows == 0 && range_count == 0) return UMHS_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int64_t row_blocks = (n_rows + 255) / 256;
+  int64_t range_blocks = (range_count + 255) / 256;
+  if (range_blocks > 1024) range_blocks = 1024;
+  if (row_blocks + range_blocks > 0x7fffffff) return UMHS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(adam_rows_range_kernel, dim3((unsigned)(row_blocks + range_blocks)), dim3(256), 0, umhs_s(stream), params, grads,
+                     exp_avg, exp_avg_sq, rows, n_rows, (int)row_blocks, range_begin, range_count, (float)(lr / bc1), beta1, beta2, eps,
+                     (float)sqrt(bc2), grad_scale, clamp_begin, clamp_end);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }

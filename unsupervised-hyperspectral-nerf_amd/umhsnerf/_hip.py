@@ -102,6 +102,7 @@ SIGNATURES = {
     "umhs_ssim_partials": (_i64, [C.c_int, C.c_int, C.c_int]),
     "umhs_ssim": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp]),
     "umhs_adam_step_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "umhs_adam_step_rows_range": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _i64, _i64, _vp]),
     "umhs_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _i64, _i64, _vp]),
 }
 

@@ -549,6 +549,14 @@ def adam_step_rows(p, g, m, v, rows, step: int, lr: float, betas=(0.9, 0.999), e
                                               grad_scale, _hip.stream()), "umhs_adam_step_rows")
 
 
+def adam_step_rows_range(p, g, m, v, rows, begin: int, end: int, step: int, lr: float, betas=(0.9, 0.999), eps=1e-15, grad_scale=1.0,
+                         clamp_range=(0, 0)):
+    """adam_step_rows(rows) + adam_step on elements [begin, end) of the same flat buffers (clamp_range in absolute elements): one launch."""
+    _hip.check(_hip.lib().umhs_adam_step_rows_range(ptr(p), ptr(g), ptr(m), ptr(v), ptr(rows), rows.numel(), begin, end - begin, lr, betas[0],
+                                                    betas[1], eps, step, grad_scale, clamp_range[0], clamp_range[1], _hip.stream()),
+               "umhs_adam_step_rows_range")
+
+
 # --------------------------------------------------------------------------------------------- #
 # autograd glue
 # --------------------------------------------------------------------------------------------- #

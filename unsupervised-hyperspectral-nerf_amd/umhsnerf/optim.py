@@ -87,6 +87,11 @@ class UMHSAdam(torch.optim.Optimizer):
                 def update(a: int, b: int, scale: float) -> None:
                     """Adam on elements [a, b) of the flat buffers; the sparse coarse levels only on their live rows."""
                     if sparse is not None and a == 0 and b >= sparse[1] and sparse[0].device == p.device:
+                        if done_by_backward is not None and done_by_backward[0] <= sparse[1] and done_by_backward[1] < b:
+                            # the backward took everything between the sparse rows and the MLP tail: rows + tail in one launch
+                            ops.adam_step_rows_range(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], sparse[0], done_by_backward[1], b,
+                                                     st["step"], lr, group["betas"], group["eps"], grad_scale=scale, clamp_range=(cb, ce))
+                            return
                         ops.adam_step_rows(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], sparse[0], st["step"], lr, group["betas"],
                                            group["eps"], grad_scale=scale)
                         a = sparse[1]
