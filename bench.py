@@ -183,7 +183,8 @@ def main():
 
     timer = KernelTimer(ops)
     OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "composite_fwd", "tmid_minmax", "ray_train_tail", "composite_bwd", "field_bwd",
-           "hashgrid_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "field_fwd_prepare", "field_bwd_prepare", "adam_step")
+           "hashgrid_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "field_fwd_prepare", "field_bwd_prepare", "adam_step",
+           "adam_step_rows", "adam_step_rows_range")  # (one GPU: the dense hash levels' Adam step rides in hashgrid_bwd_apply)
     for name in OPS:
         timer.wrap(name)
     # Inside the timed region only the dominant operator carries HIP events (2 per step): an event is a barrier packet on the
