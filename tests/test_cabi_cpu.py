@@ -90,3 +90,63 @@ def test_argument_errors_are_reported_before_anything_is_launched():
     assert lib.umhs_adam_step(dummy, dummy, dummy, dummy, 16, 1e-2, 0.9, 0.999, 1e-15, 0, 1.0, 0, 0, None) == ARG  # step < 1
     assert lib.umhs_hashgrid_bwd_workspace_bytes(1000, 16, 22) == 0  # 2^22 table: only the atomic path (more than 128 buckets)
     assert lib.umhs_hashgrid_bwd_workspace_bytes(1000, 16, 20) > 0
+
+
+def test_null_pointers_of_the_field_and_hashgrid_entries_are_argument_errors():
+    """Every pointer a given configuration dereferences is checked on the host (the one GPU fault of round 1
+    was a NULL ``d_enc`` reaching the bucket-histogram kernel).  Nothing below gets as far as a launch."""
+    from umhsnerf import _hip
+
+    lib = _hip.lib()
+    ARG = -1
+    d = ctypes.c_void_p(4096)
+    cfg = _hip.FieldCfg(31, 6, 1, 0, 0.4)
+    pp = _hip.FieldParams(*([4096] * 21))
+    gp = _hip.FieldGrads(*([4096] * 21))
+    fwd = lambda **kw: lib.umhs_field_fwd(*[kw.get(k, v) for k, v in dict(
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, wpos=d, dirs=d, sel=d, n=64, sigma=d, sigma_raw=d, emb=d,
+        spectral=d, spectral2=d, specular=d, abund=d, logits=d, ws=None, wsb=0, ready=0, stream=None).items()])
+    for missing in ("params", "enc", "wpos", "dirs", "sel", "sigma", "spectral"):
+        assert fwd(**{missing: None}) == ARG, missing
+    assert fwd(sn=3) == ARG  # odd strides cannot be float2 rows
+    no_w = _hip.FieldParams(*([4096] * 21))
+    no_w.dir_w1 = None  # a layer this cfg uses
+    assert fwd(params=ctypes.byref(no_w)) == ARG
+    bwd = lambda **kw: lib.umhs_field_bwd(*[kw.get(k, v) for k, v in dict(
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, wpos=d, dirs=d, sel=d, sigma_raw=d, emb=d, logits=d, n=64,
+        d_sigma=d, d_spectral=d, d_emb=None, d_enc=d, grads=ctypes.byref(gp), ws=d, wsb=1 << 30, ready=0, stream=None).items()])
+    for missing in ("params", "enc", "wpos", "dirs", "sel", "sigma_raw", "emb", "d_sigma", "d_spectral", "grads"):
+        assert bwd(**{missing: None}) == ARG, missing
+    assert bwd(ws=None) == -3 and bwd(wsb=16) == -3  # workspace missing / too small
+    # hash-grid backward halves: positions, scalings, gradient and destination are all required before anything is launched
+    prep = lambda pos=d, sc=d: lib.umhs_hashgrid_bwd_prepare(pos, sc, 512, 0, 16, 19, d, 1 << 30, None)
+    assert prep(pos=None) == ARG and prep(sc=None) == ARG
+    app = lambda pos=d, g=d, sc=d, tab=d: lib.umhs_hashgrid_bwd_apply(pos, g, 2, 1024, sc, 512, 0, 16, 0, 16, 19, tab, 1, d, 1 << 30, None)
+    assert app(pos=None) == ARG and app(g=None) == ARG and app(sc=None) == ARG and app(tab=None) == ARG
+    one = lambda g=d, tab=d: lib.umhs_hashgrid_bwd(d, g, 2, 1024, d, 512, 0, 16, 19, tab, 0, d, 1 << 30, None)
+    assert one(g=None) == ARG and one(tab=None) == ARG
+    # training tail: ground truths / outputs the selected losses need
+    tail = lambda **kw: lib.umhs_ray_train_tail(*[kw.get(k, v) for k, v in dict(
+        s=d, M=d, E=d, acc=d, depth=d, mm=d, colors=d, gt=d, gt_rgb=d, bg=None, R=64, B=31, C=6, alpha=0.2, ws=5.0, wr=1.0, rgb_loss=1, rgb=d,
+        dclip=d, probs=d, raw=d, pred=d, losses=d, d_spec=d, d_acc=d, scratch=d, sb=4096, stream=None).items()])
+    for missing in ("s", "M", "acc", "mm", "gt", "gt_rgb", "losses", "d_spec", "d_acc", "scratch", "E", "colors", "depth"):
+        assert tail(**{missing: None}) == ARG, missing
+
+
+def test_workspace_slots_are_not_regrown_or_rebuilt_under_an_outstanding_prepare():
+    """ops._workspace hands a *_prepare call and its consumer the same buffer or raises: a slot with an outstanding lease is never
+    re-grown (the consumer would read an unfilled buffer) and never rebuilt by another call (it would read somebody else's image)."""
+    from umhsnerf import ops
+
+    dev = torch.device("cpu")  # the bookkeeping is device-agnostic; no kernel is called here
+    ops._ws_cache.pop((0, 7), None)
+    a = ops._workspace(1 << 20, dev, slot=7)
+    ops._lease(dev, 7, "some_prepare")
+    assert ops._workspace(1 << 19, dev, slot=7) is a  # smaller or equal requests are served from the same buffer
+    with pytest.raises(RuntimeError, match="re-grown"):
+        ops._workspace(1 << 22, dev, slot=7)
+    with pytest.raises(RuntimeError, match="overwrite"):
+        ops._require_free(dev, 7, "other_call")
+    ops._release(dev, 7)
+    assert ops._workspace(1 << 22, dev, slot=7) is not a
+    ops._ws_cache.pop((0, 7), None)

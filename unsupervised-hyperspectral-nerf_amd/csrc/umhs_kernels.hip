@@ -578,6 +578,9 @@ static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t
 
 // histogram (count_wgs workgroups per level; 0 = one per run of samples), per-workgroup prefix, bucket scan
 static int hb_run_prepare(const HbArgs& a, int n_levels, int count_wgs, umhs_stream_t stream) {
+  // The histogram pass reads the gradient only in the one-call form (grad_mask): a prepare half built from hb_args() has
+  // d_enc == nullptr, and a pass that dereferenced it anyway is the nil-address GPU fault recorded in DESIGN.md section 9.
+  if (a.grad_mask && !a.d_enc) return UMHS_ERR_ARG;
   const size_t m = (size_t)a.nlev * a.nb;
   dim3 pgrid((unsigned)(count_wgs > 0 && count_wgs < a.nwg ? count_wgs : a.nwg), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<false>, pgrid, dim3(256), 0, umhs_s(stream), a);
@@ -589,6 +592,7 @@ static int hb_run_prepare(const HbArgs& a, int n_levels, int count_wgs, umhs_str
 }
 
 static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stream_t stream) {  // scatter + bucket reduce
+  if (!a.d_enc || !d_table || !a.pos01 || !a.scalings) return UMHS_ERR_ARG;  // every pointer the two kernels dereference
   dim3 pgrid((unsigned)((a.n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<true>, pgrid, dim3(256), 0, umhs_s(stream), a);
   const size_t lds = (size_t)(2 << a.bucket_bits) * 8;

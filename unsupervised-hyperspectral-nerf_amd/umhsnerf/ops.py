@@ -182,6 +182,7 @@ def hashgrid_bwd_prepare(pos01, scalings, log2_T: int, level_begin: int = 0, lev
     ws = _workspace(nbytes, pos01.device, slot=1)
     _hip.check(_hip.lib().umhs_hashgrid_bwd_prepare(ptr(pos01), ptr(scalings), n, level_begin, level_count, log2_T, ptr(ws), ws.numel(),
                                                     _hip.stream()), "umhs_hashgrid_bwd_prepare")
+    _lease(pos01.device, WS_HASH_BWD, "hashgrid_bwd_prepare")
     return True
 
 
@@ -201,10 +202,14 @@ def hashgrid_bwd_apply(pos01, d_enc, scalings, log2_T: int, d_table, level_major
                                                            float(adam["lr"]), float(adam["betas"][0]), float(adam["betas"][1]),
                                                            float(adam["eps"]), int(adam["step"]), int(adam["level_begin"]),
                                                            _hip.stream()), "umhs_hashgrid_bwd_apply_adam")
+        if level_begin + level_count >= ws_range[0] + ws_range[1]:
+            _release(pos01.device, WS_HASH_BWD)
         return
     _hip.check(_hip.lib().umhs_hashgrid_bwd_apply(ptr(pos01), ptr(d_enc), sn, sl, ptr(scalings), n, level_begin, level_count, ws_range[0],
                                                   ws_range[1], log2_T, ptr(d_table), int(overwrite), ptr(ws), ws.numel(), _hip.stream()),
                "umhs_hashgrid_bwd_apply")
+    if level_begin + level_count >= ws_range[0] + ws_range[1]:  # the last level group of this prepare has been launched
+        _release(pos01.device, WS_HASH_BWD)
 
 
 def reserve_step_workspaces(spec: FieldSpec, n: int, device) -> bool:
@@ -212,6 +217,8 @@ def reserve_step_workspaces(spec: FieldSpec, n: int, device) -> bool:
     stream never allocate there (blocks handed out under another stream would need record_stream bookkeeping).
     Returns whether the partitioned hash-grid backward is available for this n."""
     cfg = spec.cfg(False)
+    for slot in (WS_FIELD_BWD, WS_HASH_BWD, WS_FIELD_FWD):  # a lease still open here belongs to a step that was abandoned
+        _release(device, slot)
     _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), device, slot=2)
     _workspace(_hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n), device)
     nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, NUM_LEVELS, spec.layout.log2_hashmap_size)
@@ -226,6 +233,7 @@ def field_fwd_prepare(spec: FieldSpec, flat):
     pp = spec.layout.c_struct(flat, _hip.FieldParams)
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), flat.device, slot=2)
     _hip.check(_hip.lib().umhs_field_fwd_prepare(C.byref(cfg), C.byref(pp), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_fwd_prepare")
+    _lease(flat.device, WS_FIELD_FWD, "field_fwd_prepare")
 
 
 def field_bwd_prepare(spec: FieldSpec, flat, n: int):
@@ -234,6 +242,7 @@ def field_bwd_prepare(spec: FieldSpec, flat, n: int):
     pp = spec.layout.c_struct(flat, _hip.FieldParams)
     ws = _workspace(_hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n), flat.device)
     _hip.check(_hip.lib().umhs_field_bwd_prepare(C.byref(cfg), C.byref(pp), ptr(ws), ws.numel(), _hip.stream()), "umhs_field_bwd_prepare")
+    _lease(flat.device, WS_FIELD_BWD, "field_bwd_prepare")
 
 
 def field_fwd_outputs(spec: FieldSpec, n: int, dev, density_only=False, want_emb=None, want_aux=True, want_logits=False):
@@ -265,6 +274,8 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
     o = out if out is not None else field_fwd_outputs(spec, n, dev, density_only, want_emb, want_aux, want_logits)
     off, cnt = part if part is not None else (0, n)
     at = lambda t, width: (t.data_ptr() + 4 * width * off) if t is not None else None
+    if not pack_ready:
+        _require_free(dev, WS_FIELD_FWD, "field_fwd (pack image rebuild)")
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_fwd(C.byref(cfg), C.byref(pp), at(enc, sn), sn, sl, at(wpos, 3), at(dirs, 3), at(sel, 1), cnt,
                                          at(o["sigma"], 1), at(o["sigma_raw"], 1), at(o["emb"], GEO_FEAT_DIM), at(o["spectral"], L.wavelengths),
@@ -272,6 +283,8 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
                                          at(o["abundances"], L.num_classes), at(o.get("feat_logits"), 16), ptr(ws), ws.numel(), int(pack_ready),
                                          _hip.stream()),
                "umhs_field_fwd")
+    if pack_ready:
+        _release(dev, WS_FIELD_FWD)
     return o
 
 
@@ -283,6 +296,7 @@ def field_density(spec: FieldSpec, flat, pos01, sel, want_emb: bool = True):
     cfg = spec.cfg(True)
     pp = L.c_struct(flat, _hip.FieldParams)
     o = field_fwd_outputs(spec, n, dev, True, want_emb, True, False)
+    _require_free(dev, WS_FIELD_FWD, "field_density (pack image rebuild)")
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_density(C.byref(cfg), C.byref(pp), ptr(pos01), ptr(L.view(flat, "mlp_base.encoder.hash_table")),
                                              ptr(spec.scalings), L.log2_hashmap_size, ptr(sel), n, ptr(o["sigma"]), ptr(o["sigma_raw"]),
@@ -291,15 +305,39 @@ def field_density(spec: FieldSpec, flat, pos01, sel, want_emb: bool = True):
 
 
 _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+_ws_leases: Dict[Tuple[int, int], str] = {}  # (device, slot) -> the *_prepare call whose consumer has not been launched yet
+
+WS_FIELD_BWD, WS_HASH_BWD, WS_FIELD_FWD = 0, 1, 2  # slots of the per-device workspace cache
 
 
 def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    """Cached per-(device, slot) scratch.  A slot is never re-grown while a ``*_prepare`` call has parked data in it for a consumer
+    that has not been launched yet (``_lease`` / ``_release``): the consumer would be handed a fresh, unfilled buffer."""
     key = (device.index or 0, slot)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
+        if key in _ws_leases:
+            raise RuntimeError(f"workspace slot {slot} would be re-grown ({0 if ws is None else ws.numel()} -> {nbytes} bytes) while "
+                               f"{_ws_leases[key]} holds data in it for a consumer that has not run; size it first "
+                               "(ops.reserve_step_workspaces)")
         ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
         _ws_cache[key] = ws
     return ws
+
+
+def _lease(device, slot: int, who: str) -> None:
+    _ws_leases[(device.index or 0, slot)] = who
+
+
+def _release(device, slot: int) -> None:
+    _ws_leases.pop((device.index or 0, slot), None)
+
+
+def _require_free(device, slot: int, who: str) -> None:
+    """A call that rebuilds a slot's contents must not run between a ``*_prepare`` and its consumer."""
+    held = _ws_leases.get((device.index or 0, slot))
+    if held is not None:
+        raise RuntimeError(f"{who} would overwrite workspace slot {slot} while {held} holds data in it for a consumer that has not run")
 
 
 def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
@@ -318,6 +356,8 @@ def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_ra
                                          ptr(sigma_raw), ptr(emb), ptr(feat_logits), n,
                                          ptr(d_sigma), ptr(d_spectral), ptr(d_emb), ptr(d_enc), C.byref(gp), ptr(ws),
                                          ws.numel(), int(packs_ready), _hip.stream()), "umhs_field_bwd")
+    if packs_ready:
+        _release(sel.device, WS_FIELD_BWD)
     return d_enc
 
 
