@@ -170,7 +170,7 @@ def main():
     N = R * S
     bands = list(np.linspace(400, 700, B))
     mc = UMHSConfig(method=cfg["method"], pred_specular=cfg["pred_specular"], temperature=cfg["temperature"], per_band_outputs=True)
-    pipe = UMHSPipeline(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=local, seed=42)
+    pipe = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=local, seed=42)
     trained_like_init(pipe.model.field, seed=42)
     if world > 1:
         dist.broadcast(pipe.model.field.flat.data, src=0)

@@ -36,7 +36,7 @@ def main():
         torch.manual_seed(11)  # the training background colour is random (umhs_model.py:466-470 in the reference)
         torch.cuda.manual_seed(11)
         mc = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, per_band_outputs=True)
-        pipe = UMHSPipeline(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=0, seed=3)
+        pipe = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=0, seed=3)
         trained_like_init(pipe.model.field, seed=3)
         dist.broadcast(pipe.model.field.flat.data, src=0)
         with torch.no_grad():

@@ -100,11 +100,34 @@ def _sink_worker(rank, world, port, out):
             for l0, cnt in sink.groups(12):
                 sink.segment_done(buf[l0 * 4:(l0 + cnt) * 4])
             sink.commit()
-            assert p.grad is buf and not sink.owns_next_backward()  # a second backward would have to accumulate: plain path
+            assert p.grad is buf and sink.owns_next_backward()  # a further backward would ADD to the buffer (gradient accumulation) ...
+            with pytest.raises(RuntimeError, match="already started its all-reduce"):
+                sink.begin()  # ... which more than one rank may only do when the exchange was deferred to the last micro-step
             assert sink.finish(p.grad)
             torch.testing.assert_close(p.grad, torch.arange(64.0) * 3 + 2 * it)
             assert not sink.finish(p.grad)  # nothing pending any more
             p.grad = None
+        # an accumulation window of three micro-steps: no exchange (one level group) until the last, which reduces the SUM
+        for micro in range(3):
+            sink.defer_reduce = micro < 2
+            assert sink.owns_next_backward()
+            buf = sink.begin()
+            assert sink.accumulating == (micro > 0)
+            assert sink.groups(12) == ([(0, 12)] if micro < 2 else [(0, 3), (3, 3), (6, 3), (9, 3)])
+            if micro == 0:
+                buf.copy_(torch.full((64,), float(rank + 1)))
+            else:
+                buf.add_(float(rank + 1))  # the kernels' += mode
+            sink.segment_done(buf[48:])
+            for l0, cnt in sink.groups(12):
+                sink.segment_done(buf[l0 * 4:(l0 + cnt) * 4])
+            sink.commit()
+            assert bool(sink.works) == (micro == 2)
+        assert sink.finish(p.grad)
+        torch.testing.assert_close(p.grad, torch.full((64,), 9.0))  # 3 micro-steps x (1 + 2)
+        p.grad = torch.zeros(64)  # a gradient somebody else put there: autograd's job, not the sink's
+        assert not sink.owns_next_backward()
+        p.grad = None
         sink.async_reduce = False
         assert sink.groups(16) == [(0, 16)]
         sink.begin().fill_(1.0)

@@ -112,7 +112,7 @@ def test_training_from_the_datamanager_reduces_the_loss():
         bands = list(np.linspace(420, 680, B))
     dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=2048), device=DEV, seed=1, train=split)
     cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="black")
-    pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": bands, "num_classes": 3}, seed=2, datamanager=dm)
+    pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": bands, "num_classes": 3}, seed=2, datamanager=dm)
     with torch.no_grad():  # a self-consistent target: rgb = converter(hs)
         split.image = pipe.model.converter(split.hs_image.view(-1, B)).view(*split.hs_image.shape[:3], 3).contiguous()
     losses = []
@@ -160,7 +160,7 @@ def test_eval_image_path_and_metrics():
     split, _, _, _ = _split(n=3, B=B)
     dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=1024), device=DEV, seed=1, train=split)
     cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="black")
-    pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=2, datamanager=dm)
+    pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=2, datamanager=dm)
     for step in range(3):
         pipe.get_train_loss_dict(step)
     cam, batch = dm.next_eval_image(0)

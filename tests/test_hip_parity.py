@@ -508,7 +508,7 @@ def test_model_train_iteration_matches_oracle_step():
     R, S, B, Cn, temp = 40, 20, 31, 6, 0.4
     bands = list(np.linspace(400, 700, B))
     cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=temp, log2_hashmap_size=14, background_color="black")
-    pipe = UMHSPipeline(cfg, torch.device(DEV), metadata={"wavelengths": bands, "num_classes": Cn}, seed=3)
+    pipe = UMHSPipeline.from_packed_samples(cfg, torch.device(DEV), metadata={"wavelengths": bands, "num_classes": Cn}, seed=3)
     p = T.FieldParams(Cn, B, True, log2_hashmap_size=14, table_scale=0.5, seed=9)
     with torch.no_grad():
         p.base_b[1][0] += 1.0

@@ -186,7 +186,7 @@ def test_direct_training_step_equals_the_autograd_path(method, specular, monkeyp
         monkeypatch.setenv("UMHS_DIRECT_STEP", direct)
         torch.manual_seed(4)
         cfg = UMHSConfig(method=method, pred_specular=specular, temperature=0.5, per_band_outputs=True)
-        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=8)
+        pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=8)
         with torch.no_grad():
             tab = pipe.model.field.layout.view(pipe.model.field.flat.data, "mlp_base.encoder.hash_table")
             tab.mul_(300.0)
@@ -236,7 +236,7 @@ def test_full_size_training_step_other_configs(name, R, S, B, C, spec, temp, mon
         monkeypatch.setenv("UMHS_DIRECT_STEP", direct)
         torch.manual_seed(5)
         cfg = UMHSConfig(method="rgb+spectral", pred_specular=spec, temperature=temp, per_band_outputs=False)
-        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": C}, seed=6)
+        pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": C}, seed=6)
         with torch.no_grad():
             pipe.model.field.layout.view(pipe.model.field.flat.data, "mlp_base.encoder.hash_table").mul_(300.0)
             batch = {"image": pipe.model.converter(b["gt_spectral"]), "hs_image": b["gt_spectral"]}
@@ -278,7 +278,7 @@ def test_adam_step_riding_in_the_reduce_pass_is_the_same_update(monkeypatch):
         monkeypatch.setenv("UMHS_FUSED_ADAM", fused)
         torch.manual_seed(4)
         cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.5, per_band_outputs=False)
-        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=8)
+        pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=8)
         with torch.no_grad():
             pipe.model.field.layout.view(pipe.model.field.flat.data, "mlp_base.encoder.hash_table").mul_(300.0)
             batch = {"image": pipe.model.converter(b["gt_spectral"]), "hs_image": b["gt_spectral"]}

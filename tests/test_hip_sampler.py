@@ -117,7 +117,7 @@ def test_short_training_run_with_occupancy_sampler():
     bands = list(range(450, 651, 10))
     cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.5, log2_hashmap_size=15, grid_resolution=32,
                      grid_levels=2, background_color="black", per_band_outputs=False)
-    pipe = UMHSPipeline(cfg, torch.device(DEV), metadata={"wavelengths": bands, "num_classes": Cn}, seed=11)
+    pipe = UMHSPipeline.from_packed_samples(cfg, torch.device(DEV), metadata={"wavelengths": bands, "num_classes": Cn}, seed=11)
     model = pipe.model.train()
     o, d = _rays(R, seed=21, inside_frac=0.0)
     bundle = RayBundle(origins=o.to(DEV), directions=d.to(DEV))
@@ -159,7 +159,7 @@ def test_training_forward_reuses_the_samplers_hash_features(monkeypatch):
         split, _, _, _ = _split(n=4, B=B, const=0.5)
         dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=2048), device=DEV, seed=4, train=split)
         cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="black")
-        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=5, datamanager=dm)
+        pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=5, datamanager=dm)
         for step in range(20):
             pipe.get_train_loss_dict(step)
         rb, batch = dm.next_train(20)
@@ -200,7 +200,7 @@ def test_march_prefetched_one_step_ahead_is_the_same_training_run(monkeypatch):
         split, _, _, _ = _split(n=4, B=B, const=0.5)
         dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=1024), device=DEV, seed=4, train=split)
         cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="random")
-        pipe = UMHSPipeline(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=5, datamanager=dm)
+        pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=5, datamanager=dm)
         used, losses = 0, []
         for step in range(40):  # crosses the grid updates at steps 16 and 32
             ahead = getattr(pipe, "_ahead", None)

@@ -15,7 +15,7 @@ CFGS = {"C2": bench.C2,
         "C5": dict(R=8192, S=64, B=141, C=4, temperature=0.7, pred_specular=False, method="rgb+spectral")}
 for name, c in CFGS.items():
     mc = UMHSConfig(method=c["method"], pred_specular=c["pred_specular"], temperature=c["temperature"], per_band_outputs=True)
-    pipe = UMHSPipeline(mc, dev, metadata={"wavelengths": list(np.linspace(400, 700, c["B"])), "num_classes": c["C"]}, seed=42)
+    pipe = UMHSPipeline.from_packed_samples(mc, dev, metadata={"wavelengths": list(np.linspace(400, 700, c["B"])), "num_classes": c["C"]}, seed=42)
     bench.trained_like_init(pipe.model.field, seed=42)
     b = bench.synthetic_batch(c["R"], c["S"], c["B"], seed=42, device=dev)
     rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])

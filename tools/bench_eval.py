@@ -12,7 +12,7 @@ Bd, H = 31, int(os.environ.get("EVAL_HW", "256"))
 split, _, _, _ = _split(n=4, H=H, W=H, B=Bd, const=0.6)
 dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=4096), device="cuda:0", seed=1, train=split)
 cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="random")
-p = UMHSPipeline(cfg, "cuda:0", metadata={"wavelengths": list(np.linspace(400, 700, Bd)), "num_classes": 6}, seed=2, datamanager=dm)
+p = UMHSPipeline.from_packed_samples(cfg, "cuda:0", metadata={"wavelengths": list(np.linspace(400, 700, Bd)), "num_classes": 6}, seed=2, datamanager=dm)
 with torch.no_grad():
     split.image = p.model.converter(split.hs_image.view(-1, Bd)).view(*split.hs_image.shape[:3], 3).contiguous()
 for step in range(300):

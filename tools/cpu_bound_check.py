@@ -12,7 +12,7 @@ from umhsnerf.umhs_pipeline import UMHSPipeline
 dev = torch.device("cuda", 0)
 cfg = C2; R, S, B, Cn = cfg["R"], cfg["S"], cfg["B"], cfg["C"]
 mc = UMHSConfig(method=cfg["method"], pred_specular=cfg["pred_specular"], temperature=cfg["temperature"], per_band_outputs=True)
-pipe = UMHSPipeline(mc, dev, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=42)
+pipe = UMHSPipeline.from_packed_samples(mc, dev, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=42)
 trained_like_init(pipe.model.field, seed=42)
 b = synthetic_batch(R, S, B, seed=42, device=dev)
 rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])

@@ -12,7 +12,7 @@ from umhsnerf.umhs_pipeline import UMHSPipeline
 dev = torch.device("cuda", 0)
 R, S, B, Cn = C2["R"], C2["S"], C2["B"], C2["C"]
 mc = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, per_band_outputs=True)
-pipe = UMHSPipeline(mc, dev, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=42)
+pipe = UMHSPipeline.from_packed_samples(mc, dev, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=42)
 trained_like_init(pipe.model.field, seed=42)
 b = synthetic_batch(R, S, B, seed=42, device=dev)
 rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])
@@ -35,7 +35,7 @@ Bd = 8
 split, _, _, _ = _split(n=6, B=Bd, const=0.6)
 dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=4096), device="cuda:0", seed=1, train=split)
 cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="black")
-p2 = UMHSPipeline(cfg, "cuda:0", metadata={"wavelengths": list(np.linspace(420, 680, Bd)), "num_classes": 3}, seed=2, datamanager=dm)
+p2 = UMHSPipeline.from_packed_samples(cfg, "cuda:0", metadata={"wavelengths": list(np.linspace(420, 680, Bd)), "num_classes": 3}, seed=2, datamanager=dm)
 with torch.no_grad():
     split.image = p2.model.converter(split.hs_image.view(-1, Bd)).view(*split.hs_image.shape[:3], 3).contiguous()
 t0 = time.perf_counter()

@@ -7,26 +7,36 @@ leave the GPU.  The uniform draws come from ``torch.rand`` on the device generat
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple, Type
 
 import torch
 
 from .. import ops
-from .._ns_compat import RayBundle
+from .._ns_compat import InstantiateConfig, RayBundle
 from .umhs_dataparser import Cameras, DataparserOutputs, UMHSDataParserConfig
 from .utils.hs_dataloader import HyperspectralDataset
 
 
 @dataclass
-class UMHSDataManagerConfig:
-    dataparser: UMHSDataParserConfig = field(default_factory=UMHSDataParserConfig)
+class UMHSDataManagerConfig(InstantiateConfig):
+    """``UMHSDataManagerConfig`` (umhs_datamanager.py:36-47): ``setup(device=, test_mode=, world_size=, local_rank=, num_classes=)``."""
+
+    _target: Type = field(default_factory=lambda: UMHSDataManager)
+    dataparser: Any = field(default_factory=UMHSDataParserConfig)
     train_num_rays_per_batch: int = 4096
     eval_num_rays_per_batch: int = 4096
     images_on_gpu: bool = True
     patch_size: int = 1
 
-    def setup(self, **kwargs) -> "UMHSDataManager":
-        return UMHSDataManager(self, **kwargs)
+
+class _DatasetView:
+    """What the pipeline reads off ``datamanager.train_dataset`` (umhs_pipeline.py:96-104): scene_box, metadata, len()."""
+
+    def __init__(self, split, scene_box, metadata):
+        self._split, self.scene_box, self.metadata = split, scene_box, metadata
+
+    def __len__(self) -> int:
+        return len(self._split)
 
 
 class ResidentSplit:
@@ -98,10 +108,20 @@ class UMHSDataManager:
             metadata = self.train_dataparser_outputs.metadata
             self.scene_box = self.train_dataparser_outputs.scene_box
         self.train_split, self.eval_split, self.metadata = train, eval, metadata or {}
+        self.train_dataset = _DatasetView(train, getattr(self, "scene_box", None), self.metadata)
+        self.eval_dataset = _DatasetView(eval, getattr(self, "scene_box", None), self.metadata) if eval is not None else None
+        if not hasattr(self, "train_dataparser_outputs"):  # resident splits handed in directly (tests): same attribute, metadata only
+            self.train_dataparser_outputs = type("Outputs", (), {"metadata": self.metadata})()
         self.train_count = self.eval_count = 0
         self.generator = torch.Generator(device=self.device)
         self.generator.manual_seed(seed + local_rank)
         self._eval_cursor = 0
+
+    def to(self, device):  # the stacks were placed at construction (umhs_pipeline.py:94 calls datamanager.to(device))
+        return self
+
+    def get_param_groups(self) -> Dict:
+        return {}
 
     def get_train_rays_per_batch(self) -> int:
         return self.config.train_num_rays_per_batch

@@ -73,6 +73,10 @@ class FieldLayout:
     def offset(self, name: str) -> int:
         return self.entries[name][0]
 
+    def tail_offset(self) -> int:
+        """First element behind the hash table: the MLP weights / biases and the endmembers follow."""
+        return self.entries["mlp_base.mlp.layers.0.weight"][0]
+
     # (C struct field, state-dict key)
     C_FIELDS = (
         ("base_w0", "mlp_base.mlp.layers.0.weight"), ("base_b0", "mlp_base.mlp.layers.0.bias"),
@@ -88,9 +92,11 @@ class FieldLayout:
         ("endmembers", "endmembers"),
     )
 
-    def c_struct(self, flat: torch.Tensor, cls):
+    def c_struct(self, flat: torch.Tensor, cls, tail_only: Optional[torch.Tensor] = None):
+        """``tail_only``: a tensor holding just the MLP / endmember segments (elements [tail_offset(), total) of the flat layout);
+        the struct then points into it -- none of its fields lies in the hash table."""
         s = cls()
-        base = flat.data_ptr()
+        base = flat.data_ptr() if tail_only is None else tail_only.data_ptr() - 4 * self.tail_offset()
         for cname, key in self.C_FIELDS:
             setattr(s, cname, base + 4 * self.entries[key][0])
         return s
@@ -341,13 +347,14 @@ def _require_free(device, slot: int, who: str) -> None:
 
 
 def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
-              packs_ready=False, feat_logits=None):
-    """Writes d_enc (returned) and the MLP / endmember gradients straight into ``d_flat`` (flat layout)."""
+              packs_ready=False, feat_logits=None, d_tail=None):
+    """Writes d_enc (returned) and the MLP / endmember gradients straight into ``d_flat`` (flat layout) -- or, when ``d_tail`` is
+    given (a tensor of ``total - tail_offset()`` floats), into that instead (gradient accumulation adds it to the flat gradient)."""
     n = sel.shape[0]
     L = spec.layout
     cfg = spec.cfg(False)
     pp = L.c_struct(flat, _hip.FieldParams)
-    gp = L.c_struct(d_flat, _hip.FieldGrads)
+    gp = L.c_struct(d_flat, _hip.FieldGrads, tail_only=d_tail)
     sn, sl = enc_strides(n, level_major)
     d_enc = torch.empty_like(enc)
     nbytes = _hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n)
@@ -497,11 +504,15 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
     own = sink is not None and sink.param is flat and sink.owns_next_backward()
     # the 64 MiB table segment is fully written by hashgrid_bwd(overwrite=True): no memset of the flat gradient
     d_flat = sink.begin() if own else torch.empty_like(flat)
-    tail = L.offset("mlp_base.mlp.layers.0.weight")
+    acc = own and sink.accumulating  # a further micro-step of an accumulation window: everything below ADDS to the buffer
+    tail = L.tail_offset()
     if not own:  # field_reduce overwrites every weight / bias / endmember entry; only the alignment padding between the segments is
         d_flat[tail:].zero_()  # never written -- the sink's persistent buffer has it zeroed once, a fresh tensor needs it now
+    d_tail = torch.zeros(L.total - tail, device=flat.device, dtype=torch.float32) if acc else None
     d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
-                      packs_ready=prepared, feat_logits=feat_logits)
+                      packs_ready=prepared, feat_logits=feat_logits, d_tail=d_tail)
+    if acc:
+        d_flat[tail:].add_(d_tail)
     if own:
         sink.segment_done(d_flat[tail:])
     table = L.view(d_flat, "mlp_base.encoder.hash_table")
@@ -510,7 +521,8 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
         torch.cuda.current_stream(flat.device).wait_event(hash_ready)
     groups = sink.groups(NUM_LEVELS) if own else [(0, NUM_LEVELS)]
     # armed by the trainer (one GPU, optimizer.step() follows): the table's Adam step rides in the reduce pass (UMHSAdam.arm_fused)
-    fused = sink.take_fused_adam(flat) if (own and prepared and len(groups) == 1 and pos01.shape[0] > 0) else None
+    fused = sink.take_fused_adam(flat) if (own and not acc and prepared and len(groups) == 1 and pos01.shape[0] > 0) else None
+    ow = not acc  # overwrite mode writes every slot of the levels; accumulation runs the same kernels in their += mode
     for l0, cnt in groups:
         if prepared and fused is not None:
             lv = lambda t: L.view(t, "mlp_base.encoder.hash_table")
@@ -519,9 +531,9 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
             tb = L.offset("mlp_base.encoder.hash_table")
             sink.adam_done = (fused["step"], tb + fused["level_begin"] * T * FEATURES_PER_LEVEL, tb + NUM_LEVELS * T * FEATURES_PER_LEVEL)
         elif prepared:  # histogram + scan of all levels were done ahead of time (hashgrid_bwd_prepare)
-            hashgrid_bwd_apply(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
+            hashgrid_bwd_apply(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=ow, level_begin=l0, level_count=cnt)
         else:
-            hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=True, level_begin=l0, level_count=cnt)
+            hashgrid_bwd(pos01, d_enc, spec.scalings, L.log2_hashmap_size, table, True, overwrite=ow, level_begin=l0, level_count=cnt)
         if own:
             sink.table_levels_done(table, l0, cnt)
     if own:  # the buffer becomes param.grad directly (autograd gets None: nothing to accumulate or copy)

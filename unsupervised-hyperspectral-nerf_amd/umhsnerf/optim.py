@@ -22,7 +22,9 @@ def exp_decay_lr(step: int, lr_init: float = 2e-2, lr_final: float = 1e-5, max_s
 
 class UMHSAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 2e-2, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-15,
-                 clamp_range: Tuple[int, int] = (0, 0), lr_final: Optional[float] = None, max_steps: int = 30000):
+                 clamp_range: Tuple[int, int] = (0, 0), lr_final: Optional[float] = None, max_steps: int = 30000, weight_decay: float = 0.0):
+        if weight_decay:  # accepted because nerfstudio's AdamOptimizerConfig.setup() passes it; the reference leaves it at 0
+            raise NotImplementedError("UMHSAdam has no weight decay (umhs_config.py:61 uses AdamOptimizerConfig(lr=2e-2, eps=1e-15))")
         defaults = dict(lr=lr, betas=betas, eps=eps, clamp_range=clamp_range, lr_init=lr, lr_final=lr_final, max_steps=max_steps)
         super().__init__(params, defaults)
 

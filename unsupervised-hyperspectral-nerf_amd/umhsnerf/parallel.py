@@ -72,7 +72,12 @@ class FlatGradSink:
     kernel that finishes it has been launched: the small MLP/endmember tail right after the field backward, then the hash
     table per level group while the partition/reduce kernels of the next group still run -- so most of the 67 MB
     exchange hides behind the tail of the backward instead of following it.  ``UMHSAdam.step`` waits for the pending
-    reductions and applies 1/world.  Gradient accumulation (``param.grad`` already set) falls back to the plain path.
+    reductions and applies 1/world.
+
+    Gradient accumulation (the trainer's ``gradient_accumulation_steps``, scripts/rgb+spectral.sh:5): a backward that finds
+    ``param.grad`` to be this very buffer ADDS to it (``accumulating``): the hash-grid scatter runs in its ``+=`` mode and the
+    MLP / endmember tail goes through a small temporary.  With more than one rank the exchange must start in the last
+    micro-step only: the trainer sets ``defer_reduce`` on the others (UMHSPipeline does, from its ``gradient_accumulation_steps``).
     """
 
     def __init__(self, param: torch.nn.Parameter, level_groups: Optional[int] = None):
@@ -84,6 +89,8 @@ class FlatGradSink:
         self.reduced_ptr = None
         self.sparse_levels, self.sparse_rows = 0, None  # set_sparse_levels(): coarse levels travel as their live rows only
         self.fused_adam, self.adam_done = None, None  # UMHSAdam.arm_fused() / what the backward then did (step, begin, end)
+        self.accumulating = False  # this backward adds to the buffer (set by begin())
+        self.defer_reduce = False  # not the last micro-step of an accumulation window: no exchange yet
 
     def set_sparse_levels(self, scalings, log2_T: int) -> None:
         """Coarse hash levels use a small, rank-independent subset of their 2^log2_T slots (4,913 of 524,288 at level 0): send the
@@ -101,11 +108,24 @@ class FlatGradSink:
             return None
         return fa
 
+    def _grad_is_buffer(self) -> bool:
+        g = self.param.grad
+        return g is not None and self.buffer is not None and g.data_ptr() == self.buffer.data_ptr() and g.shape == self.buffer.shape
+
     def owns_next_backward(self) -> bool:
-        return self.param.grad is None
+        """True when the coming backward may write this buffer directly: no gradient yet (overwrite), or the gradient IS this
+        buffer (a further micro-step of an accumulation window: add).  A foreign ``param.grad`` leaves the job to autograd."""
+        return self.param.grad is None or self._grad_is_buffer()
 
     def begin(self) -> torch.Tensor:
         p = self.param
+        self.accumulating = self._grad_is_buffer()
+        if self.accumulating:
+            if self.works or self.reduced_ptr is not None:
+                raise RuntimeError("gradient accumulation on more than one rank: the previous micro-step already started its all-reduce. "
+                                   "Tell the pipeline (UMHSPipelineConfig.gradient_accumulation_steps = the trainer's value) so that "
+                                   "only the last micro-step exchanges gradients")
+            return self.buffer
         self.fresh = self.buffer is None or self.buffer.shape != p.shape or self.buffer.device != p.device
         if self.fresh:  # zeroed once: the backward overwrites every parameter's entry each step, never the alignment padding
             self.buffer = torch.zeros_like(p.data)
@@ -113,8 +133,11 @@ class FlatGradSink:
         self.reduced_ptr = None
         return self.buffer
 
+    def reducing(self) -> bool:
+        return world()[1] > 1 and self.async_reduce and not self.defer_reduce
+
     def groups(self, n_levels: int):
-        if world()[1] == 1 or not self.async_reduce:
+        if not self.reducing():
             return [(0, n_levels)]
         g = max(1, n_levels // self.level_groups)
         out = [(l, min(g, n_levels - l)) for l in range(0, n_levels, g)]
@@ -123,13 +146,13 @@ class FlatGradSink:
         return out
 
     def segment_done(self, view: torch.Tensor) -> None:
-        if world()[1] > 1 and self.async_reduce:
+        if self.reducing():
             off = (view.data_ptr() - self.buffer.data_ptr()) // self.buffer.element_size()
             self.works.append((off, off + view.numel(), dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), None))
 
     def table_levels_done(self, table: torch.Tensor, l0: int, cnt: int) -> None:
         """Levels [l0, l0+cnt) of the table gradient ([L*T, 2] view of the buffer) are final: start their reduction."""
-        if not (world()[1] > 1 and self.async_reduce):
+        if not self.reducing():
             return
         T, ns = getattr(self, "table_rows", 0), self.sparse_levels
         lo, hi = l0, l0 + cnt

@@ -1,26 +1,76 @@
 """Method registration (mirror of ``umhsnerf/umhs_config.py:34-69``): ``umhs_method`` for nerfstudio's
-``nerfstudio.method_configs`` entry point (method name ``umhsnerf``, alias ``umhs``).
+``nerfstudio.method_configs`` entry point (``pyproject.toml``: ``umhsnerf = 'umhsnerf.umhs_config:umhs_method'``).
 
-With nerfstudio installed this builds the real MethodSpecification/TrainerConfig; without it (offline) it exposes
-the same defaults as a plain dict so the hot path and its tests do not depend on nerfstudio."""
+With nerfstudio importable ``umhs_method`` is a real ``MethodSpecification(config=TrainerConfig(method_name="umhsnerf", ...))``
+whose pipeline / datamanager / model configs are this package's classes and whose ``"fields"`` optimizer is the fused HIP Adam.
+Only a missing nerfstudio (ImportError) selects the offline form below -- any other failure while building the
+specification surfaces.  Offline, ``umhs_method`` holds the same configuration objects in a plain namespace, so the hot path and
+its tests do not depend on nerfstudio."""
 from __future__ import annotations
 
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Any, Optional, Tuple, Type
+
+from .data.umhs_datamanager import UMHSDataManagerConfig
+from .data.umhs_dataparser import UMHSDataParserConfig
+from .optim import UMHSAdam
 from .umhs_model import UMHSConfig
+from .umhs_pipeline import UMHSPipelineConfig
 
 METHOD_NAME = "umhsnerf"
-TRAINER_DEFAULTS = dict(
+DESCRIPTION = "umhs method (MI355X HIP hot path)"
+
+
+def make_pipeline_config() -> UMHSPipelineConfig:
+    """umhs_config.py:42-58: datamanager 9216*4 train / 4096 eval rays per batch, model eval chunks of 512 rays."""
+    return UMHSPipelineConfig(
+        datamanager=UMHSDataManagerConfig(dataparser=UMHSDataParserConfig(), train_num_rays_per_batch=9216 * 4, eval_num_rays_per_batch=4096),
+        model=UMHSConfig(eval_num_rays_per_chunk=512),
+    )
+
+
+TRAINER_FIELDS = dict(  # umhs_config.py:35-41,66-67
     method_name=METHOD_NAME, steps_per_eval_batch=500, steps_per_save=2000, max_num_iterations=30000,
-    mixed_precision=False,  # fp32 hot path (reference: True -> fp16 autocast on CUDA); parity is quoted vs fp32
-    train_num_rays_per_batch=9216 * 4, eval_num_rays_per_batch=4096, eval_num_rays_per_chunk=512,
-    optimizers={"fields": {"optimizer": dict(lr=2e-2, eps=1e-15), "scheduler": dict(lr_final=1e-5, max_steps=30000)}},
+    mixed_precision=False,  # the hot path is fp32 (reference: True = fp16 autocast around tcnn); parity is quoted against fp32
+    save_only_latest_checkpoint=False, vis="viewer",
 )
+OPTIMIZER_FIELDS = dict(lr=2e-2, eps=1e-15)  # AdamOptimizerConfig(lr=2e-2, eps=1e-15), umhs_config.py:61
+SCHEDULER_FIELDS = dict(lr_final=0.00001, max_steps=30000)  # ExponentialDecaySchedulerConfig, umhs_config.py:62
 
-try:  # pragma: no cover - needs nerfstudio
-    from nerfstudio.engine.trainer import TrainerConfig  # type: ignore
-    from nerfstudio.plugins.types import MethodSpecification  # type: ignore
 
-    from .umhs_pipeline import make_nerfstudio_trainer_config
+def make_nerfstudio_method():
+    """The reference's ``MethodSpecification`` with this package's classes.  Raises ImportError without nerfstudio."""
+    from nerfstudio.configs.base_config import ViewerConfig
+    from nerfstudio.engine.optimizers import AdamOptimizerConfig
+    from nerfstudio.engine.schedulers import ExponentialDecaySchedulerConfig
+    from nerfstudio.engine.trainer import TrainerConfig
+    from nerfstudio.plugins.types import MethodSpecification
 
-    umhs_method = MethodSpecification(config=make_nerfstudio_trainer_config(TRAINER_DEFAULTS), description="umhs method (MI355X HIP hot path)")
-except Exception:
-    umhs_method = {"config": dict(TRAINER_DEFAULTS, model=UMHSConfig(eval_num_rays_per_chunk=512)), "description": "umhs method (MI355X HIP hot path)"}
+    @dataclass
+    class UMHSAdamOptimizerConfig(AdamOptimizerConfig):
+        """Adam for param group "fields": one fused launch over the flat buffer (+ clamp_endmembers, + the gradient exchange).  The
+        learning rate comes from nerfstudio's scheduler through ``param_group["lr"]`` (UMHSAdam's own decay stays off)."""
+
+        _target: Type = UMHSAdam
+
+    return MethodSpecification(
+        config=TrainerConfig(
+            **TRAINER_FIELDS,
+            pipeline=make_pipeline_config(),
+            optimizers={"fields": {"optimizer": UMHSAdamOptimizerConfig(**OPTIMIZER_FIELDS),
+                                   "scheduler": ExponentialDecaySchedulerConfig(**SCHEDULER_FIELDS)}},
+            viewer=ViewerConfig(num_rays_per_chunk=1 << 12),
+        ),
+        description=DESCRIPTION,
+    )
+
+
+try:
+    umhs_method = make_nerfstudio_method()
+except ImportError:  # nerfstudio is not installed: same configuration, plain containers
+    umhs_method = SimpleNamespace(
+        config=SimpleNamespace(**TRAINER_FIELDS, pipeline=make_pipeline_config(),
+                               optimizers={"fields": {"optimizer": dict(OPTIMIZER_FIELDS, _target=UMHSAdam), "scheduler": dict(SCHEDULER_FIELDS)}}),
+        description=DESCRIPTION,
+    )

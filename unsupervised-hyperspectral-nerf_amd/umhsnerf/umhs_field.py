@@ -71,7 +71,7 @@ class UMHSField(nn.Module):
         self.temperature, self.converter, self.use_scalar = temperature, converter, True
         self.spatial_distortion = spatial_distortion
         self.layout = ops.FieldLayout(num_classes, wavelengths, pred_specular, log2_hashmap_size)
-        self.register_buffer("scalings", ops.hash_scalings(ops.NUM_LEVELS, 16, max_res))
+        self.register_buffer("scalings", ops.hash_scalings(ops.NUM_LEVELS, 16, max_res), persistent=False)  # a plain attribute upstream
         g = torch.Generator().manual_seed(seed) if seed is not None else None
         flat = torch.zeros(self.layout.total)
         L = self.layout
@@ -110,21 +110,37 @@ class UMHSField(nn.Module):
     def named_views(self) -> Dict[str, Tensor]:
         return {k: self.layout.view(self.flat.detach(), k) for k in self.layout.entries}
 
-    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):  # reference key names
-        sd = destination if destination is not None else {}
-        for k, v in self.named_views().items():
-            sd[prefix + k] = v.clone()
-        sd[prefix + "aabb"] = self.aabb
-        return sd
+    # Checkpoints speak the reference's key names (``_model.field.mlp_base.encoder.hash_table`` ...): the flat buffer is saved as
+    # its per-tensor views and loaded back through them, at every level of the module tree (nn.Module recurses through
+    # ``_save_to_state_dict`` / ``_load_from_state_dict``, so ``UMHSModel`` / ``UMHSPipeline`` checkpoints work too).
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for k in self.layout.entries:
+            v = self.layout.view(self.flat if keep_vars else self.flat.detach(), k)
+            destination[prefix + k] = v
+        destination[prefix + "aabb"] = self.aabb if keep_vars else self.aabb.detach()
 
-    def load_state_dict(self, state_dict, strict: bool = True):
-        missing = [k for k in self.layout.entries if k not in state_dict]
-        if strict and missing:
-            raise KeyError(f"missing keys {missing}; expected {_REF_KEYS_DOC}")
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         with torch.no_grad():
-            for k in self.layout.entries:
-                if k in state_dict:
-                    self.layout.view(self.flat, k).copy_(state_dict[k].to(self.flat.device))
+            for k, (_, shp) in self.layout.entries.items():
+                src = state_dict.get(prefix + k)
+                if src is None:
+                    if strict:
+                        missing_keys.append(prefix + k)
+                    continue
+                if tuple(src.shape) != tuple(shp):
+                    error_msgs.append(f"size mismatch for {prefix + k}: checkpoint {tuple(src.shape)} vs field {tuple(shp)}")
+                    continue
+                self.layout.view(self.flat, k).copy_(src.to(self.flat.device, torch.float32))
+            if prefix + "aabb" in state_dict:
+                self.aabb.copy_(state_dict[prefix + "aabb"].to(self.aabb.device))
+                self._aabb_host = tuple(float(v) for v in self.aabb.flatten().tolist())
+                self._spec_cache = None  # (a dict without "aabb" keeps the constructed box: parameter-only dicts load too)
+        if strict:
+            mine = {prefix + k for k in self.layout.entries} | {prefix + "aabb"}
+            kids = tuple(prefix + name + "." for name, m in self._modules.items() if m is not None)
+            for key in state_dict:
+                if key.startswith(prefix) and key not in mine and not key.startswith(kids):
+                    unexpected_keys.append(key)
 
     def _spec(self) -> ops.FieldSpec:
         if self._sparse_end and os.environ.get("UMHS_SPARSE_ADAM", "1") != "0":

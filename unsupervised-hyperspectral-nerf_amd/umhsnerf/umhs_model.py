@@ -4,23 +4,23 @@ driving the HIP hot path: field -> packed transmittance/compositing over all ban
 Output keys, shapes, loss weights and callbacks follow the reference.  What differs by design:
   * the four per-stream renderer calls of ``get_outputs`` (:270-304) are ONE compositing launch;
   * ``scale_gradients_by_distance_squared`` (:241-242) is applied inside the compositing backward;
-  * the sampler is pluggable: nerfacc's CUDA occupancy marcher does not exist on ROCm, so until the HIP marcher
-    lands ``get_outputs`` uses ``PackedUniformSampler``; ``get_outputs_from_samples`` takes any
-    packed samples (this is what the benchmark and tests feed).
+  * nerfacc's CUDA occupancy marcher does not exist on ROCm: ``get_outputs`` samples through the HIP marcher
+    (``sampler.OccGridEstimator`` / ``VolumetricSampler``); ``get_outputs_from_samples`` takes any packed samples (this is
+    what the benchmark and the parity tests feed).
 """
 from __future__ import annotations
 
 import os
 
 from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Literal, Optional, Tuple, Union
+from typing import Callable, Dict, List, Literal, Optional, Tuple, Type, Union
 
 import numpy as np
 import torch
 from torch import Tensor, nn
 
 from . import _hip, ops
-from ._ns_compat import FieldHeadNames, RayBundle, RaySamples, packed_ray_samples
+from ._ns_compat import FieldHeadNames, ModelBase, ModelConfigBase, RayBundle, RaySamples, TrainingCallback, TrainingCallbackLocation
 from .optim import UMHSAdam
 from .sampler import OccGridEstimator, VolumetricSampler
 from .umhs_field import UMHSField
@@ -36,9 +36,11 @@ CLASS_COLORS = torch.tensor([
 
 
 @dataclass
-class UMHSConfig:
-    """``UMHSConfig(InstantNGPModelConfig)``, umhs_model.py:61-119 (same names and defaults)."""
+class UMHSConfig(ModelConfigBase):
+    """``UMHSConfig(InstantNGPModelConfig)``, umhs_model.py:61-119 (same names and defaults; a nerfstudio ``ModelConfig`` when
+    nerfstudio is importable -- not an ``InstantNGPModelConfig``, whose model would build tcnn / nerfacc modules first)."""
 
+    _target: Type = field(default_factory=lambda: UMHSModel)
     enable_collider: bool = False
     collider_params: Optional[Dict[str, float]] = field(default_factory=lambda: {"near_plane": 2.0, "far_plane": 6.0})
     grid_resolution: Union[int, List[int]] = 128
@@ -63,36 +65,7 @@ class UMHSConfig:
     pred_specular: bool = False
     load_vca: bool = False
     eval_num_rays_per_chunk: int = 512
-    sampler: Literal["occupancy", "uniform"] = "occupancy"  # "occupancy" = the reference's nerfacc grid marcher (HIP port)
-    samples_per_ray: int = 64  # PackedUniformSampler only
     per_band_outputs: bool = True  # wv_i / residual_i / abundances_i views (umhs_model.py:273-304)
-
-    def setup(self, **kwargs) -> "UMHSModel":
-        return UMHSModel(self, **kwargs)
-
-
-class PackedUniformSampler(nn.Module):
-    """Stand-in for nerfstudio's VolumetricSampler (nerfacc occupancy marcher, umhs_model.py:206-209,229-237) until the
-    HIP marcher exists: S samples per ray with step render_step_size*(1+cone_angle*t), strided over the unit box."""
-
-    def __init__(self, samples_per_ray: int):
-        super().__init__()
-        self.S = samples_per_ray
-
-    @torch.no_grad()
-    def forward(self, ray_bundle: RayBundle, near_plane: float, far_plane: float, render_step_size: float,
-                alpha_thre: float = 0.0, cone_angle: float = 0.0) -> Tuple[RaySamples, Tensor]:
-        o, d = ray_bundle.origins, ray_bundle.directions
-        R, S = o.shape[0], self.S
-        t_near = (o.norm(dim=-1) - 1.3).clamp(min=near_plane)
-        if self.training:
-            t_near = t_near + torch.rand_like(t_near) * render_step_size
-        k = torch.arange(S, device=o.device, dtype=torch.float32)
-        t0 = (t_near[:, None] + k[None, :] * (2.6 / S)).reshape(-1)
-        t1 = t0 + render_step_size * (1 + cone_angle * t0)
-        ray_indices = torch.arange(R, device=o.device).repeat_interleave(S)
-        cam = ray_bundle.camera_indices[ray_indices] if ray_bundle.camera_indices is not None else None
-        return packed_ray_samples(o[ray_indices], d[ray_indices], t0, t1, cam), ray_indices
 
 
 class BandOutputs(dict):
@@ -181,18 +154,27 @@ class LazyMetrics(dict):
         return dict.values(self.materialize())
 
 
-class UMHSModel(nn.Module):
-    """UMHS model (``UMHSModel(NGPModel)``)."""
+class UMHSModel(ModelBase):
+    """UMHS model (``UMHSModel(NGPModel)``); built by ``config.setup(scene_box=, num_train_data=, metadata=, grad_scaler=,
+    num_classes=, wavelengths=)`` exactly as the reference pipeline does (umhs_pipeline.py:98-105)."""
 
     def __init__(self, config: UMHSConfig, scene_box=None, num_train_data: int = 1, metadata: Optional[Dict] = None,
-                 seed: Optional[int] = None, **kwargs):
-        super().__init__()
+                 seed: Optional[int] = None, grad_scaler=None, num_classes: Optional[int] = None, wavelengths=None, **kwargs):
+        nn.Module.__init__(self)  # nerfstudio's Model.__init__ would call populate_modules() before the fields below exist
         self.config = config
+        self.scene_box, self.render_aabb, self.collider, self.callbacks = scene_box, None, None, None
         aabb = getattr(scene_box, "aabb", scene_box)
         self.scene_aabb_t = torch.as_tensor(aabb if aabb is not None else [[-1, -1, -1], [1, 1, 1]], dtype=torch.float32).reshape(2, 3)
         self.num_train_data = num_train_data
-        self.kwargs = dict(metadata or kwargs.get("metadata") or {})
-        if "wavelengths" not in self.kwargs or "num_classes" not in self.kwargs:
+        self.grad_scaler = grad_scaler  # fp32 hot path: carried for interface parity, never used
+        # the reference reads self.kwargs["metadata"]["wavelengths" | "num_classes"] (umhs_model.py:171-172,188-189); the two
+        # explicit kwargs of its pipeline (:103-104) fill in what a metadata dict lacks
+        self.kwargs = dict(metadata or {})
+        if wavelengths is not None:
+            self.kwargs.setdefault("wavelengths", wavelengths)
+        if num_classes is not None:
+            self.kwargs.setdefault("num_classes", num_classes)
+        if self.kwargs.get("wavelengths") is None or "num_classes" not in self.kwargs:
             raise KeyError('metadata must carry "wavelengths" and "num_classes" (umhs_model.py:171-172,188-189)')
         self._seed = seed
         self.populate_modules()
@@ -219,10 +201,7 @@ class UMHSModel(nn.Module):
             c.render_step_size = float(((self.scene_aabb_t[1] - self.scene_aabb_t[0]) ** 2).sum().sqrt() / 1000)
         # umhs_model.py:201-209: nerfacc.OccGridEstimator(roi_aabb, resolution, levels) + VolumetricSampler(grid, density_fn)
         self.occupancy_grid = OccGridEstimator(self.scene_aabb_t.flatten(), resolution=int(c.grid_resolution), levels=c.grid_levels)
-        if c.sampler == "occupancy":
-            self.sampler = VolumetricSampler(self.occupancy_grid, density_fn=self.field.density_fn)
-        else:
-            self.sampler = PackedUniformSampler(c.samples_per_ray)
+        self.sampler = VolumetricSampler(self.occupancy_grid, density_fn=self.field.density_fn)
         self.cluster_probe = ClusterLookup(len(wl), self.kwargs["num_classes"])
         self.background_color = c.background_color
 
@@ -253,8 +232,19 @@ class UMHSModel(nn.Module):
         self.step = step
         self.occupancy_grid.update_every_n_steps(step=step, occ_eval_fn=lambda x: self.field.density_fn(x) * self.config.render_step_size)
 
-    def get_training_callbacks(self, training_callback_attributes=None) -> List:
-        return [("before_train_iteration", self.update_occupancy_grid), ("after_train_iteration", self.clamp_endmembers)]
+    def get_training_callbacks(self, training_callback_attributes=None) -> List[TrainingCallback]:
+        """umhs_model.py:542-591: clamp_endmembers AFTER every iteration (spectral methods), update_occupancy_grid BEFORE."""
+        callbacks = []
+        if self.config.method != "rgb":
+            callbacks.append(TrainingCallback(where_to_run=[TrainingCallbackLocation.AFTER_TRAIN_ITERATION], update_every_num_iters=1,
+                                              func=self.clamp_endmembers))
+        callbacks.append(TrainingCallback(where_to_run=[TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], update_every_num_iters=1,
+                                          func=self.update_occupancy_grid))
+        return callbacks
+
+    def update_to_step(self, step: int) -> None:
+        """nerfstudio Model.update_to_step (called by load_pipeline, umhs_pipeline.py:167): nothing here depends on the step."""
+        self.step = step
 
     # ---- forward -----------------------------------------------------------------------------------
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
@@ -304,12 +294,9 @@ class UMHSModel(nn.Module):
     def _sample(self, ray_bundle: RayBundle):
         c = self.config
         with torch.no_grad():
-            if isinstance(self.sampler, VolumetricSampler):
-                ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
-                                                        render_step_size=c.render_step_size, alpha_thre=c.alpha_thre,
-                                                        cone_angle=c.cone_angle)
-            else:
-                ray_samples, ray_indices = self.sampler(ray_bundle, c.near_plane, c.far_plane, c.render_step_size, c.alpha_thre, c.cone_angle)
+            ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
+                                                    render_step_size=c.render_step_size, alpha_thre=c.alpha_thre,
+                                                    cone_angle=c.cone_angle)
         return ray_samples, ray_indices
 
     def forward(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
@@ -368,10 +355,11 @@ class UMHSModel(nn.Module):
 
     # ---- training step without autograd -------------------------------------------------------------
     def direct_step_supported(self, batch) -> bool:
-        sink = self.field._grad_sink if self.field.use_grad_sink else None
+        if not self.field.use_grad_sink:
+            return False
+        sink = self.field._spec().grad_sink  # created on first use
         return (self.training and self.config.method in ("spectral", "rgb+spectral") and batch["image"].shape[-1] == 3
-                and os.environ.get("UMHS_DIRECT_STEP", "1") != "0" and self.field.use_grad_sink
-                and (sink is None or sink.owns_next_backward()) and self.field.flat.grad is None)
+                and os.environ.get("UMHS_DIRECT_STEP", "1") != "0" and sink.owns_next_backward())
 
     def draw_training_background(self, batch: Dict) -> Optional[Tensor]:
         """The random background of this step's rgb loss (RGBRenderer.blend_background_for_loss_computation), drawn by the caller

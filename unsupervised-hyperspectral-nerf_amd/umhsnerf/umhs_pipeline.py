@@ -1,62 +1,167 @@
-"""Pipeline glue (mirror of ``umhsnerf/umhs_pipeline.py``).  The reference forces ``world_size = 1``
-(``:86,108-109``), which silently disables its DDP wrap; here ray batches are sharded one rank per GPU and the flat
-"fields" gradient is all-reduced over RCCL/xGMI inside ``UMHSAdam.step``.
+"""Pipeline (mirror of ``umhsnerf/umhs_pipeline.py``): ``UMHSPipelineConfig`` (``:30-45``), ``UMHSPipeline`` with the
+reference's constructor ``(config, device, test_mode, world_size, local_rank, grad_scaler)`` (``:62-113``), its eval entry
+points (``:115-154``) and ``load_pipeline`` (``:157-175``).
 
-Data managers / parsers / checkpoint I/O are nerfstudio's and out of scope for the hot path."""
+What differs by design: the reference forces ``world_size = 1`` (``:86,108-109``), which silently disables its DDP wrap; here
+ray batches are sharded one rank per GPU and the flat "fields" gradient is all-reduced over RCCL/xGMI by the gradient sink
+(``parallel.FlatGradSink``) while the backward is still running, so there is no DDP wrapper around the model."""
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional
+from dataclasses import dataclass, field
+from typing import Any, Dict, Literal, Mapping, Optional, Type
 
 import torch
 import torch.distributed as dist
 
-from ._ns_compat import RaySamples
+from ._ns_compat import PipelineBase, PipelineConfigBase, RaySamples
+from .data.umhs_datamanager import UMHSDataManagerConfig
 from .umhs_model import UMHSConfig, UMHSModel
 
 
-class UMHSPipeline(torch.nn.Module):
-    """Minimal pipeline: model + one train iteration on packed samples (what ``Trainer.train_iteration`` does around
-    ``pipeline.get_train_loss_dict``: forward, loss, backward, optimizer step)."""
+@dataclass
+class UMHSPipelineConfig(PipelineConfigBase):
+    """``UMHSPipelineConfig(VanillaPipelineConfig)``, umhs_pipeline.py:30-45 (same names and defaults)."""
 
-    def __init__(self, config: UMHSConfig, device, metadata: Optional[Dict] = None, world_size: int = 1, local_rank: int = 0,
-                 seed: Optional[int] = 42, scene_box=None, datamanager=None):
-        super().__init__()
-        self.world_size, self.local_rank = world_size, local_rank
-        self.device = torch.device(device)
-        self.datamanager = datamanager  # data.umhs_datamanager.UMHSDataManager (umhs_pipeline.py:87-94) or None (packed-sample callers)
+    _target: Type = field(default_factory=lambda: UMHSPipeline)
+    datamanager: Any = field(default_factory=UMHSDataManagerConfig)
+    model: Any = field(default_factory=UMHSConfig)
+    check_nan: bool = False
+    num_classes: int = 5
+    gradient_accumulation_steps: int = 1
+    """Not in the reference (its scripts pass ``--gradient-accumulation_steps`` to the trainer, scripts/rgb+spectral.sh:5): set it to
+    the trainer's value when running on more than one GPU, so that the gradient exchange starts in the LAST micro-step's backward."""
+
+
+class _DepositedGrad(torch.autograd.Function):
+    """Loss value whose gradient w.r.t. the flat parameter has ALREADY been written to ``param.grad`` by the launch-sequence step
+    (UMHSModel.forward_backward_from_samples).  nerfstudio's Trainer calls ``loss.backward()`` on what get_train_loss_dict returns;
+    this makes that call a no-op instead of a second backward.  Needs an upstream gradient of 1 (GradScaler off: our TrainerConfig
+    sets mixed_precision=False -- the hot path is fp32)."""
+
+    @staticmethod
+    def forward(ctx, value, flat):
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
+
+
+class UMHSPipeline(PipelineBase):
+    """UMHS pipeline.  Built by nerfstudio's Trainer through ``config.pipeline.setup(device=..., test_mode=..., world_size=...,
+    local_rank=..., grad_scaler=...)`` -- the trainer then owns zero_grad / backward / optimizer.step (``trainer_driven``) -- or
+    by ``from_packed_samples`` (benchmark, tests), which owns a fused-Adam optimizer and steps it itself."""
+
+    def __init__(self, config: UMHSPipelineConfig, device, test_mode: Literal["test", "val", "inference"] = "val", world_size: int = 1,
+                 local_rank: int = 0, grad_scaler=None):
+        torch.nn.Module.__init__(self)  # like the reference's super(VanillaPipeline, self).__init__(): no base-class construction
+        self.config = config
+        if config.check_nan:
+            torch.autograd.set_detect_anomaly(True)
+        self.test_mode = test_mode
+        datamanager = config.datamanager.setup(device=device, test_mode=test_mode, world_size=world_size, local_rank=local_rank,
+                                               num_classes=config.num_classes)
+        if hasattr(datamanager, "to"):
+            datamanager.to(device)
+        assert datamanager.train_dataset is not None, "Missing input dataset"
+        model = config.model.setup(
+            scene_box=datamanager.train_dataset.scene_box, num_train_data=len(datamanager.train_dataset),
+            metadata=datamanager.train_dataset.metadata, grad_scaler=grad_scaler, num_classes=config.num_classes,
+            wavelengths=datamanager.train_dataparser_outputs.metadata.get("wavelengths", None))
+        self._init_common(model.to(device), datamanager, device, world_size, local_rank, trainer_driven=True,
+                          gradient_accumulation_steps=config.gradient_accumulation_steps)
+
+    @classmethod
+    def from_packed_samples(cls, config: UMHSConfig, device, metadata: Optional[Dict] = None, world_size: int = 1, local_rank: int = 0,
+                            seed: Optional[int] = 42, scene_box=None, datamanager=None, gradient_accumulation_steps: int = 1):
+        """Model config + metadata -> pipeline that owns its optimizer (``train_iteration`` / ``get_train_loss_dict`` step it).
+        ``datamanager``: a ``UMHSDataManager`` or None (callers that feed packed samples: bench.py, the parity tests)."""
+        self = cls.__new__(cls)
+        torch.nn.Module.__init__(self)
+        self.config = UMHSPipelineConfig(model=config, num_classes=int((metadata or {}).get("num_classes", 5)),
+                                         gradient_accumulation_steps=gradient_accumulation_steps)
+        self.test_mode = "val"
         if datamanager is not None:
             metadata = {**(datamanager.metadata or {}), **(metadata or {})}
             scene_box = scene_box if scene_box is not None else getattr(datamanager, "scene_box", None)
-        self._model = UMHSModel(config, scene_box=scene_box, metadata=metadata, seed=seed).to(device)
+        model = UMHSModel(config, scene_box=scene_box, metadata=metadata, seed=seed).to(device)
+        self._init_common(model, datamanager, device, world_size, local_rank, trainer_driven=False,
+                          gradient_accumulation_steps=gradient_accumulation_steps)
+        return self
+
+    def _init_common(self, model, datamanager, device, world_size, local_rank, trainer_driven, gradient_accumulation_steps):
+        self.world_size, self.local_rank = world_size, local_rank
+        self._device = torch.device(device)  # (nerfstudio's Pipeline.device is a read-only property: own attribute + property below)
+        self.datamanager = datamanager
+        self._model = model
+        self.trainer_driven = trainer_driven
+        self.gradient_accumulation_steps = max(1, int(gradient_accumulation_steps))
+        self._micro = 0  # micro-steps accumulated since the last optimizer step (train_iteration bookkeeping)
         if world_size > 1:  # identical parameters on every rank (DDP's initial broadcast)
             dist.broadcast(self._model.field.flat.data, src=0)
         self._model.field.use_grad_sink = True  # backward fills param.grad in place and reduces finished segments early
-        self.optimizer = self._model.make_optimizer()
+        self.optimizer = None if trainer_driven else self._model.make_optimizer()
 
     @property
     def model(self) -> UMHSModel:
         return self._model
 
-    def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None):
-        self.optimizer.zero_grad(set_to_none=True)
-        if self._model.direct_step_supported(batch):  # straight launch sequence, no autograd graph
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    # ---- micro-step bookkeeping (gradient accumulation) --------------------------------------------------------------
+    def _begin_micro_step(self, micro: int) -> bool:
+        """Called in front of a forward/backward: ``micro`` = index inside the accumulation window.  Zeroes the gradient at the
+        window's start when this pipeline owns the optimizer (the nerfstudio trainer does it itself, Optimizers.zero_grad_some) and
+        tells the gradient sink whether this backward is the one that exchanges gradients.  Returns "last micro-step"."""
+        last = micro == self.gradient_accumulation_steps - 1
+        if not self.trainer_driven and micro == 0:
+            self.optimizer.zero_grad(set_to_none=True)
+        sink = self._model.field._spec().grad_sink
+        sink.defer_reduce = not last
+        if last and not self.trainer_driven and self.gradient_accumulation_steps == 1:
             self.optimizer.arm_fused()  # optimizer.step() follows unconditionally: the table's Adam step may ride in the backward
+        return last
+
+    def _deposit(self, loss_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Trainer-driven mode: the trainer will call ``.backward()`` on the summed losses -- the gradient is in ``param.grad`` already."""
+        flat = self._model.field.flat
+        return {k: _DepositedGrad.apply(v, flat) for k, v in loss_dict.items()}
+
+    def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None):
+        """One micro-step on caller-provided packed samples (bench.py, parity tests): forward, losses, backward and -- on the last
+        micro-step of the accumulation window -- the optimizer step.  Needs ``from_packed_samples`` (an own optimizer)."""
+        if self.trainer_driven:
+            raise RuntimeError("train_iteration() steps the pipeline's own optimizer; a trainer-built pipeline is driven through "
+                               "get_train_loss_dict()")
+        last = self._begin_micro_step(self._micro)
+        if self._model.direct_step_supported(batch):  # straight launch sequence, no autograd graph
             outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, num_rays, batch, packed_info)
         else:
             outputs = self._model.get_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
             loss_dict = self._model.get_loss_dict(outputs, batch)
             sum(loss_dict.values()).backward()
-        self.optimizer.step()
+        self._micro = 0 if last else self._micro + 1
+        if last:
+            self.optimizer.step()
         return outputs, loss_dict
 
     # ---- the reference's pipeline surface (umhs_pipeline.py:115-150 and VanillaPipeline.get_train_loss_dict) -----------
     def get_train_loss_dict(self, step: int):
-        """One ``Trainer.train_iteration``: BEFORE callbacks (occupancy grid), next_train, forward, loss, backward, Adam (+ gradient
-        reduction), AFTER callbacks (clamp_endmembers, fused into the Adam kernel).  Returns (outputs, loss_dict, metrics_dict)."""
-        self._model.update_occupancy_grid(step)
+        """``VanillaPipeline.get_train_loss_dict``: next_train, forward, losses, metrics -> (outputs, loss_dict, metrics_dict).
+
+        Trainer-driven (built by nerfstudio's Trainer): the trainer has run the BEFORE_TRAIN_ITERATION callbacks (occupancy grid)
+        and zeroed the gradients, and will call ``backward()`` on the summed losses and step its optimizers.  The launch-sequence
+        step below has then already left the gradient in ``param.grad`` (``_DepositedGrad`` makes the trainer's backward a no-op);
+        the general autograd path returns ordinary differentiable losses.
+        Stand-alone (``from_packed_samples``): this call is the whole ``Trainer.train_iteration`` -- callbacks, backward, fused
+        Adam + clamp (+ gradient exchange) included."""
+        if not self.trainer_driven:
+            self._model.update_occupancy_grid(step)
         ray_bundle, batch = self._next_train(step)
-        self.optimizer.zero_grad(set_to_none=True)
+        last = self._begin_micro_step(step % self.gradient_accumulation_steps)
         if self._model.direct_step_supported(batch):
             sampled = torch.cuda.Event() if self.device.type == "cuda" else None
             if sampled is not None:
@@ -79,16 +184,19 @@ class UMHSPipeline(torch.nn.Module):
                 grid.pre_sync_hook = None
             if not ahead.get("done"):  # the sampler had nothing to prune (no host sync there): same work, now
                 while_gpu_busy()
-            self.optimizer.arm_fused()  # optimizer.step() follows unconditionally: the table's Adam step may ride in the backward
             outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, len(ray_bundle), batch,
                                                                            background=ahead["bg"])
             metrics_dict = self._model.get_metrics_dict(outputs, batch)
+            if self.trainer_driven:
+                loss_dict = self._deposit(loss_dict)
         else:
             outputs = self._model(ray_bundle)
             metrics_dict = self._model.get_metrics_dict(outputs, batch)
             loss_dict = self._model.get_loss_dict(outputs, batch, metrics_dict)
-            sum(loss_dict.values()).backward()
-        self.optimizer.step()
+            if not self.trainer_driven:
+                sum(loss_dict.values()).backward()
+        if last and not self.trainer_driven:
+            self.optimizer.step()
         return outputs, loss_dict, metrics_dict
 
     # ---- one-step-ahead ray batch + occupancy march -------------------------------------------------------------------
@@ -127,6 +235,25 @@ class UMHSPipeline(torch.nn.Module):
             ready.record(side)
         self._ahead = (step, ray_bundle, batch, ready)
 
+    def load_pipeline(self, loaded_state: Mapping[str, Any], step: int) -> None:
+        """umhs_pipeline.py:157-175: strip DDP's ``module.`` prefix, ``model.update_to_step(step)``, ``load_state_dict``.  Checkpoints
+        carry the reference's key names (``_model.field.mlp_base.encoder.hash_table`` ...).  Keys of modules this build does not hold
+        (the reference's lpips network, ``field.mlp_base`` of the discarded NGP parent ...) are ignored; a missing field key is an
+        error.  (The reference's debugging side effects -- printing the dict, np.save of the endmembers -- are not reproduced.)"""
+        state = _strip_module_prefix(loaded_state)
+        self._model.update_to_step(step)
+        result = self.load_state_dict(state, strict=False)
+        missing = [k for k in result.missing_keys if ".field." in k or k.startswith("field.")]
+        if missing:
+            raise RuntimeError(f"checkpoint lacks field parameters: {missing}")
+
+    def get_param_groups(self) -> Dict[str, list]:
+        """VanillaPipeline.get_param_groups: datamanager groups (none here) + the model's ``{"fields": [...]}``."""
+        return self._model.get_param_groups()
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> list:
+        return self._model.get_training_callbacks(training_callback_attributes)
+
     @torch.no_grad()
     def get_eval_loss_dict(self, step: int):
         self.eval()
@@ -148,6 +275,10 @@ class UMHSPipeline(torch.nn.Module):
         return metrics_dict, images_dict
 
 
+def _strip_module_prefix(loaded_state: Mapping[str, Any]) -> Dict[str, Any]:
+    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in loaded_state.items()}
+
+
 def _tensors_of(obj) -> list:
     """Every CUDA tensor reachable from a batch dict / RayBundle (for stream bookkeeping)."""
     if torch.is_tensor(obj):
@@ -161,5 +292,3 @@ def _tensors_of(obj) -> list:
     return []
 
 
-def make_nerfstudio_trainer_config(defaults):  # pragma: no cover - needs nerfstudio
-    raise NotImplementedError("nerfstudio TrainerConfig wiring is exercised only where nerfstudio is installed")
