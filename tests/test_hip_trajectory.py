@@ -155,7 +155,7 @@ def test_trunc_exp_clamped_backward(bias):
     assert unclamped > 100 or unclamped < 0.01  # the clamp is what this test sees
 
 
-@pytest.mark.parametrize("C,B,spec,temp", [(9, 128, True, 0.3), (4, 141, False, 0.7), (15, 192, True, 0.5)])
+@pytest.mark.parametrize("C,B,spec,temp", [(9, 128, True, 0.3), (4, 141, False, 0.7), (15, 160, True, 0.5)])
 def test_field_bwd_many_bands_many_workgroups(C, B, spec, temp):
     """The B > 32 heads backward against the oracle at N = 4,288 (>= 33 workgroup tiles and a partial last tile), d_enc and
     every parameter gradient <= 5e-5; shapes of scripts/cbox_dragon.sh (128 bands) and rgb+spectral.sh (141), and the kernels' limit."""
@@ -194,8 +194,10 @@ def test_field_bwd_many_bands_many_workgroups(C, B, spec, temp):
             else:
                 pre, idx = k.rsplit(".", 1)
                 got = layout.view(d_flat, f"{key[pre[:-2]]}.layers.{idx}.{'weight' if pre.endswith('_w') else 'bias'}")
-            assert gref is not None
-            assert_close(f"grad {k}", got, gref, 5e-5)
+            if gref is None:  # mlp_directional without the specular head: unused by the reference, written as zeros here
+                assert not spec and k.startswith("dir_") and float(got.abs().max()) == 0.0, k
+            else:
+                assert_close(f"grad {k}", got, gref, 5e-5)
 
 
 def test_positional_encoding_far_from_the_origin():

@@ -1362,6 +1362,449 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
   flush_db<WAVES>(dbB1, st, slab + sl.off_db[L_B1], sl.cols[L_B1], tid);
 }
 
+// =============================================================================================
+// One-pass backward (the default when its register / LDS budget allows, i.e. B <= 16 * OP_TBMAX): the whole field backward --
+// mlp_base, mlp_head, feature_mlp, mlp_directional, mixing -- in ONE kernel with no LDS staging and no barrier in its loop.
+//
+// The dX chain and the forward recompute are the exact fp32 MFMA chain of the kernels above.  What changed is dW = dZ^T X, the
+// contraction over samples (= over lanes in the "samples on lanes" layout).  The kernels above stage both operands through LDS
+// to transpose them ([sample][feature] rows written with ds_write_b128, read back column-wise) -- by the PMC and the
+// section ablations ~100 us of staging and ~20 us of barriers for 58 us of MFMA work at C2.  Here a tile is transposed ON THE
+// MATRIX PIPE: an fp32 value is split into two bf16 pieces (x = hi + lo + O(2^-17 x)), and one v_mfma_f32_16x16x16_bf16 of a
+// piece against an identity B operand (every lane builds its fragment from its own id) yields the "swapped" tile -- lane =
+// (feature l&15, quarter q), register r <-> sample 4q+r -- exactly, because the products are x * 1.  Two swapped tiles ARE the
+// A and B operands of dW[out][in] += sum_s dZ[s][out] X[s][in] on the bf16 MFMA (k-slot <-> sample), evaluated as
+// hi*hi + hi*lo + lo*hi with fp32 accumulation: 2^-16 relative per product, unbiased (round-to-nearest pieces), summed over
+// 262 k samples -- two orders inside the 5e-5 gradient budget, measured in tests/test_hip_parity.py::test_field_bwd.
+// The bf16 MFMA issues in half the cycles of the fp32 one for 4x its K, so transposes + dW cost ~1/4 of the fp32 dW they replace.
+// Consequences: every wave owns ALL dW tiles for its own samples (296 accumulator registers at C2 -- one wave per SIMD, the
+// accumulators in AGPRs), nothing is handed between kernels (no d_bo / d_fl / d_bo2 round trips, no saved emb / sigma_raw /
+// feature logits: the base MLP is recomputed too), and the four waves of a workgroup never wait for each other.
+// =============================================================================================
+typedef short v4s __attribute__((ext_vector_type(4)));
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+
+struct STile {  // swapped 16-feature x 16-sample tile in bf16 pieces: lane (feature c = l&15, q = l>>4), element r <-> sample 4q+r
+  v4s hi, lo;
+};
+
+__device__ __forceinline__ v4s ident_frag(int lane) {  // B operand of the transposing MFMA: I[k = 4q+u][col c] = (k == c)
+  const int c = lane & 15, q = lane >> 4;
+  v4s f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) f[u] = ((c >> 2) == q && (c & 3) == u) ? (short)0x3F80 : (short)0;
+  return f;
+}
+__device__ __forceinline__ short bf_bits(float x) { return __builtin_bit_cast(short, (__bf16)x); }  // round to nearest even
+__device__ __forceinline__ float bf_val(short h) { return __uint_as_float(((uint32_t)(uint16_t)h) << 16); }
+__device__ __forceinline__ v4s pack_hi16(const v4f& v) {  // the four values ARE bf16 numbers: keep their upper halves
+  const uint32_t a = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+  const uint32_t b = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
+  return __builtin_bit_cast(v4s, make_uint2(a, b));
+}
+
+// "samples on lanes" tile (4 registers: features 4q+r of a 16-feature tile, this lane's sample) -> swapped bf16 tile.
+// COLSUM: also adds this lane's share of the column sums (sum over its 4 samples; the 4 lane quarters are added by the reduce).
+template <bool COLSUM>
+__device__ __forceinline__ STile to_swapped(const float* __restrict__ x4, const v4s& ident, float* colsum = nullptr) {
+  v4s hi, lo;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const short h = bf_bits(x4[r]);
+    hi[r] = h, lo[r] = bf_bits(x4[r] - bf_val(h));
+  }
+  const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+  const v4f dh = MFMA_BF(hi, ident, z), dl = MFMA_BF(lo, ident, z);
+  if (COLSUM) *colsum += ((dh[0] + dh[1]) + (dh[2] + dh[3])) + ((dl[0] + dl[1]) + (dl[2] + dl[3]));
+  STile s;
+  s.hi = pack_hi16(dh), s.lo = pack_hi16(dl);
+  return s;
+}
+
+// acc[to * TI + ti] += Z[to]^T X[ti]  (three bf16 products per tile pair; the passes run over all pairs so that no MFMA waits
+// for the one before it on the same accumulator)
+template <int TO, int TI>
+__device__ __forceinline__ void dw_pairs(v4f* __restrict__ acc, const STile (&Z)[TO], const STile (&X)[TI]) {
+#pragma unroll
+  for (int to = 0; to < TO; ++to)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) acc[to * TI + ti] = MFMA_BF(Z[to].hi, X[ti].hi, acc[to * TI + ti]);
+#pragma unroll
+  for (int to = 0; to < TO; ++to)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) acc[to * TI + ti] = MFMA_BF(Z[to].hi, X[ti].lo, acc[to * TI + ti]);
+#pragma unroll
+  for (int to = 0; to < TO; ++to)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) acc[to * TI + ti] = MFMA_BF(Z[to].lo, X[ti].hi, acc[to * TI + ti]);
+}
+
+// accumulator / bias-sum slots of one wave (items of 64 lanes x 4 floats; the slab keeps this order)
+template <int TBMAX>
+struct OnePassSlots {
+  static constexpr int A_B0 = 0, A_B1 = 8, A_H0 = 12, A_H1 = 20, A_H2 = 36, A_F0 = 40, A_F1 = 48, A_F2 = 64, A_D0 = 68, A_D1 = 70,
+                       A_MX = 70 + TBMAX, NACC = 70 + 2 * TBMAX;
+  static constexpr int D_B0 = 0, D_B1 = 4, D_H0 = 5, D_H1 = 9, D_H2 = 13, D_F0 = 14, D_F1 = 18, D_F2 = 22, D_D0 = 23, D_D1 = 24,
+                       NDB = 24 + TBMAX, NDBV = (NDB + 3) / 4, NITEMS = NACC + NDBV;
+};
+constexpr int OP_CHUNK = 32;  // items per round of the end-of-launch reduction over the 4 waves (4 x 32 x 1 KiB = 128 KiB of LDS)
+
+template <bool SPEC, int TBMAX>
+__global__ __launch_bounds__(256, 1) void field_bwd_onepass_kernel(FieldIO io, PackDesc pd, TPackDesc td,
+                                                                   const float* __restrict__ image,
+                                                                   const float* __restrict__ wT_image, int wt_off,
+                                                                   float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef OnePassSlots<TBMAX> SL;
+  {
+    const int n4 = (pd.total + 3) >> 2, m4 = (td.total + 3) >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(image)[i];
+    for (int i = threadIdx.x; i < m4; i += 256)
+      reinterpret_cast<float4*>(lds + wt_off)[i] = reinterpret_cast<const float4*>(wT_image)[i];
+  }
+  __syncthreads();
+  const float* const wT = lds + wt_off;
+  constexpr int NT = 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const v4s ident = ident_frag(lane);
+  v4f acc[SL::NACC];
+  float db[SL::NDBV * 4];
+#pragma unroll
+  for (int i = 0; i < SL::NACC; ++i) acc[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < SL::NDBV * 4; ++i) db[i] = 0.0f;
+  const int C = io.C, B = io.B, TB = io.TB;
+  const int64_t ntiles = (io.n + 63) / 64;
+  // One wave per SIMD: nothing else hides a global load, so every per-sample input of a tile is requested one tile ahead.
+  struct TileIn {
+    float2 e[4];
+    float w[3], d[3], dsig, sel, demb[4], dsp[TBMAX][4];
+  };
+  auto fetch = [&](int64_t tile, TileIn& in) {
+    int64_t n = tile * 64 + wave * 16 + j;
+    const bool ok = n < io.n;
+    if (!ok) n = io.n - 1;
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv) in.e[lv] = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) in.w[s] = io.wpos[3 * n + s];
+    if (SPEC) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) in.d[s] = io.dirs[3 * n + s];
+    }
+    in.sel = io.sel[n];
+    in.dsig = ok ? io.d_sigma[n] : 0.0f;  // rows past the end carry zero upstream gradients: every dZ of theirs is then zero
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = 4 * q + r - 1;
+      in.demb[r] = (io.d_emb && ok && e >= 0) ? io.d_emb[n * 15 + e] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < TBMAX; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int b = 16 * t + 4 * q + r;
+        in.dsp[t][r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
+      }
+  };
+  TileIn cur, nxt;
+  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t n = tile * 64 + wave * 16 + j;
+    const bool ok = n < io.n;
+    if (!ok) n = io.n - 1;
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
+    // =================== forward recompute: mlp_base, encodings, both head MLPs, directional hidden layer ========
+    float encf[NT][8];
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv) encf[0][2 * lv] = cur.e[lv].x, encf[0][2 * lv + 1] = cur.e[lv].y;
+    v4f t4[NT][4];
+    float h[NT][16];
+    gemm_pack<4, 8, NT, 2>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+    relu_to<4, NT>(h, t4);
+    v4f bo4[NT][1];
+    gemm_pack<1, 16, NT, 2>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+    float in27[NT][7], dir28[NT][7];
+    {
+      float pe[3];
+      pe_slots(pe, cur.w[0], cur.w[1], cur.w[2], q);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) in27[0][3 + r] = bo4[0][0][r];  // slot 0 (sigma_raw) meets a zero weight column
+      if (SPEC) {
+        float sh[4];
+        sh_slots(sh, cur.d[0], cur.d[1], cur.d[2], q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
+      }
+    }
+    float a1h[NT][16], a2h[NT][16], a1f[NT][16], a2f[NT][16];
+    v4f hd4[NT][1], fl4[NT][1];
+    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+    relu_to<4, NT>(a1h, t4);
+    gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+    relu_to<4, NT>(a2h, t4);
+    gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+    relu_to<4, NT>(a1f, t4);
+    gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+    relu_to<4, NT>(a2f, t4);
+    gemm_pack<1, 16, NT, 2>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    HeadState<NT> hs;
+    head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
+    float hdir[NT][4];
+    if (SPEC) {
+      v4f d4[NT][1];
+      gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+      relu_to<1, NT>(hdir, d4);
+    }
+    // swapped forms of the layer inputs that several dW products share.  Input layers keep their operand order, so a swapped
+    // tile's column c = 4q'+u is whatever lane quarter q' holds in slot u (onepass_col() maps it back in the slab reduce):
+    //   x27S[0]: positional encoding 3q'+u (u < 3), [1]: base-MLP output slot c;  dirS[0]: SH c, [1]: positional encoding again
+    STile x27S[2], dirS[2], hdirS[1], mS[1];
+    {
+      const float pe4[4] = {in27[0][0], in27[0][1], in27[0][2], 0.0f};
+      x27S[0] = to_swapped<false>(pe4, ident);
+      x27S[1] = to_swapped<false>(&in27[0][3], ident);
+      mS[0] = to_swapped<false>(hs.m[0], ident);
+      if (SPEC) {
+        dirS[0] = to_swapped<false>(&dir28[0][0], ident);
+        dirS[1] = x27S[0];
+        hdirS[0] = to_swapped<false>(hdir[0], ident);
+      }
+    }
+    // =================== band tiles: mixing and the specular tail ==================================================
+    v4f dm4[NT][1], dhd4[NT][1];
+    dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    float ds1 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TBMAX; ++t) {
+      if (t < TB) {
+        float dsp[NT][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsp[0][r] = cur.dsp[t][r];
+        gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+        STile dspS[1];
+        dspS[0] = to_swapped<false>(dsp[0], ident);
+        dw_pairs<1, 1>(&acc[SL::A_MX + t], dspS, mS);  // dE^T[b][c] += sum_n d_spectral[n][b] m[n][c]
+        if (SPEC) {
+          v4f sc[NT][1];
+          gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+          float dzd[NT][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sp = sigmoidf_(sc[0][0][r]);
+            ds1 += dsp[0][r] * sp;
+            dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
+          }
+          gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
+          STile dzdS[1];
+          dzdS[0] = to_swapped<true>(dzd[0], ident, &db[SL::D_D1 + t]);
+          dw_pairs<1, 1>(&acc[SL::A_D1 + t], dzdS, hdirS);
+        }
+      }
+    }
+    ds1 = xq_sum(ds1);
+    // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
+    float dhs[NT][4], dfl[NT][4];
+    {
+      const float inv_t = 1.0f / io.temperature;
+      float da[4], dot = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dmr = dm4[0][0][r];
+        const float dsg = dmr * hs.ab[0][r];
+        dhs[0][r] = dsg * hs.sg[0][r] * (1.0f - hs.sg[0][r]);
+        da[r] = (4 * q + r < C) ? dmr * hs.sg[0][r] : 0.0f;
+        dot += hs.ab[0][r] * da[r];
+      }
+      dot = xq_sum(dot);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * q + r;
+        float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) * inv_t : 0.0f;
+        if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
+        dfl[0][r] = g;
+        if (c >= C) dhs[0][r] = 0.0f;
+      }
+    }
+    if (SPEC) {  // mlp_directional hidden layer
+      float dz[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
+      STile dzS[1];
+      dzS[0] = to_swapped<true>(dz, ident, &db[SL::D_D0]);
+      dw_pairs<1, 2>(&acc[SL::A_D0], dzS, dirS);
+    }
+    v4f dbo4[NT][1];
+    dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    // one 27->64->64->out MLP (head or feature): dW of its three layers, dX down to the base-MLP slots
+    auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f* __restrict__ acc2,
+                        v4f* __restrict__ acc1, v4f* __restrict__ acc0, float* __restrict__ db2, float* __restrict__ db1,
+                        float* __restrict__ db0, int t2, int t1, int t0) __attribute__((always_inline)) {
+      STile zS[4], xS[4];
+      STile z1[1];
+      z1[0] = to_swapped<true>(dzo[0], ident, db2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xS[t] = to_swapped<false>(&a2[0][4 * t], ident);
+      dw_pairs<1, 4>(acc2, z1, xS);
+      v4f g4[NT][4];
+      gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
+      float dz1[NT][16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dz1[0][4 * t], ident, db1 + t);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xS[t] = to_swapped<false>(&a1[0][4 * t], ident);
+      dw_pairs<4, 4>(acc1, zS, xS);
+      gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
+      float dz0[NT][16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dz0[0][4 * t], ident, db0 + t);
+      dw_pairs<4, 2>(acc0, zS, x27S);
+      gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
+    };
+    mlp3_bwd(dhs, a2h, a1h, &acc[SL::A_H2], &acc[SL::A_H1], &acc[SL::A_H0], &db[SL::D_H2], &db[SL::D_H1], &db[SL::D_H0], T_H2, T_H1,
+             T_H0);
+    mlp3_bwd(dfl, a2f, a1f, &acc[SL::A_F2], &acc[SL::A_F1], &acc[SL::A_F0], &db[SL::D_F2], &db[SL::D_F1], &db[SL::D_F0], T_F2, T_F1,
+             T_F0);
+    // =================== mlp_base ======================================================================================
+    float dzb1[NT][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dzb1[0][r] = ok ? dbo4[0][0][r] + cur.demb[r] : 0.0f;
+    if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
+      dzb1[0][0] = cur.dsig * cur.sel * expf(fminf(fmaxf(bo4[0][0][0], -15.0f), 15.0f));
+    }
+    {
+      STile z1[1], hS[4];
+      z1[0] = to_swapped<true>(dzb1[0], ident, &db[SL::D_B1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) hS[t] = to_swapped<false>(&h[0][4 * t], ident);
+      dw_pairs<1, 4>(&acc[SL::A_B1], z1, hS);
+    }
+    v4f g4[NT][4];
+    gemm_pack<4, 4, NT, 1>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
+    float dzb0[NT][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+    {
+      STile zS[4], eS[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dzb0[0][4 * t], ident, &db[SL::D_B0 + t]);
+      eS[0] = to_swapped<false>(&encf[0][0], ident);  // column c = 4q'+u <-> hash feature 8q'+u
+      eS[1] = to_swapped<false>(&encf[0][4], ident);  //                    <-> hash feature 8q'+4+u
+      dw_pairs<4, 2>(&acc[SL::A_B0], zS, eS);
+    }
+    v4f de4[NT][2];
+    gemm_pack<2, 16, NT, 1>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
+    if (ok && io.d_enc) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int lv = 8 * t + 2 * q + rr;  // feature e = 16t+4q+r -> level e>>1, component e&1
+          *reinterpret_cast<float2*>(io.d_enc + n * io.sn + (int64_t)lv * io.sl) = make_float2(de4[0][t][2 * rr], de4[0][t][2 * rr + 1]);
+        }
+    }
+    cur = nxt;
+  }
+  // =================== sum the four waves' accumulators through LDS (the pack images are dead), one slab per workgroup ======
+  float* const slab = slabs + (size_t)blockIdx.x * (SL::NITEMS * 256);
+#pragma unroll
+  for (int c0 = 0; c0 < SL::NITEMS; c0 += OP_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OP_CHUNK; ++i) {
+      const int it = c0 + i;
+      if (it < SL::NITEMS) {
+        v4f v;
+        if (it < SL::NACC) {
+          v = acc[it < SL::NACC ? it : 0];
+        } else {
+          const int k = 4 * (it - SL::NACC);
+          v = v4f{db[k >= 0 ? k : 0], db[k >= 0 ? k + 1 : 0], db[k >= 0 ? k + 2 : 0], db[k >= 0 ? k + 3 : 0]};
+        }
+        *reinterpret_cast<v4f*>(lds + ((wave * OP_CHUNK + i) * 64 + lane) * 4) = v;
+      }
+    }
+    __syncthreads();
+    const int cnt = (SL::NITEMS - c0 < OP_CHUNK ? SL::NITEMS - c0 : OP_CHUNK) * 64;
+    for (int e = tid; e < cnt; e += 256) {
+      v4f s = *reinterpret_cast<const v4f*>(lds + e * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const v4f*>(lds + (w * OP_CHUNK * 64 + e) * 4);
+      *reinterpret_cast<v4f*>(slab + (c0 * 64 + e) * 4) = s;
+    }
+  }
+}
+
+// slab -> gradient tensors of the one-pass kernel.  item -> (layer, to, ti); a swapped input tile's column c of layer kind
+// `kind` is reference input column onepass_col(kind, ti, c) (or -1: a padding slot).
+struct OnePassMap {
+  int nacc, ndb, nitems;
+  short layer[128], to[128], ti[128];  // per accumulator item
+  short db_layer[64], db_tile[64];     // per bias-sum tile
+};
+__device__ __forceinline__ int onepass_col(int kind, int ti, int c) {
+  const int qq = c >> 2, u = c & 3;
+  switch (kind) {
+    case IN_ENC: return 8 * qq + 4 * ti + u;
+    case IN_27: return ti == 0 ? (u < 3 ? 3 * qq + u : -1) : (c >= 1 ? 12 + c - 1 : -1);
+    case IN_DIR28: return ti == 0 ? c : (u < 3 ? 16 + 3 * qq + u : -1);
+    default: return 16 * ti + c;  // IN_HID64 / IN_HID16 / IN_MIX: natural order
+  }
+}
+
+__global__ __launch_bounds__(256) void field_reduce_onepass_kernel(const float* __restrict__ slabs, int nslabs, OnePassMap mp,
+                                                                   PackDesc pd, GradPtrs gp) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int nw = mp.nacc * 256, nb = mp.ndb * 16;
+  const size_t stride = (size_t)mp.nitems * 256;
+  if (e < nw) {
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.0f;
+    int w = 0;
+    for (; w + 7 < nslabs; w += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += slabs[(size_t)(w + k) * stride + e];
+    }
+    for (; w < nslabs; ++w) a[0] += slabs[(size_t)w * stride + e];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    const int item = e >> 8, rel = e & 255, r = rel & 3, ln = rel >> 2;
+    const int l = mp.layer[item];
+    if (l < 0) return;
+    const LayerDesc& L = pd.L[l];
+    const int out = 16 * mp.to[item] + 4 * (ln >> 4) + r;
+    if (l == L_MX) {  // dE^T[b][c]
+      const int cls = ln & 15;
+      if (out < L.OUT && cls < L.IN && gp.W[l]) gp.W[l][(size_t)cls * L.OUT + out] = s;
+      return;
+    }
+    const int in = onepass_col(L.kind, mp.ti[item], ln & 15);
+    if (out < L.OUT && in >= 0 && in < L.IN && gp.W[l]) gp.W[l][(size_t)out * L.IN + in] = s;
+  } else if (e < nw + nb) {
+    const int k = e - nw, T = k >> 4, c = k & 15;  // bias tile T (slot in db[]), column c: sum over slabs and the 4 lane quarters
+    const int l = mp.db_layer[T];
+    if (l < 0) return;
+    const size_t off = (size_t)(mp.nacc + (T >> 2)) * 256 + (T & 3);
+    float s = 0.0f;
+    for (int w = 0; w < nslabs; ++w) {
+      const float* p = slabs + (size_t)w * stride + off;
+      s += (p[(c)*4] + p[(16 + c) * 4]) + (p[(32 + c) * 4] + p[(48 + c) * 4]);
+    }
+    const int o = 16 * mp.db_tile[T] + c;
+    if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
+  }
+}
+
 // ---- sum the per-workgroup slabs and scatter into the reference-layout gradient tensors ------------
 struct GradPtrs {
   float* W[NLAYERS];

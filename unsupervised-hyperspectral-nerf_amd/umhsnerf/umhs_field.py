@@ -124,8 +124,7 @@ class UMHSField(nn.Module):
             for k, (_, shp) in self.layout.entries.items():
                 src = state_dict.get(prefix + k)
                 if src is None:
-                    if strict:
-                        missing_keys.append(prefix + k)
+                    missing_keys.append(prefix + k)  # reported even when not strict (load_state_dict's return value lists them)
                     continue
                 if tuple(src.shape) != tuple(shp):
                     error_msgs.append(f"size mismatch for {prefix + k}: checkpoint {tuple(src.shape)} vs field {tuple(shp)}")
@@ -135,12 +134,23 @@ class UMHSField(nn.Module):
                 self.aabb.copy_(state_dict[prefix + "aabb"].to(self.aabb.device))
                 self._aabb_host = tuple(float(v) for v in self.aabb.flatten().tolist())
                 self._spec_cache = None  # (a dict without "aabb" keeps the constructed box: parameter-only dicts load too)
-        if strict:
+        if True:
             mine = {prefix + k for k in self.layout.entries} | {prefix + "aabb"}
             kids = tuple(prefix + name + "." for name, m in self._modules.items() if m is not None)
             for key in state_dict:
                 if key.startswith(prefix) and key not in mine and not key.startswith(kids):
                     unexpected_keys.append(key)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Called on the field directly, a dict of just the reference-named parameters loads too (``strict`` then concerns those
+        names only: buffers -- ``aabb``, ``converter.transform_matrix`` -- keep their constructed values when absent)."""
+        res = super().load_state_dict(state_dict, strict=False)
+        if strict:
+            missing = [k for k in res.missing_keys if k in self.layout.entries]  # (prefix is empty here)
+            if missing or res.unexpected_keys:
+                raise RuntimeError(f"Error(s) in loading state_dict for UMHSField: missing {missing}, unexpected {list(res.unexpected_keys)}; "
+                                   f"expected {_REF_KEYS_DOC}")
+        return res
 
     def _spec(self) -> ops.FieldSpec:
         if self._sparse_end and os.environ.get("UMHS_SPARSE_ADAM", "1") != "0":
