@@ -31,8 +31,33 @@ import torch
 import torch.distributed as dist
 
 C2 = dict(R=4096, S=64, B=31, C=6, temperature=0.4, pred_specular=True, method="rgb+spectral")
+# the other single-GPU shapes of BASELINE.json (scripts/cbox_dragon.sh:3-9, pinecone.sh:5-12 per GPU, rgb+spectral.sh:6-14); C2 is the
+# configuration the headline metric is quoted on and the default, the others are selected with --config
+CONFIGS = {
+    "C2": dict(C2, workload="C2 hotdog 31-band rgb+spectral train step (fwd+loss+bwd+Adam)"),
+    "C3": dict(R=8192, S=64, B=128, C=9, temperature=0.3, pred_specular=True, method="rgb+spectral",
+               workload="C3 cbox_dragon 128-band rgb+spectral train step (fwd+loss+bwd+Adam)"),
+    "C4": dict(R=8192, S=64, B=31, C=4, temperature=0.5, pred_specular=True, method="rgb+spectral",
+               workload="C4 pinecone 31-band, 8192 rays per GPU (65536 over 8 GPUs) rgb+spectral train step"),
+    "C5": dict(R=8192, S=64, B=141, C=4, temperature=0.7, pred_specular=False, method="rgb+spectral",
+               workload="C5 141-band joint rgb+spectral train step, 4 endmembers, no specular head"),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-ATOMIC_PEAK_GBS = 1300.0  # ibid. "Global float atomics": chip-wide ~1.3 TB/s of added bytes
+MFMA_F32_PEAK_TF = 157.3  # ibid.: dense fp32-input MFMA (v_mfma_f32_16x16x4_f32)
+
+
+def csrc_hash() -> str:
+    """Content hash of the kernel sources: profiles/*/pmc_summary.json records the hash it was measured on, and counters from a
+    different build are not reported."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def synthetic_batch(R, S, B, seed, device):
@@ -105,7 +130,7 @@ def cpu_baseline(cfg, seed, budget_s=15.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))  # a 1-GPU box owns a 16-core share of the host; more threads only oversubscribe
     torch.set_num_threads(cores)
-    R = 1024  # bounded sample: 1024 of the 4096 rays (x64 samples), same distributions
+    R = cfg["R"] if cfg["B"] <= 32 else 1024  # the full batch where a step fits the budget (~1.6 s at C2), else a 1024-ray sample
     p = T.FieldParams(cfg["C"], cfg["B"], cfg["pred_specular"], cfg["method"], table_scale=0.5, seed=seed)
     with torch.no_grad():
         p.base_b[1][0] += 1.5
@@ -127,7 +152,7 @@ def cpu_baseline(cfg, seed, budget_s=15.0):
     print(f"[bench] cpu_baseline: {cores} threads, {R} rays x {cfg['S']} samples ...", file=sys.stderr, flush=True)
     step(1)  # warm-up
     t0, n = time.perf_counter(), 0
-    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 8):
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 10):
         n += 1
         step(n + 1)
         print(f"[bench] cpu_baseline step {n}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
@@ -141,6 +166,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,6 +178,7 @@ def main():
     local = local % max(ndev, 1)  # (rehearsals with more ranks than GPUs share a device; the driver runs one rank per GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    backend = None
     if world > 1:
         backend = os.environ.get("UMHS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for 1-GPU rehearsals
         if backend == "nccl":
@@ -160,12 +187,12 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from umhsnerf import ops
+    from umhsnerf import ops, parallel
     from umhsnerf._ns_compat import packed_ray_samples
     from umhsnerf.umhs_model import UMHSConfig
     from umhsnerf.umhs_pipeline import UMHSPipeline
 
-    cfg = C2
+    cfg = CONFIGS[args.config]
     R, S, B, Cn = cfg["R"], cfg["S"], cfg["B"], cfg["C"]
     N = R * S
     bands = list(np.linspace(400, 700, B))
@@ -187,9 +214,9 @@ def main():
            "adam_step_rows", "adam_step_rows_range")  # (one GPU: the dense hash levels' Adam step rides in hashgrid_bwd_apply)
     for name in OPS:
         timer.wrap(name)
-    # Inside the timed region only the dominant operator carries HIP events (2 per step): an event is a barrier packet on the
-    # queue, and a pair around every one of the ~12 operators costs ~12 % of the step.  The full per-operator table comes from
-    # a separate, untimed pass over the same step.
+    # Inside the timed region only the dominant operator carries HIP events (2 per step) plus one event per step boundary (for the
+    # median): an event is a barrier packet on the queue, and a pair around every one of the ~12 operators costs ~12 % of the
+    # step.  The full per-operator table comes from a separate, untimed pass over the same step.
     timer.only = {"field_bwd"}
 
     def step():
@@ -198,21 +225,27 @@ def main():
     for _ in range(args.warmup):
         step()
     timer.enabled = True
+    parallel.STATS.update(bytes=0, messages=0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         outputs, loss_dict = step()
+        marks[i + 1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    exchanged = dict(parallel.STATS)
+    per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]  # GPU-side step boundaries on the launch stream
+    tmax = torch.tensor([dt, float(np.median(per_step_ms))], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, median_ms = float(tmax[0].item()), float(tmax[1].item())
     dom_live = timer.summary()
     timer.records.clear()
     timer.only, timer.enabled = None, True  # untimed breakdown pass (all ranks: the step contains the collectives)
@@ -220,6 +253,27 @@ def main():
         step()
     torch.cuda.synchronize()
     timer.enabled = False
+    dist_info = None
+    if world > 1:  # how much of the step is exchange that did NOT hide under the backward: the same step with the collectives off
+        parallel.EXCHANGE_DISABLED = True
+        for _ in range(3):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(min(args.steps, 20)):
+            step()
+        torch.cuda.synchronize()
+        t_noex = torch.tensor([(time.perf_counter() - t1) / min(args.steps, 20)], device=device, dtype=torch.float64)
+        parallel.EXCHANGE_DISABLED = False
+        dist.all_reduce(t_noex, op=dist.ReduceOp.MAX)
+        sink = pipe.model.field._grad_sink
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": ndev,
+                     "mb_exchanged_per_step": round(exchanged["bytes"] / args.steps / 1e6, 2),
+                     "messages_per_step": round(exchanged["messages"] / args.steps, 2),
+                     "level_groups": getattr(sink, "level_groups", None), "async_reduce": getattr(sink, "async_reduce", None),
+                     "ms_per_step_without_exchange": round(float(t_noex.item()) * 1e3, 4),
+                     "exposed_exchange_ms": round(dt / args.steps * 1e3 - float(t_noex.item()) * 1e3, 4)}
 
     if rank == 0:
         ksum = timer.summary()
@@ -227,56 +281,72 @@ def main():
         ms_step = dt / args.steps * 1e3
         psnr = float(pipe.model.psnr(outputs["spectral"].detach(), b["gt_spectral"]))
         loss_dict = {k: v.detach() for k, v in loss_dict.items()}
-        print(f"[bench] gpu: {ms_step:.3f} ms/step, {R * world * args.steps / dt:.0f} rays/s", file=sys.stderr, flush=True)
-        # algorithmic bytes per launch (1024 B/sample of hash-grid gather resp. gradient scatter,
-        # + the level-major feature rows (128 B) and positions (12 B) each kernel streams)
-        alg = {
-            "hashgrid_bwd": N * (1024 + 128 + 12),
-            "hashgrid_bwd_apply": N * (1024 + 128 + 12),
-            "hashgrid_fwd": N * (1024 + 128 + 12),
-            "adam_step": pipe.model.field.flat.numel() * 28,
-        }
+        print(f"[bench] gpu: {ms_step:.3f} ms/step (median {median_ms:.3f}), {R * world * args.steps / dt:.0f} rays/s", file=sys.stderr, flush=True)
         kern = {k: round(v[0], 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][0])}
         dom = next(iter(kern))
-        # HBM traffic / MFMA-busy of the dominant operator from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/r01/pmc_summary.json; counters cannot be read from inside the process)
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")) as f:
-                pmc = json.load(f)["kernels"]
-        except Exception:
-            pass
-        op_kernels = {"field_bwd": ("field_bwd_part_kernel", "field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce_kernel"),
+        # algorithmic work per launch: hash gather / scatter 1024 B per sample + the level-major feature rows (128 B) and
+        # positions (12 B); field MLPs 2 x MAC per sample (forward), backward = dX + dW = 2 x forward; compositing and the optimizer
+        # by the bytes they must move once
+        spec = cfg["pred_specular"]
+        mac = 3072 + 2 * (1728 + 4096) + 64 * Cn + 64 * (Cn + (1 if spec else 0)) + ((448 + 16 * B) if spec else 0) + Cn * B + 256
+        nstream = (3 * B if spec else B) + Cn
+        alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12), "hashgrid_bwd_apply": N * (1024 + 128 + 12),
+                     "composite_fwd": N * (nstream + 4) * 4, "composite_bwd": N * (2 * B + 5) * 4,
+                     "adam_step": pipe.model.field.flat.numel() * 28}
+        alg_flops = {"field_fwd": 2.0 * mac * N, "field_bwd": 4.0 * mac * N}
+        # HBM traffic / MFMA-busy from the committed rocprofv3 --pmc passes of this same command -- only when they were taken on
+        # THIS build of the kernels (the summary records the source hash); counters cannot be read from inside the process
+        pmc, pmc_src = {}, None
+        for rd in ("r02", "r01"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rd, "pmc_summary.json")) as f:
+                    js = json.load(f)
+                if js.get("csrc_sha") == csrc_hash() and js.get("config", "C2") == args.config:
+                    pmc, pmc_src = js["kernels"], f"profiles/{rd}/pmc_summary.json"
+                    break
+            except Exception:
+                pass
+        op_kernels = {"field_bwd": ("field_bwd_part_kernel", "field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce", "field_bwd_tf_kernel"),
                       "field_fwd": ("field_fwd_kernel", "field_pack_fwd"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
                       "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"),
-                      "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel"), "adam_step": ("adam_kernel",)}
-        traffic = sum(v["hbm_traffic_bytes"] for k, v in pmc.items() if any(k.startswith(p_) for p_ in op_kernels.get(dom, ()))) or None
-        busy = [v["mfma_util"] for k, v in pmc.items() if "mfma_util" in v and
-                k.startswith(("field_bwd_part_kernel<0", "field_bwd_heads") if dom == "field_bwd" else "field_fwd_kernel")]
-        roof = None
-        if dom in alg:
-            ach = alg[dom] / (ksum[dom][0] * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=traffic, avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1])
-        else:  # fp32-input MFMA (v_mfma_f32_16x16x4_f32), dense peak 157.3 TFLOP/s; algorithmic FLOPs per sample: SURVEY 8d
-            fwd_flop = 33.9e3
-            flops = {"field_fwd": fwd_flop * N, "field_bwd": 2 * fwd_flop * N}.get(dom)  # backward = dX + dW = 2x forward
-            if flops:
-                ach = flops / (ksum[dom][0] * 1e-3) / 1e12
-                roof = dict(bound="mfma", kernel=dom + " (two heads kernels + base kernel + slab reduce)" if dom == "field_bwd" else dom,
-                            achieved=round(ach, 2), peak=157.3, unit="TFLOP/s", frac=round(ach / 157.3, 4), traffic=traffic,
-                            avg_ms=round(ksum[dom][0], 4), launches=ksum[dom][1],
-                            mfma_busy_frac_pmc=(busy[0] if busy else None),
-                            note="frac = algorithmic FLOPs / time / peak; mfma_busy_frac_pmc = SQ_VALU_MFMA_BUSY_CYCLES share incl. recompute and tile padding")
+                      "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel"), "adam_step": ("adam_kernel",),
+                      "composite_fwd": ("composite_fwd_kernel",), "composite_bwd": ("composite_bwd_kernel",)}
+
+        def roof_of(op):
+            ms, launches = ksum[op]
+            traffic = sum(v["hbm_traffic_bytes"] for k, v in pmc.items() if "hbm_traffic_bytes" in v and any(k.startswith(p_) for p_ in op_kernels.get(op, ()))) or None
+            if op in alg_bytes:
+                ach = alg_bytes[op] / (ms * 1e-3) / 1e9
+                return dict(kernel=op, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                            traffic=traffic, avg_ms=round(ms, 4), launches=launches)
+            if op in alg_flops:
+                ach = alg_flops[op] / (ms * 1e-3) / 1e12
+                busy = [v["mfma_util"] for k, v in pmc.items() if "mfma_util" in v and any(k.startswith(p_) for p_ in op_kernels[op])]
+                return dict(kernel=op, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4),
+                            traffic=traffic, avg_ms=round(ms, 4), launches=launches, mfma_busy_frac_pmc=(max(busy) if busy else None))
+            return None
+
+        rooflines = [r for r in (roof_of(op) for op in kern) if r is not None]
+        roof = next((r for r in rooflines if r["kernel"] == dom), rooflines[0] if rooflines else None)
+        if roof is not None:
+            roof = dict(roof, pmc_source=pmc_src,
+                        note="dominant operator, timed with HIP events inside the timed region; achieved = algorithmic bytes or FLOPs (SURVEY 8d) "
+                             "/ time; traffic / mfma_busy_frac_pmc only when profiles/*/pmc_summary.json was taken on this build")
         line = {
-            "metric": "train rays/sec (hotdog-shaped 31-band, C2)", "value": round(R * world * args.steps / dt, 1), "unit": "rays/s",
+            "metric": f"train rays/sec (hotdog-shaped 31-band, C2)" if args.config == "C2" else f"train rays/sec ({args.config})",
+            "value": round(R * world * args.steps / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "ms_per_step_median": round(median_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 hotdog 31-band rgb+spectral train step (fwd+loss+bwd+Adam)", "rays_per_gpu": R, "samples_per_ray": S,
+            "config": {"workload": cfg["workload"], "rays_per_gpu": R, "samples_per_ray": S,
                        "bands": B, "endmembers": Cn, "global_rays": R * world, "hash_table": "16x2^19x2 f32", "parallelism": f"dp{world}"},
-            "spectral_psnr_db": round(psnr, 3), "loss": {k: round(float(v), 6) for k, v in loss_dict.items()},
-            "kernels_ms": kern, "roofline": roof,
+            "sanity": {"loss": {k: round(float(v), 6) for k, v in loss_dict.items()},
+                       "spectral_psnr_db_vs_uniform_random_gt": round(psnr, 3),
+                       "note": "the synthetic ground truth is uniform noise: these only show the step is numerically alive, not image quality"},
+            "kernels_ms": kern, "roofline": roof, "rooflines": rooflines, "csrc_sha": csrc_hash(),
         }
+        if dist_info is not None:
+            line["dist"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, seed=42)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)

@@ -1,4 +1,5 @@
-"""Helper launched by test_hip_distributed.py under torch.distributed.run (2 ranks, gloo, one shared GPU).
+"""Helper launched by test_hip_distributed.py under torch.distributed.run: 2 ranks over gloo sharing one GPU, or -- with
+UMHS_CHECK_BACKEND=nccl on a box with >= 2 GPUs -- one device per rank over RCCL.
 
 Each rank draws its own rays; the gradient that reaches Adam must be bit-identical whether the flat gradient is all-reduced
 per finished segment during the backward (FlatGradSink, the default) or in one piece afterwards, and a short training
@@ -23,9 +24,15 @@ def main():
     from umhsnerf.umhs_pipeline import UMHSPipeline
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    device = torch.device("cuda", 0)
-    dist.init_process_group("gloo")
+    backend = os.environ.get("UMHS_CHECK_BACKEND", "gloo")
+    dev_index = rank if backend == "nccl" else 0  # RCCL needs one device per rank; gloo ranks share the GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group("gloo")
+    flag_dev = device if backend == "nccl" else "cpu"
     R, S, B, Cn = 256, 32, 31, 6
     bands = list(np.linspace(400, 700, B))
     b = synthetic_batch(R, S, B, seed=7 + rank, device=device)
@@ -36,7 +43,8 @@ def main():
         torch.manual_seed(11)  # the training background colour is random (umhs_model.py:466-470 in the reference)
         torch.cuda.manual_seed(11)
         mc = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, per_band_outputs=True)
-        pipe = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=0, seed=3)
+        pipe = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=dev_index,
+                                                seed=3)
         trained_like_init(pipe.model.field, seed=3)
         dist.broadcast(pipe.model.field.flat.data, src=0)
         with torch.no_grad():
@@ -74,10 +82,27 @@ def main():
     other = p1.clone()
     dist.broadcast(other, src=0)
     ok = ok and torch.equal(other, p1)  # ranks stay in lock step
-    flag = torch.tensor([1 if ok else 0])
+    # an accumulation window (2 micro-steps, exchange deferred to the second) leaves both ranks with the same parameters as well
+    torch.manual_seed(11)
+    torch.cuda.manual_seed(11)
+    mc = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, per_band_outputs=True)
+    acc = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=dev_index, seed=3,
+                                           gradient_accumulation_steps=2)
+    trained_like_init(acc.model.field, seed=3)
+    dist.broadcast(acc.model.field.flat.data, src=0)
+    with torch.no_grad():
+        batch = {"image": acc.model.converter(b["gt_spectral"]), "hs_image": b["gt_spectral"]}
+    before = acc.model.field.flat.detach().clone()
+    for _ in range(4):
+        acc.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
+    pa = acc.model.field.flat.detach().clone()
+    other = pa.clone()
+    dist.broadcast(other, src=0)
+    ok = ok and torch.equal(other, pa) and not torch.equal(pa, before)
+    flag = torch.tensor([1 if ok else 0], device=flag_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print("ASYNC_REDUCE_CHECK", "OK" if int(flag) == 1 else "MISMATCH",
+        print("ASYNC_REDUCE_CHECK", "OK" if int(flag) == 1 else "MISMATCH", backend, dist.get_backend(),
               float((g1 - g0).abs().max()), float((p1 - p0).abs().max()), flush=True)
     dist.destroy_process_group()
     sys.exit(0 if int(flag) == 1 else 1)

@@ -1,5 +1,6 @@
-"""N>1 flow on the GPU box: 2 ranks sharing the one GPU, gloo as the transport (RCCL needs one device per rank).
-Checks the early per-segment gradient reduction (parallel.FlatGradSink) against the plain post-backward all-reduce."""
+"""N>1 flow on the GPU box: 2 ranks sharing the one GPU with gloo as the transport, and -- whenever the box has two or more
+GPUs -- 2 ranks with one device each over RCCL (backend "nccl").  Both check the early per-segment gradient reduction
+(parallel.FlatGradSink) against the plain post-backward all-reduce, bit for bit, and an accumulation window."""
 import os
 import subprocess
 import sys
@@ -48,8 +49,19 @@ def test_async_segment_reduce_is_bit_identical_to_plain_allreduce():
     touched = (gt[: ns << 19].abs().sum(-1) > 0)
     assert float(touched.sum()) > 0.95 * rows.numel()  # ...and the set is tight: random positions reach nearly all of it
 
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    _two_ranks("gloo", 29533)
+
+
+def _two_ranks(backend: str, port: int):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", UMHS_CHECK_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(HERE, "dist_async_reduce_check.py")], env=env, capture_output=True, text=True,
+                        "--master-port", str(port), os.path.join(HERE, "dist_async_reduce_check.py")], env=env, capture_output=True, text=True,
                        timeout=300)
-    assert r.returncode == 0 and "ASYNC_REDUCE_CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and f"ASYNC_REDUCE_CHECK OK {backend}" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs only on a box with >= 2 GPUs")
+def test_async_segment_reduce_over_rccl_one_device_per_rank():
+    """The same check with backend "nccl" (= RCCL on ROCm), one GPU per rank: the first place RCCL itself executes the sink's
+    per-segment async all-reduces (the 1-GPU boxes of the build pool can only run the gloo variant above)."""
+    _two_ranks("nccl", 29534)

@@ -194,8 +194,8 @@ def test_field_bwd_many_bands_many_workgroups(C, B, spec, temp):
             else:
                 pre, idx = k.rsplit(".", 1)
                 got = layout.view(d_flat, f"{key[pre[:-2]]}.layers.{idx}.{'weight' if pre.endswith('_w') else 'bias'}")
-            if gref is None:  # mlp_directional without the specular head: unused by the reference, written as zeros here
-                assert not spec and k.startswith("dir_") and float(got.abs().max()) == 0.0, k
+            if gref is None:  # mlp_directional without the specular head: unused by the reference (no gradient), left alone here
+                assert not spec and k.startswith("dir_"), k
             else:
                 assert_close(f"grad {k}", got, gref, 5e-5)
 

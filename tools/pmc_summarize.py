@@ -5,7 +5,10 @@ SQ_WAVE_CYCLES / SQ_WAIT_* are quad-cycles summed over waves; GRBM_GUI_ACTIVE is
 import csv, glob, json, os, re, statistics, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01/pmc_summary.json"
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02/pmc_summary.json"
+config = sys.argv[3] if len(sys.argv) > 3 else "C2"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # the build the counters were taken on: bench.py reports them only for the same kernel sources
 vals = {}
 for tag in ("fetch", "write", "sq", "grbm"):
     for f in glob.glob(os.path.join(root, f"pmcb_{tag}", "**", "*counter_collection.csv"), recursive=True):
@@ -44,5 +47,5 @@ for name, c in vals.items():
     res[name] = e
 json.dump({"source": "rocprofv3 --pmc passes of tools/pmc_bench.sh over `bench.py --steps 6 --warmup 2` (C2, 1 GPU); median per launch; "
            "FETCH_SIZE doubled per MI355X_MICROARCH.md; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)",
-           "kernels": res}, open(out, "w"), indent=1)
+           "csrc_sha": csrc_hash(), "config": config, "kernels": res}, open(out, "w"), indent=1)
 print("wrote", out, len(res), "kernels")

@@ -1363,8 +1363,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
 }
 
 // =============================================================================================
-// One-pass backward (the default when its register / LDS budget allows, i.e. B <= 16 * OP_TBMAX): the whole field backward --
-// mlp_base, mlp_head, feature_mlp, mlp_directional, mixing -- in ONE kernel with no LDS staging and no barrier in its loop.
+// Transpose-free backward (the default): two kernels, no LDS staging and no barrier inside their loops.
+//   PART 0: mlp_head + mlp_directional + mixing.  Reads the forward's emb and feature logits, emits d_fl [N,16] (gradient of
+//           the feature logits) and d_bo [N,16] (its share of the gradient of the base MLP's outputs).
+//   PART 1: feature_mlp + mlp_base.  Recomputes the base MLP from the hash features (so it needs no saved emb / sigma_raw),
+//           consumes d_fl, d_bo, d_sigma, writes d_enc.
 //
 // The dX chain and the forward recompute are the exact fp32 MFMA chain of the kernels above.  What changed is dW = dZ^T X, the
 // contraction over samples (= over lanes in the "samples on lanes" layout).  The kernels above stage both operands through LDS
@@ -1375,11 +1378,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
 // (feature l&15, quarter q), register r <-> sample 4q+r -- exactly, because the products are x * 1.  Two swapped tiles ARE the
 // A and B operands of dW[out][in] += sum_s dZ[s][out] X[s][in] on the bf16 MFMA (k-slot <-> sample), evaluated as
 // hi*hi + hi*lo + lo*hi with fp32 accumulation: 2^-16 relative per product, unbiased (round-to-nearest pieces), summed over
-// 262 k samples -- two orders inside the 5e-5 gradient budget, measured in tests/test_hip_parity.py::test_field_bwd.
+// 262 k samples -- well inside the 5e-5 gradient budget (tests/test_hip_parity.py::test_field_bwd, test_hip_trajectory.py).
 // The bf16 MFMA issues in half the cycles of the fp32 one for 4x its K, so transposes + dW cost ~1/4 of the fp32 dW they replace.
-// Consequences: every wave owns ALL dW tiles for its own samples (296 accumulator registers at C2 -- one wave per SIMD, the
-// accumulators in AGPRs), nothing is handed between kernels (no d_bo / d_fl / d_bo2 round trips, no saved emb / sigma_raw /
-// feature logits: the base MLP is recomputed too), and the four waves of a workgroup never wait for each other.
+// Consequence: every wave owns ALL dW tiles of its part for its own samples (148 / 174 accumulator registers at C2, 238 in
+// part 0 at 192 bands) -- one wave per SIMD with the accumulators in AGPRs, four independent waves per workgroup, every weight
+// pack (forward and transposed) LDS-resident for any band count the forward supports.
 // =============================================================================================
 typedef short v4s __attribute__((ext_vector_type(4)));
 #define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
@@ -1439,73 +1442,85 @@ __device__ __forceinline__ void dw_pairs(v4f* __restrict__ acc, const STile (&Z)
     for (int ti = 0; ti < TI; ++ti) acc[to * TI + ti] = MFMA_BF(Z[to].lo, X[ti].hi, acc[to * TI + ti]);
 }
 
-// accumulator / bias-sum slots of one wave (items of 64 lanes x 4 floats; the slab keeps this order)
+// accumulator / bias-sum slots of a wave (items of 64 lanes x 4 floats; the slab keeps this order).  Part 0 owns the accumulator
+// items [0, A1) and the bias tiles [0, D1S); part 1 the rest.
 template <int TBMAX>
-struct OnePassSlots {
-  static constexpr int A_B0 = 0, A_B1 = 8, A_H0 = 12, A_H1 = 20, A_H2 = 36, A_F0 = 40, A_F1 = 48, A_F2 = 64, A_D0 = 68, A_D1 = 70,
-                       A_MX = 70 + TBMAX, NACC = 70 + 2 * TBMAX;
-  static constexpr int D_B0 = 0, D_B1 = 4, D_H0 = 5, D_H1 = 9, D_H2 = 13, D_F0 = 14, D_F1 = 18, D_F2 = 22, D_D0 = 23, D_D1 = 24,
-                       NDB = 24 + TBMAX, NDBV = (NDB + 3) / 4, NITEMS = NACC + NDBV;
+struct TfSlots {
+  static constexpr int A_H0 = 0, A_H1 = 8, A_H2 = 24, A_D0 = 28, A_D1 = 30, A_MX = 30 + TBMAX, A1 = 30 + 2 * TBMAX;
+  static constexpr int A_F0 = A1, A_F1 = A1 + 8, A_F2 = A1 + 24, A_B0 = A1 + 28, A_B1 = A1 + 36, NACC = A1 + 40;
+  static constexpr int D_H0 = 0, D_H1 = 4, D_H2 = 8, D_D0 = 9, D_D1 = 10, D1S = 4 * ((10 + TBMAX + 3) / 4);
+  static constexpr int D_F0 = D1S, D_F1 = D1S + 4, D_F2 = D1S + 8, D_B0 = D1S + 9, D_B1 = D1S + 13, NDB = 4 * ((D1S + 14 + 3) / 4);
+  static constexpr int NITEMS = NACC + NDB / 4;
+  // part p's accumulator items [acc0(p), acc1(p)) and bias v4f items [dbv0(p), dbv1(p)) (absolute item = NACC + dbv)
+  static constexpr int acc0(int p) { return p == 0 ? 0 : A1; }
+  static constexpr int acc1(int p) { return p == 0 ? A1 : NACC; }
+  static constexpr int dbv0(int p) { return p == 0 ? 0 : D1S / 4; }
+  static constexpr int dbv1(int p) { return p == 0 ? D1S / 4 : NDB / 4; }
 };
-constexpr int OP_CHUNK = 32;  // items per round of the end-of-launch reduction over the 4 waves (4 x 32 x 1 KiB = 128 KiB of LDS)
+constexpr int TF_CHUNK = 32;  // items per round of the end-of-launch reduction over the 4 waves (4 x 32 x 1 KiB = 128 KiB of LDS)
 
-template <bool SPEC, int TBMAX>
-__global__ __launch_bounds__(256, 1) void field_bwd_onepass_kernel(FieldIO io, PackDesc pd, TPackDesc td,
-                                                                   const float* __restrict__ image,
-                                                                   const float* __restrict__ wT_image, int wt_off,
-                                                                   float* __restrict__ slabs) {
+template <int PART, bool SPEC, int TBMAX>
+__global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDesc pd, TPackDesc td, const float* __restrict__ image,
+                                                              const float* __restrict__ wT_image, ImgSegs seg_f, ImgSegs seg_t,
+                                                              int wt_off, float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  typedef OnePassSlots<TBMAX> SL;
-  {
-    const int n4 = (pd.total + 3) >> 2, m4 = (td.total + 3) >> 2;
-    for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(image)[i];
-    for (int i = threadIdx.x; i < m4; i += 256)
-      reinterpret_cast<float4*>(lds + wt_off)[i] = reinterpret_cast<const float4*>(wT_image)[i];
-  }
+  typedef TfSlots<TBMAX> SL;
+  copy_segs(lds, image, seg_f);  // pd / td carry offsets local to this part's LDS image
+  copy_segs(lds + wt_off, wT_image, seg_t);
   __syncthreads();
   const float* const wT = lds + wt_off;
   constexpr int NT = 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const v4s ident = ident_frag(lane);
-  v4f acc[SL::NACC];
-  float db[SL::NDBV * 4];
+  constexpr int A0 = SL::acc0(PART), NA = SL::acc1(PART) - A0, DB0 = 4 * SL::dbv0(PART), NDBP = 4 * (SL::dbv1(PART) - SL::dbv0(PART));
+  v4f acc_[NA];
+  float db_[NDBP];
 #pragma unroll
-  for (int i = 0; i < SL::NACC; ++i) acc[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = 0; i < NA; ++i) acc_[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int i = 0; i < SL::NDBV * 4; ++i) db[i] = 0.0f;
+  for (int i = 0; i < NDBP; ++i) db_[i] = 0.0f;
+  // acc_ / db_ are indexed with the absolute slots of TfSlots minus this part's first slot (compile-time indices only)
   const int C = io.C, B = io.B, TB = io.TB;
   const int64_t ntiles = (io.n + 63) / 64;
   // One wave per SIMD: nothing else hides a global load, so every per-sample input of a tile is requested one tile ahead.
   struct TileIn {
-    float2 e[4];
-    float w[3], d[3], dsig, sel, demb[4], dsp[TBMAX][4];
+    float w[3], d[3];
+    float2 e[PART == 1 ? 4 : 1];
+    v4f x0, x1;  // part 0: saved feature logits, -;  part 1: d_fl, d_bo (from part 0)
+    float emb[4], dsig, sel, demb[4];
   };
   auto fetch = [&](int64_t tile, TileIn& in) {
     int64_t n = tile * 64 + wave * 16 + j;
     const bool ok = n < io.n;
     if (!ok) n = io.n - 1;
 #pragma unroll
-    for (int lv = 0; lv < 4; ++lv) in.e[lv] = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
-#pragma unroll
     for (int s = 0; s < 3; ++s) in.w[s] = io.wpos[3 * n + s];
-    if (SPEC) {
+    if (PART == 0) {
+      if (SPEC) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) in.d[s] = io.dirs[3 * n + s];
-    }
-    in.sel = io.sel[n];
-    in.dsig = ok ? io.d_sigma[n] : 0.0f;  // rows past the end carry zero upstream gradients: every dZ of theirs is then zero
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = 4 * q + r - 1;
-      in.demb[r] = (io.d_emb && ok && e >= 0) ? io.d_emb[n * 15 + e] : 0.0f;
-    }
-#pragma unroll
-    for (int t = 0; t < TBMAX; ++t)
+        for (int s = 0; s < 3; ++s) in.d[s] = io.dirs[3 * n + s];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int b = 16 * t + 4 * q + r;
-        in.dsp[t][r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
+        const int e = 4 * q + r - 1;
+        in.emb[r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) meets a zero weight column
       }
+      in.x0 = *reinterpret_cast<const v4f*>(io.feat_logits_in + n * 16 + 4 * q);
+    } else {
+#pragma unroll
+      for (int lv = 0; lv < 4; ++lv) in.e[lv] = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
+      const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+      // rows past the end carry zero upstream gradients: every dZ of theirs is then zero
+      in.x0 = ok ? *reinterpret_cast<const v4f*>(io.d_fl + n * 16 + 4 * q) : z;
+      in.x1 = ok ? *reinterpret_cast<const v4f*>(io.d_bo + n * 16 + 4 * q) : z;
+      in.sel = io.sel[n];
+      in.dsig = ok ? io.d_sigma[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r - 1;
+        in.demb[r] = (io.d_emb && ok && e >= 0) ? io.d_emb[n * 15 + e] : 0.0f;
+      }
+    }
   };
   TileIn cur, nxt;
   if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
@@ -1514,138 +1529,21 @@ __global__ __launch_bounds__(256, 1) void field_bwd_onepass_kernel(FieldIO io, P
     const bool ok = n < io.n;
     if (!ok) n = io.n - 1;
     if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
-    // =================== forward recompute: mlp_base, encodings, both head MLPs, directional hidden layer ========
-    float encf[NT][8];
-#pragma unroll
-    for (int lv = 0; lv < 4; ++lv) encf[0][2 * lv] = cur.e[lv].x, encf[0][2 * lv + 1] = cur.e[lv].y;
     v4f t4[NT][4];
-    float h[NT][16];
-    gemm_pack<4, 8, NT, 2>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
-    relu_to<4, NT>(h, t4);
-    v4f bo4[NT][1];
-    gemm_pack<1, 16, NT, 2>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
-    float in27[NT][7], dir28[NT][7];
-    {
-      float pe[3];
-      pe_slots(pe, cur.w[0], cur.w[1], cur.w[2], q);
+    float in27[NT][7];
+    float pe[3];
+    pe_slots(pe, cur.w[0], cur.w[1], cur.w[2], q);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) in27[0][3 + r] = bo4[0][0][r];  // slot 0 (sigma_raw) meets a zero weight column
-      if (SPEC) {
-        float sh[4];
-        sh_slots(sh, cur.d[0], cur.d[1], cur.d[2], q);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
-      }
-    }
-    float a1h[NT][16], a2h[NT][16], a1f[NT][16], a2f[NT][16];
-    v4f hd4[NT][1], fl4[NT][1];
-    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
-    relu_to<4, NT>(a1h, t4);
-    gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
-    relu_to<4, NT>(a2h, t4);
-    gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
-    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
-    relu_to<4, NT>(a1f, t4);
-    gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
-    relu_to<4, NT>(a2f, t4);
-    gemm_pack<1, 16, NT, 2>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
-    HeadState<NT> hs;
-    head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
-    float hdir[NT][4];
-    if (SPEC) {
-      v4f d4[NT][1];
-      gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
-      relu_to<1, NT>(hdir, d4);
-    }
-    // swapped forms of the layer inputs that several dW products share.  Input layers keep their operand order, so a swapped
-    // tile's column c = 4q'+u is whatever lane quarter q' holds in slot u (onepass_col() maps it back in the slab reduce):
-    //   x27S[0]: positional encoding 3q'+u (u < 3), [1]: base-MLP output slot c;  dirS[0]: SH c, [1]: positional encoding again
-    STile x27S[2], dirS[2], hdirS[1], mS[1];
-    {
-      const float pe4[4] = {in27[0][0], in27[0][1], in27[0][2], 0.0f};
-      x27S[0] = to_swapped<false>(pe4, ident);
-      x27S[1] = to_swapped<false>(&in27[0][3], ident);
-      mS[0] = to_swapped<false>(hs.m[0], ident);
-      if (SPEC) {
-        dirS[0] = to_swapped<false>(&dir28[0][0], ident);
-        dirS[1] = x27S[0];
-        hdirS[0] = to_swapped<false>(hdir[0], ident);
-      }
-    }
-    // =================== band tiles: mixing and the specular tail ==================================================
-    v4f dm4[NT][1], dhd4[NT][1];
-    dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    float ds1 = 0.0f;
-#pragma unroll
-    for (int t = 0; t < TBMAX; ++t) {
-      if (t < TB) {
-        float dsp[NT][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dsp[0][r] = cur.dsp[t][r];
-        gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
-        STile dspS[1];
-        dspS[0] = to_swapped<false>(dsp[0], ident);
-        dw_pairs<1, 1>(&acc[SL::A_MX + t], dspS, mS);  // dE^T[b][c] += sum_n d_spectral[n][b] m[n][c]
-        if (SPEC) {
-          v4f sc[NT][1];
-          gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
-          float dzd[NT][4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sp = sigmoidf_(sc[0][0][r]);
-            ds1 += dsp[0][r] * sp;
-            dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
-          }
-          gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
-          STile dzdS[1];
-          dzdS[0] = to_swapped<true>(dzd[0], ident, &db[SL::D_D1 + t]);
-          dw_pairs<1, 1>(&acc[SL::A_D1 + t], dzdS, hdirS);
-        }
-      }
-    }
-    ds1 = xq_sum(ds1);
-    // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
-    float dhs[NT][4], dfl[NT][4];
-    {
-      const float inv_t = 1.0f / io.temperature;
-      float da[4], dot = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float dmr = dm4[0][0][r];
-        const float dsg = dmr * hs.ab[0][r];
-        dhs[0][r] = dsg * hs.sg[0][r] * (1.0f - hs.sg[0][r]);
-        da[r] = (4 * q + r < C) ? dmr * hs.sg[0][r] : 0.0f;
-        dot += hs.ab[0][r] * da[r];
-      }
-      dot = xq_sum(dot);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 4 * q + r;
-        float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) * inv_t : 0.0f;
-        if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
-        dfl[0][r] = g;
-        if (c >= C) dhs[0][r] = 0.0f;
-      }
-    }
-    if (SPEC) {  // mlp_directional hidden layer
-      float dz[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
-      STile dzS[1];
-      dzS[0] = to_swapped<true>(dz, ident, &db[SL::D_D0]);
-      dw_pairs<1, 2>(&acc[SL::A_D0], dzS, dirS);
-    }
+    for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
     v4f dbo4[NT][1];
     dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    // one 27->64->64->out MLP (head or feature): dW of its three layers, dX down to the base-MLP slots
-    auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f* __restrict__ acc2,
-                        v4f* __restrict__ acc1, v4f* __restrict__ acc0, float* __restrict__ db2, float* __restrict__ db1,
-                        float* __restrict__ db0, int t2, int t1, int t0) __attribute__((always_inline)) {
+    // one 27->64->64->out MLP (head or feature): dW of its three layers, dX down to the base-MLP slots.  x27S: swapped
+    // forms of the MLP's input; input layers keep their operand order, so a swapped tile's column c = 4q'+u is whatever lane
+    // quarter q' holds in slot u (tf_col() maps it back in the slab reduce): [0] positional encoding 3q'+u (u < 3), [1] base-MLP
+    // output slot c.
+    auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], const STile(&x27S)[2],
+                        v4f* __restrict__ acc2, v4f* __restrict__ acc1, v4f* __restrict__ acc0, float* __restrict__ db2,
+                        float* __restrict__ db1, float* __restrict__ db0, int t2, int t1, int t0) __attribute__((always_inline)) {
       STile zS[4], xS[4];
       STile z1[1];
       z1[0] = to_swapped<true>(dzo[0], ident, db2);
@@ -1671,88 +1569,240 @@ __global__ __launch_bounds__(256, 1) void field_bwd_onepass_kernel(FieldIO io, P
       dw_pairs<4, 2>(acc0, zS, x27S);
       gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
     };
-    mlp3_bwd(dhs, a2h, a1h, &acc[SL::A_H2], &acc[SL::A_H1], &acc[SL::A_H0], &db[SL::D_H2], &db[SL::D_H1], &db[SL::D_H0], T_H2, T_H1,
-             T_H0);
-    mlp3_bwd(dfl, a2f, a1f, &acc[SL::A_F2], &acc[SL::A_F1], &acc[SL::A_F0], &db[SL::D_F2], &db[SL::D_F1], &db[SL::D_F0], T_F2, T_F1,
-             T_F0);
-    // =================== mlp_base ======================================================================================
-    float dzb1[NT][4];
+    if constexpr (PART == 0) {
+      // =================== forward recompute: head MLP, directional hidden layer (feature logits come from the forward) ===
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dzb1[0][r] = ok ? dbo4[0][0][r] + cur.demb[r] : 0.0f;
-    if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
-      dzb1[0][0] = cur.dsig * cur.sel * expf(fminf(fmaxf(bo4[0][0][0], -15.0f), 15.0f));
-    }
-    {
-      STile z1[1], hS[4];
-      z1[0] = to_swapped<true>(dzb1[0], ident, &db[SL::D_B1]);
+      for (int r = 0; r < 4; ++r) in27[0][3 + r] = cur.emb[r];
+      float dir28[NT][7];
+      if (SPEC) {
+        float sh[4];
+        sh_slots(sh, cur.d[0], cur.d[1], cur.d[2], q);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) hS[t] = to_swapped<false>(&h[0][4 * t], ident);
-      dw_pairs<1, 4>(&acc[SL::A_B1], z1, hS);
-    }
-    v4f g4[NT][4];
-    gemm_pack<4, 4, NT, 1>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
-    float dzb0[NT][16];
+        for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-    {
-      STile zS[4], eS[2];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dzb0[0][4 * t], ident, &db[SL::D_B0 + t]);
-      eS[0] = to_swapped<false>(&encf[0][0], ident);  // column c = 4q'+u <-> hash feature 8q'+u
-      eS[1] = to_swapped<false>(&encf[0][4], ident);  //                    <-> hash feature 8q'+4+u
-      dw_pairs<4, 2>(&acc[SL::A_B0], zS, eS);
-    }
-    v4f de4[NT][2];
-    gemm_pack<2, 16, NT, 1>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
-    if (ok && io.d_enc) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int lv = 8 * t + 2 * q + rr;  // feature e = 16t+4q+r -> level e>>1, component e&1
-          *reinterpret_cast<float2*>(io.d_enc + n * io.sn + (int64_t)lv * io.sl) = make_float2(de4[0][t][2 * rr], de4[0][t][2 * rr + 1]);
+        for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
+      }
+      float a1h[NT][16], a2h[NT][16];
+      v4f hd4[NT][1], fl4[NT][1];
+      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+      relu_to<4, NT>(a1h, t4);
+      gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+      relu_to<4, NT>(a2h, t4);
+      gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+      fl4[0][0] = cur.x0;
+      HeadState<NT> hs;
+      head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
+      float hdir[NT][4];
+      if (SPEC) {
+        v4f d4[NT][1];
+        gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+        relu_to<1, NT>(hdir, d4);
+      }
+      STile x27S[2], dirS[2], hdirS[1], mS[1];  // dirS[0]: SH c, dirS[1]: the positional encoding again
+      {
+        const float pe4[4] = {pe[0], pe[1], pe[2], 0.0f};
+        x27S[0] = to_swapped<false>(pe4, ident);
+        x27S[1] = to_swapped<false>(&in27[0][3], ident);
+        mS[0] = to_swapped<false>(hs.m[0], ident);
+        if (SPEC) {
+          dirS[0] = to_swapped<false>(&dir28[0][0], ident);
+          dirS[1] = x27S[0];
+          hdirS[0] = to_swapped<false>(hdir[0], ident);
         }
+      }
+      // =================== band tiles: mixing and the specular tail (the next tile's gradients are requested a tile ahead) ===
+      v4f dm4[NT][1], dhd4[NT][1];
+      dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      float ds1 = 0.0f;
+      auto load_dsp = [&](int t, float(&g)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = 16 * t + 4 * q + r;
+          g[r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
+        }
+      };
+      float dnext[4];
+      load_dsp(0, dnext);
+#pragma unroll
+      for (int t = 0; t < TBMAX; ++t) {
+        if (t < TB) {
+          float dsp[NT][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dsp[0][r] = dnext[r];
+          if (t + 1 < TB) load_dsp(t + 1, dnext);
+          gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+          STile dspS[1];
+          dspS[0] = to_swapped<false>(dsp[0], ident);
+          dw_pairs<1, 1>(&acc_[SL::A_MX - A0 + t], dspS, mS);  // dE^T[b][c] += sum_n d_spectral[n][b] m[n][c]
+          if (SPEC) {
+            v4f sc[NT][1];
+            gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+            float dzd[NT][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sp = sigmoidf_(sc[0][0][r]);
+              ds1 += dsp[0][r] * sp;
+              dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
+            }
+            gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
+            STile dzdS[1];
+            dzdS[0] = to_swapped<true>(dzd[0], ident, &db_[SL::D_D1 - DB0 + t]);
+            dw_pairs<1, 1>(&acc_[SL::A_D1 - A0 + t], dzdS, hdirS);
+          }
+        }
+      }
+      ds1 = xq_sum(ds1);
+      // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
+      float dhs[NT][4], dfl[NT][4];
+      {
+        const float inv_t = 1.0f / io.temperature;
+        float da[4], dot = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dmr = dm4[0][0][r];
+          const float dsg = dmr * hs.ab[0][r];
+          dhs[0][r] = dsg * hs.sg[0][r] * (1.0f - hs.sg[0][r]);
+          da[r] = (4 * q + r < C) ? dmr * hs.sg[0][r] : 0.0f;
+          dot += hs.ab[0][r] * da[r];
+        }
+        dot = xq_sum(dot);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) * inv_t : 0.0f;
+          if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
+          dfl[0][r] = g;
+          if (c >= C) dhs[0][r] = 0.0f;
+        }
+      }
+      if (ok) *reinterpret_cast<v4f*>(io.d_fl + n * 16 + 4 * q) = v4f{dfl[0][0], dfl[0][1], dfl[0][2], dfl[0][3]};
+      if (SPEC) {  // mlp_directional hidden layer
+        float dz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
+        STile dzS[1];
+        dzS[0] = to_swapped<true>(dz, ident, &db_[SL::D_D0 - DB0]);
+        dw_pairs<1, 2>(&acc_[SL::A_D0 - A0], dzS, dirS);
+      }
+      mlp3_bwd(dhs, a2h, a1h, x27S, &acc_[SL::A_H2 - A0], &acc_[SL::A_H1 - A0], &acc_[SL::A_H0 - A0], &db_[SL::D_H2 - DB0], &db_[SL::D_H1 - DB0], &db_[SL::D_H0 - DB0], T_H2,
+               T_H1, T_H0);
+      if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
+    } else {
+      // =================== forward recompute: mlp_base (its outputs are the feature MLP's inputs), feature MLP's hidden layers ===
+      float encf[NT][8];
+#pragma unroll
+      for (int lv = 0; lv < 4; ++lv) encf[0][2 * lv] = cur.e[lv].x, encf[0][2 * lv + 1] = cur.e[lv].y;
+      float h[NT][16];
+      gemm_pack<4, 8, NT, 2>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+      relu_to<4, NT>(h, t4);
+      v4f bo4[NT][1];
+      gemm_pack<1, 16, NT, 2>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) in27[0][3 + r] = bo4[0][0][r];  // slot 0 (sigma_raw) meets a zero weight column
+      float a1f[NT][16], a2f[NT][16];
+      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+      relu_to<4, NT>(a1f, t4);
+      gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+      relu_to<4, NT>(a2f, t4);
+      STile x27S[2];
+      {
+        const float pe4[4] = {pe[0], pe[1], pe[2], 0.0f};
+        x27S[0] = to_swapped<false>(pe4, ident);
+        x27S[1] = to_swapped<false>(&in27[0][3], ident);
+      }
+      float dfl[NT][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dfl[0][r] = cur.x0[r];
+      mlp3_bwd(dfl, a2f, a1f, x27S, &acc_[SL::A_F2 - A0], &acc_[SL::A_F1 - A0], &acc_[SL::A_F0 - A0], &db_[SL::D_F2 - DB0], &db_[SL::D_F1 - DB0], &db_[SL::D_F0 - DB0], T_F2,
+               T_F1, T_F0);
+      // =================== mlp_base ======================================================================================
+      float dzb1[NT][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dzb1[0][r] = ok ? (dbo4[0][0][r] + cur.x1[r]) + cur.demb[r] : 0.0f;
+      if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
+        dzb1[0][0] = cur.dsig * cur.sel * expf(fminf(fmaxf(bo4[0][0][0], -15.0f), 15.0f));
+      }
+      {
+        STile z1[1], hS[4];
+        z1[0] = to_swapped<true>(dzb1[0], ident, &db_[SL::D_B1 - DB0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hS[t] = to_swapped<false>(&h[0][4 * t], ident);
+        dw_pairs<1, 4>(&acc_[SL::A_B1 - A0], z1, hS);
+      }
+      v4f g4[NT][4];
+      gemm_pack<4, 4, NT, 1>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
+      float dzb0[NT][16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+      {
+        STile zS[4], eS[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dzb0[0][4 * t], ident, &db_[SL::D_B0 - DB0 + t]);
+        eS[0] = to_swapped<false>(&encf[0][0], ident);  // column c = 4q'+u <-> hash feature 8q'+u
+        eS[1] = to_swapped<false>(&encf[0][4], ident);  //                    <-> hash feature 8q'+4+u
+        dw_pairs<4, 2>(&acc_[SL::A_B0 - A0], zS, eS);
+      }
+      v4f de4[NT][2];
+      gemm_pack<2, 16, NT, 1>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
+      if (ok && io.d_enc) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int lv = 8 * t + 2 * q + rr;  // feature e = 16t+4q+r -> level e>>1, component e&1
+            *reinterpret_cast<float2*>(io.d_enc + n * io.sn + (int64_t)lv * io.sl) = make_float2(de4[0][t][2 * rr], de4[0][t][2 * rr + 1]);
+          }
+      }
     }
     cur = nxt;
   }
   // =================== sum the four waves' accumulators through LDS (the pack images are dead), one slab per workgroup ======
   float* const slab = slabs + (size_t)blockIdx.x * (SL::NITEMS * 256);
+  constexpr int NMINE = NA + NDBP / 4;  // this part's items: its accumulators, then its bias-sum quadruples
 #pragma unroll
-  for (int c0 = 0; c0 < SL::NITEMS; c0 += OP_CHUNK) {
+  for (int c0 = 0; c0 < NMINE; c0 += TF_CHUNK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < OP_CHUNK; ++i) {
+    for (int i = 0; i < TF_CHUNK; ++i) {
       const int it = c0 + i;
-      if (it < SL::NITEMS) {
+      if (it < NMINE) {
         v4f v;
-        if (it < SL::NACC) {
-          v = acc[it < SL::NACC ? it : 0];
+        if (it < NA) {
+          v = acc_[it < NA ? it : 0];
         } else {
-          const int k = 4 * (it - SL::NACC);
-          v = v4f{db[k >= 0 ? k : 0], db[k >= 0 ? k + 1 : 0], db[k >= 0 ? k + 2 : 0], db[k >= 0 ? k + 3 : 0]};
+          const int k = it < NA ? 0 : 4 * (it - NA);
+          v = v4f{db_[k], db_[k + 1], db_[k + 2], db_[k + 3]};
         }
-        *reinterpret_cast<v4f*>(lds + ((wave * OP_CHUNK + i) * 64 + lane) * 4) = v;
+        *reinterpret_cast<v4f*>(lds + ((wave * TF_CHUNK + i) * 64 + lane) * 4) = v;
       }
     }
     __syncthreads();
-    const int cnt = (SL::NITEMS - c0 < OP_CHUNK ? SL::NITEMS - c0 : OP_CHUNK) * 64;
-    for (int e = tid; e < cnt; e += 256) {
+    const int nit = NMINE - c0 < TF_CHUNK ? NMINE - c0 : TF_CHUNK;
+    for (int e = tid; e < nit * 64; e += 256) {
       v4f s = *reinterpret_cast<const v4f*>(lds + e * 4);
 #pragma unroll
-      for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const v4f*>(lds + (w * OP_CHUNK * 64 + e) * 4);
-      *reinterpret_cast<v4f*>(slab + (c0 * 64 + e) * 4) = s;
+      for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const v4f*>(lds + (w * TF_CHUNK * 64 + e) * 4);
+      const int it = c0 + (e >> 6);  // this part's item -> absolute slab item
+      const int abs_item = it < NA ? A0 + it : SL::NACC + SL::dbv0(PART) + (it - NA);
+      *reinterpret_cast<v4f*>(slab + (abs_item * 64 + (e & 63)) * 4) = s;
     }
   }
 }
 
-// slab -> gradient tensors of the one-pass kernel.  item -> (layer, to, ti); a swapped input tile's column c of layer kind
-// `kind` is reference input column onepass_col(kind, ti, c) (or -1: a padding slot).
-struct OnePassMap {
+struct GradPtrs {
+  float* W[NLAYERS];
+  float* b[NLAYERS];
+};
+
+// slab -> gradient tensors of the transpose-free kernels.  item -> (layer, to, ti); a swapped input tile's column c of layer kind
+// `kind` is reference input column tf_col(kind, ti, c) (or -1: a padding slot).
+struct TfMap {
   int nacc, ndb, nitems;
   short layer[128], to[128], ti[128];  // per accumulator item
   short db_layer[64], db_tile[64];     // per bias-sum tile
 };
-__device__ __forceinline__ int onepass_col(int kind, int ti, int c) {
+__device__ __forceinline__ int tf_col(int kind, int ti, int c) {
   const int qq = c >> 2, u = c & 3;
   switch (kind) {
     case IN_ENC: return 8 * qq + 4 * ti + u;
@@ -1762,7 +1812,7 @@ __device__ __forceinline__ int onepass_col(int kind, int ti, int c) {
   }
 }
 
-__global__ __launch_bounds__(256) void field_reduce_onepass_kernel(const float* __restrict__ slabs, int nslabs, OnePassMap mp,
+__global__ __launch_bounds__(256) void field_reduce_tf_kernel(const float* __restrict__ slabs, int nslabs, TfMap mp,
                                                                    PackDesc pd, GradPtrs gp) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int nw = mp.nacc * 256, nb = mp.ndb * 16;
@@ -1788,7 +1838,7 @@ __global__ __launch_bounds__(256) void field_reduce_onepass_kernel(const float* 
       if (out < L.OUT && cls < L.IN && gp.W[l]) gp.W[l][(size_t)cls * L.OUT + out] = s;
       return;
     }
-    const int in = onepass_col(L.kind, mp.ti[item], ln & 15);
+    const int in = tf_col(L.kind, mp.ti[item], ln & 15);
     if (out < L.OUT && in >= 0 && in < L.IN && gp.W[l]) gp.W[l][(size_t)out * L.IN + in] = s;
   } else if (e < nw + nb) {
     const int k = e - nw, T = k >> 4, c = k & 15;  // bias tile T (slot in db[]), column c: sum over slabs and the 4 lane quarters
@@ -1806,10 +1856,6 @@ __global__ __launch_bounds__(256) void field_reduce_onepass_kernel(const float* 
 }
 
 // ---- sum the per-workgroup slabs and scatter into the reference-layout gradient tensors ------------
-struct GradPtrs {
-  float* W[NLAYERS];
-  float* b[NLAYERS];
-};
 
 __device__ __forceinline__ int stage_col_to_in(int kind, int col) {
   if (kind == IN_27) return col < 12 ? col : (col >= 13 && col < 28 ? col - 1 : -1);
@@ -2217,8 +2263,143 @@ static unsigned bwd_grid(int64_t n, int S) {
   return (unsigned)(ntiles < 256 ? ntiles : 256);
 }
 
+// ---- transpose-free backward: per-part LDS images and launch ------------------------------------------------------------
+static unsigned tf_grid(int64_t n) {
+  const int64_t ntiles = (n + 63) / 64;
+  return (unsigned)(ntiles < 256 ? ntiles : 256);
+}
+static int tf_tbmax(int TB) { return TB <= 2 ? 2 : (TB <= 4 ? 4 : (TB <= 8 ? 8 : (TB <= 12 ? 12 : (TB <= 16 ? 16 : 0)))); }
+static int tf_nitems(int tbmax) {
+  switch (tbmax) {
+    case 2: return TfSlots<2>::NITEMS;
+    case 4: return TfSlots<4>::NITEMS;
+    case 8: return TfSlots<8>::NITEMS;
+    case 12: return TfSlots<12>::NITEMS;
+    default: return TfSlots<16>::NITEMS;
+  }
+}
+static size_t bwd_slab_floats(const BwdPlan& pl, int64_t n) {  // room for either kernel family's per-workgroup slabs
+  const size_t staged = (size_t)bwd_grid(n, pl.S) * pl.sl.total;
+  const size_t tf = (size_t)tf_grid(n) * tf_nitems(tf_tbmax(pl.TB) ? tf_tbmax(pl.TB) : 16) * 256;
+  return staged > tf ? staged : tf;
+}
 static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
-  return ((size_t)pl.td.total + (size_t)bwd_grid(n, pl.S) * pl.sl.total + (size_t)n * 48 + pl.pd_all.total) * 4 + 4096;
+  return ((size_t)pl.td.total + bwd_slab_floats(pl, n) + (size_t)n * 48 + pl.pd_all.total) * 4 + 4096;
+}
+
+struct TfPart {  // one transpose-free kernel: descriptors rebased to its own LDS image + how to assemble that image
+  PackDesc pd;
+  TPackDesc td;
+  ImgSegs seg_f, seg_t;
+  int wt_off;
+  size_t lds;
+};
+static bool tf_part(const BwdPlan& pl, int part, TfPart* pp) {
+  const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
+  const int fl1[] = {L_B0, L_B1, L_F0, L_F1}, tl1[] = {T_B1, T_B0, T_F2, T_F1, T_F0};
+  const int* fl = part == 0 ? fl0 : fl1;
+  const int nfl = part == 0 ? 5 : 4;
+  const int* tl = part == 0 ? tl0 : tl1;
+  const int ntl = 5;
+  pp->pd = pl.pd_all, pp->td = pl.td;
+  pp->seg_f.n = pp->seg_t.n = 0;
+  bool ok = true;
+  auto add = [&](ImgSegs& sg, int src, int dst, int len) {
+    if (len == 0) return;
+    if (sg.n && sg.src[sg.n - 1] + sg.len[sg.n - 1] == src && sg.dst[sg.n - 1] + sg.len[sg.n - 1] == dst) {
+      sg.len[sg.n - 1] += len;
+      return;
+    }
+    if (sg.n == 6) {
+      ok = false;
+      return;
+    }
+    sg.src[sg.n] = src, sg.dst[sg.n] = dst, sg.len[sg.n] = len, ++sg.n;
+  };
+  int cur = 0;
+  for (int i = 0; i < nfl; ++i) {  // weights, then biases, in the kernel's own compact image
+    const LayerDesc& L = pl.pd_all.L[fl[i]];
+    const int len = L.OT * ((L.KS + 3) / 4) * 256;
+    add(pp->seg_f, L.off_w, cur, len);
+    pp->pd.L[fl[i]].off_w = cur, cur += len;
+  }
+  for (int i = 0; i < nfl; ++i) {
+    const LayerDesc& L = pl.pd_all.L[fl[i]];
+    add(pp->seg_f, L.off_b, cur, 16 * L.OT);
+    pp->pd.L[fl[i]].off_b = cur, cur += 16 * L.OT;
+  }
+  pp->wt_off = (cur + 3) & ~3;
+  cur = 0;
+  for (int i = 0; i < ntl; ++i) {
+    const TDesc& T = pl.td.L[tl[i]];
+    const int len = T.OT * ((T.KS + 3) / 4) * 256;
+    add(pp->seg_t, T.off, cur, len);
+    pp->td.L[tl[i]].off = cur, cur += len;
+  }
+  pp->lds = (size_t)(pp->wt_off + cur) * 4;
+  if (pp->lds < (size_t)4 * TF_CHUNK * 256 * 4) pp->lds = (size_t)4 * TF_CHUNK * 256 * 4;  // the end-of-launch reduction's rounds
+  return ok && pp->lds <= 160 * 1024;
+}
+
+template <int TBMAX>
+static void fill_tf_map(TfMap* mp, bool spec, int TB) {
+  typedef TfSlots<TBMAX> SL;
+  static_assert(SL::NACC <= 128 && SL::NDB <= 64, "TfMap tables");
+  mp->nacc = SL::NACC, mp->ndb = SL::NDB, mp->nitems = SL::NITEMS;
+  for (int i = 0; i < 128; ++i) mp->layer[i] = -1, mp->to[i] = 0, mp->ti[i] = 0;
+  for (int i = 0; i < 64; ++i) mp->db_layer[i] = -1, mp->db_tile[i] = 0;
+  auto pairs = [&](int base, int layer, int TO, int TI) {
+    for (int to = 0; to < TO; ++to)
+      for (int ti = 0; ti < TI; ++ti) {
+        const int i = base + to * TI + ti;
+        mp->layer[i] = (short)layer, mp->to[i] = (short)to, mp->ti[i] = (short)ti;
+      }
+  };
+  pairs(SL::A_B0, L_B0, 4, 2), pairs(SL::A_B1, L_B1, 1, 4);
+  pairs(SL::A_H0, L_H0, 4, 2), pairs(SL::A_H1, L_H1, 4, 4), pairs(SL::A_H2, L_H2, 1, 4);
+  pairs(SL::A_F0, L_F0, 4, 2), pairs(SL::A_F1, L_F1, 4, 4), pairs(SL::A_F2, L_F2, 1, 4);
+  if (spec) pairs(SL::A_D0, L_D0, 1, 2);
+  for (int t = 0; t < TB; ++t) {
+    if (spec) mp->layer[SL::A_D1 + t] = L_D1, mp->to[SL::A_D1 + t] = (short)t;
+    mp->layer[SL::A_MX + t] = L_MX, mp->to[SL::A_MX + t] = (short)t;
+  }
+  auto bias = [&](int base, int layer, int TO) {
+    for (int t = 0; t < TO; ++t) mp->db_layer[base + t] = (short)layer, mp->db_tile[base + t] = (short)t;
+  };
+  bias(SL::D_B0, L_B0, 4), bias(SL::D_B1, L_B1, 1), bias(SL::D_H0, L_H0, 4), bias(SL::D_H1, L_H1, 4), bias(SL::D_H2, L_H2, 1);
+  bias(SL::D_F0, L_F0, 4), bias(SL::D_F1, L_F1, 4), bias(SL::D_F2, L_F2, 1);
+  if (spec) bias(SL::D_D0, L_D0, 1), bias(SL::D_D1, L_D1, TB);
+}
+
+template <int TBMAX>
+static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], FieldIO io, bool spec, const float* img, const float* wT, float* slabs,
+                     const GradPtrs& gp, int64_t n, umhs_stream_t stream) {
+  typedef TfSlots<TBMAX> SL;
+  const unsigned grid = tf_grid(n);
+  int rc;
+#define LAUNCH_TF(P_, S_)                                                                                                         \
+  do {                                                                                                                            \
+    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX>, part[P_].lds);                                                               \
+    if (rc) return rc;                                                                                                            \
+    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io, part[P_].pd, \
+                       part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, slabs);                             \
+  } while (0)
+  if (spec) {
+    LAUNCH_TF(0, true);
+    LAUNCH_TF(1, true);
+  } else {
+    LAUNCH_TF(0, false);
+    LAUNCH_TF(1, false);
+  }
+#undef LAUNCH_TF
+  UMHS_CHECK_LAUNCH();
+  TfMap mp;
+  fill_tf_map<TBMAX>(&mp, spec, pl.TB);
+  const int items = SL::NACC * 256 + SL::NDB * 16;
+  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3((items + 255) / 256), dim3(256), 0, umhs_s(stream), (const float*)slabs, (int)grid, mp,
+                     pl.pd_all, gp);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
 }
 
 // The weight images of the backward (transposed packs + forward pack image) depend on the parameters only: a caller may build
@@ -2278,7 +2459,7 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   float* img = wT + ((pl.td.total + 63) & ~63);
   float* slabs = img + ((pl.pd_all.total + 63) & ~63);
-  float* d_bo = slabs + (((size_t)grid * pl.sl.total + 63) & ~(size_t)63);
+  float* d_bo = slabs + ((bwd_slab_floats(pl, n) + 63) & ~(size_t)63);
   float* d_bo2 = d_bo + (((size_t)n * 16 + 63) & ~(size_t)63);
   float* d_fl = d_bo2 + (((size_t)n * 16 + 63) & ~(size_t)63);
   static const int no_split = getenv("UMHS_BWD_NO_SPLIT") ? atoi(getenv("UMHS_BWD_NO_SPLIT")) : 0;  // A/B knob
@@ -2294,6 +2475,36 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = pl.TB, io.temperature = cfg->temperature;
   io.d_sigma = d_sigma, io.d_spectral = d_spectral, io.d_emb = d_emb_ext, io.d_enc = d_enc;
   io.emb_in = emb, io.sigma_raw_in = sigma_raw, io.d_bo = d_bo;
+  GradPtrs gp;
+  {
+    float* const gw[NLAYERS] = {grads->base_w0, grads->base_w1, grads->head_w0, grads->head_w1, grads->head_w2,
+                                grads->feat_w0, grads->feat_w1, grads->feat_w2, grads->dir_w0,  grads->dir_w1,
+                                grads->endmembers};
+    float* const gb[NLAYERS] = {grads->base_b0, grads->base_b1, grads->head_b0, grads->head_b1, grads->head_b2,
+                                grads->feat_b0, grads->feat_b1, grads->feat_b2, grads->dir_b0,  grads->dir_b1,
+                                nullptr};
+    for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
+  }
+  // ---- transpose-free kernels (default; they need the forward's feature logits like the split kernels below) ---------------
+  // Measured (tools/bench_fbwd.py, one MI355X): 128 bands 951 vs 1454 us, 141 bands 895 vs 1243 us for the LDS-staged kernels below
+  // (whose fused heads kernel spills and keeps its transposed packs in L2 at B > 32); at B <= 32 the split LDS-staged kernels, two
+  // waves per SIMD, are still ahead (351 vs 392 us), so the default is: transpose-free above 32 bands.  UMHS_BWD_TF=1 / 0 forces.
+  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : -1;
+  const int tbmax = tf_tbmax(pl.TB);
+  const bool want_tf = tf_mode < 0 ? pl.TB > 2 : tf_mode != 0;
+  if (want_tf && feat_logits != nullptr && tbmax != 0) {
+    TfPart part[2];
+    if (tf_part(pl, 0, &part[0]) && tf_part(pl, 1, &part[1])) {
+      io.feat_logits_in = feat_logits, io.d_fl = d_fl;
+      switch (tbmax) {
+        case 2: return launch_tf<2>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
+        case 4: return launch_tf<4>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
+        case 8: return launch_tf<8>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
+        case 12: return launch_tf<12>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
+        default: return launch_tf<16>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
+      }
+    }
+  }
 #define LAUNCH_HEADS(S_, NA_, W_)                                                                                  \
   do {                                                                                                             \
     rc = set_lds(field_bwd_heads_kernel<S_, NA_, W_>, pl.lds_h);                                                   \
@@ -2352,14 +2563,6 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
                        (const float*)wT, pl.sl, slabs, pl.stage_off_b);
   }
   UMHS_CHECK_LAUNCH();
-  GradPtrs gp;
-  float* const gw[NLAYERS] = {grads->base_w0, grads->base_w1, grads->head_w0, grads->head_w1, grads->head_w2,
-                              grads->feat_w0, grads->feat_w1, grads->feat_w2, grads->dir_w0,  grads->dir_w1,
-                              grads->endmembers};
-  float* const gb[NLAYERS] = {grads->base_b0, grads->base_b1, grads->head_b0, grads->head_b1, grads->head_b2,
-                              grads->feat_b0, grads->feat_b1, grads->feat_b2, grads->dir_b0,  grads->dir_b1,
-                              nullptr};
-  for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
   const PackDesc& pd_all = pl.pd_all;
   const int items = pl.sl.total_w + pl.n_bias_items;
   hipLaunchKernelGGL(field_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, umhs_s(stream), (const float*)slabs,

@@ -28,11 +28,21 @@ def rank_seed(seed: int, rank: int) -> int:
     return seed + rank
 
 
+EXCHANGE_DISABLED = False  # diagnostics only (bench.py's compute-only pass): skip every gradient collective
+STATS = {"bytes": 0, "messages": 0}  # payload handed to all_reduce since the last reset (bench.py reports MB per step)
+
+
+def _all_reduce(t: torch.Tensor, async_op: bool = False):
+    STATS["bytes"] += t.numel() * t.element_size()
+    STATS["messages"] += 1
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 def allreduce_flat_grad(grad: torch.Tensor) -> float:
     """Sum the flat gradient over ranks in place; returns the factor (1/world) the optimizer applies to average it."""
     _, w = world()
-    if w > 1:
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    if w > 1 and not EXCHANGE_DISABLED:
+        _all_reduce(grad)
     return 1.0 / w
 
 
@@ -134,7 +144,7 @@ class FlatGradSink:
         return self.buffer
 
     def reducing(self) -> bool:
-        return world()[1] > 1 and self.async_reduce and not self.defer_reduce
+        return world()[1] > 1 and self.async_reduce and not self.defer_reduce and not EXCHANGE_DISABLED
 
     def groups(self, n_levels: int):
         if not self.reducing():
@@ -148,7 +158,7 @@ class FlatGradSink:
     def segment_done(self, view: torch.Tensor) -> None:
         if self.reducing():
             off = (view.data_ptr() - self.buffer.data_ptr()) // self.buffer.element_size()
-            self.works.append((off, off + view.numel(), dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), None))
+            self.works.append((off, off + view.numel(), _all_reduce(view, async_op=True), None))
 
     def table_levels_done(self, table: torch.Tensor, l0: int, cnt: int) -> None:
         """Levels [l0, l0+cnt) of the table gradient ([L*T, 2] view of the buffer) are final: start their reduction."""
@@ -161,7 +171,7 @@ class FlatGradSink:
                 raise RuntimeError("sparse hash levels must be finished by the first level group")
             compact = table.index_select(0, self.sparse_rows)
             off = (table.data_ptr() - self.buffer.data_ptr()) // self.buffer.element_size()
-            w = dist.all_reduce(compact, op=dist.ReduceOp.SUM, async_op=True)
+            w = _all_reduce(compact, async_op=True)
             self.works.append((off, off + ns * T * table.shape[1], w, (table, compact)))
             lo = ns
         if lo < hi:
