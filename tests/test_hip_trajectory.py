@@ -336,3 +336,28 @@ def test_trainer_driven_loop_equals_the_standalone_pipeline():
     assert_close("MLP / endmember parameters", driven.model.field.flat[tail:], alone.model.field.flat[tail:], 2e-5)
     assert_close("hash table", driven.model.field.flat[:tail], alone.model.field.flat[:tail], 1e-3)
     assert "psnr_spectral" in metrics
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_hashgrid_bwd_propagates_non_finite_gradients(bad):
+    """the fixed-point bucket reduce must not turn a NaN / Inf upstream gradient into an arbitrary finite table gradient
+    (the reference's index_add would hand the optimizer a NaN).  The level that saw it comes back NaN, the others stay exact."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    n, log2_T = 3000, 19
+    pos = torch.rand(n, 3, generator=g)
+    d_enc = torch.randn(16, n, 2, generator=g)
+    sc = ops.hash_scalings().to(DEV)
+    clean = torch.empty(16 << log2_T, 2, device=DEV)
+    ops.hashgrid_bwd(pos.to(DEV), d_enc.to(DEV), sc, log2_T, clean, True, method="partition", overwrite=True)
+    assert bool(torch.isfinite(clean).all())
+    d_bad = d_enc.clone()
+    d_bad[7, 1234, 1] = bad
+    got = torch.empty_like(clean)
+    ops.hashgrid_bwd(pos.to(DEV), d_bad.to(DEV), sc, log2_T, got, True, method="partition", overwrite=True)
+    T = 1 << log2_T
+    lvl = got[7 * T:8 * T]
+    assert bool(torch.isnan(lvl).any()) and not bool(torch.isfinite(lvl[lvl != 0]).any())
+    keep = torch.ones(16 * T, dtype=torch.bool, device=DEV)
+    keep[7 * T:8 * T] = False
+    assert torch.equal(got[keep], clean[keep])

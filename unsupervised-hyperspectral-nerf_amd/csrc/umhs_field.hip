@@ -1626,6 +1626,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       load_dsp(0, dnext);
 #pragma unroll
       for (int t = 0; t < TBMAX; ++t) {
+        if (TBMAX > 2) __builtin_amdgcn_sched_barrier(0);  // band tiles one after the other: hoisting across them only spills
         if (t < TB) {
           float dsp[NT][4];
 #pragma unroll

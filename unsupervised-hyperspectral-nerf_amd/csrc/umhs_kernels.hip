@@ -263,7 +263,10 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
   uint32_t slot[HB_SPT][8];
   float2 val[HB_SPT][8];
   bool emit[HB_SPT];
-  float vmax = 0.0f;
+  // max |record value| of the level as raw bits: for non-negative floats the integer order is the float order, and an Inf / NaN
+  // pattern (>= 0x7f800000) beats every finite one -- hg_reduce turns a level that saw one into NaN gradients instead of
+  // an arbitrary fixed-point conversion (fmaxf would silently drop a NaN; the reference's index_add propagates it)
+  uint32_t vmax = 0u;
 #pragma unroll
   for (int k = 0; k < HB_SPT; ++k) {
     const int64_t i = (int64_t)wg * (256 * HB_SPT) + k * 256 + tid;
@@ -312,14 +315,14 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         if (!SCATTER) atomicAdd(&hist[slot[k][c] >> a.bucket_bits], 1u);
-        if (SCATTER) vmax = fmaxf(vmax, fmaxf(fabsf(val[k][c].x), fabsf(val[k][c].y)));
+        if (SCATTER) vmax = max(vmax, max(__float_as_uint(fabsf(val[k][c].x)), __float_as_uint(fabsf(val[k][c].y))));
       }
     }
   }
   if (SCATTER) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
-    if (lane == 0 && vmax > 0.0f) atomicMax(&wgmax, __float_as_uint(vmax));
+    for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
+    if (lane == 0 && vmax > 0u) atomicMax(&wgmax, vmax);
   }
   if (!SCATTER) {
     __syncthreads();
@@ -464,10 +467,20 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
     }
     return;
   }
+  const uint32_t lmax_bits = a.lmax[lev];
+  if (lmax_bits >= 0x7f800000u) {  // a non-finite gradient reached this level: its gradient is NaN, as after the reference's index_add
+    float* dst0 = d_table + slab;
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (int j = tid * 4; j < nsl; j += 4096) {
+      *reinterpret_cast<float4*>(dst0 + j) = make_float4(qnan, qnan, qnan, qnan);
+      if (adam) step4(j, make_float4(qnan, qnan, qnan, qnan));
+    }
+    return;
+  }
   for (int i = tid; i < nsl; i += 1024) tile[i] = 0;
   // fixed-point scale 2^k:  |v| <= vmax < 2^e, at most cnt < 2^hb addends  =>  |sum| * 2^k < 2^62
   int e;
-  (void)frexpf(__uint_as_float(a.lmax[lev]), &e);
+  (void)frexpf(__uint_as_float(lmax_bits), &e);
   const int hb = 33 - __clz(cnt);  // cnt < 2^(32-clz) ; one spare bit
   const int k = 62 - hb - e;
   __syncthreads();
@@ -916,45 +929,41 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
       w = weights[nidx];
       tnext = d_sigma[nidx];
       dw = dacc;
-      for (int s = 0; s < gr.n; ++s) {
-        const int K = gr.k[s];
-        if (K <= 32) continue;  // narrow streams go through the LDS tile below
-        const float* __restrict__ vrow = gr.v[s] + nidx * (int64_t)K;
-        const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
-        float d0 = 0.0f, d1 = 0.0f;
-        int k = 0;
-        for (; k + 1 < K; k += 2) {
-          d0 += drow[k] * vrow[k];
-          d1 += drow[k + 1] * vrow[k + 1];
-        }
-        if (k < K) d0 += drow[k] * vrow[k];
-        dw += d0 + d1;
-      }
     }
     const int nvalid = min(64, cnt - c * 64);
-    // K <= 32: the chunk's [nvalid x K] rows are ONE contiguous block -> read it with full 256-byte wave loads into an LDS
-    // tile (row stride K|1: odd, so the per-lane row walk below is bank-conflict free) instead of 64 rows x K strided dwords
+    // The chunk's [nvalid x K] rows are one contiguous block.  K <= 32: read it with full 256-byte wave loads into an LDS tile
+    // (row stride K|1: odd, so the per-lane row walk below is bank-conflict free) instead of 64 rows x K strided dwords.  Wider
+    // streams (128 / 141 bands) walk 32-band slices of the block the same way, two 128-byte row segments per wave load (the
+    // row-per-lane loop they used to take ran at a third of the narrow streams' rate: 289 us at C3, 463 us at C5).
     for (int s = 0; s < gr.n; ++s) {
       const int K = gr.k[s];
-      if (K > 32) continue;
-      const int KS = K | 1;
+      const int KS = K <= 32 ? (K | 1) : 33;
       const float* __restrict__ vb = gr.v[s] + (start + c * 64) * (int64_t)K;
       const float* __restrict__ drow = gr.dout[s] + r * (int64_t)K;
-      const int tot = nvalid * K;
-      for (int e = lane; e < tot; e += 64) {
-        const int jj = e / K;
-        tile[jj * KS + (e - jj * K)] = vb[e];
-      }
-      if (lane < K) dl[lane] = drow[lane];
-      if (valid) {
-        float d0 = 0.0f, d1 = 0.0f;
-        int k = 0;
-        for (; k + 1 < K; k += 2) {
-          d0 += dl[k] * tile[lane * KS + k];
-          d1 += dl[k + 1] * tile[lane * KS + k + 1];
+      for (int k0 = 0; k0 < K; k0 += 32) {
+        const int kw = min(32, K - k0);
+        if (K <= 32) {
+          const int tot = nvalid * K;
+          for (int e = lane; e < tot; e += 64) {
+            const int jj = e / K;
+            tile[jj * KS + (e - jj * K)] = vb[e];
+          }
+        } else {
+          const int col = lane & 31;
+          for (int jj = lane >> 5; jj < nvalid; jj += 2)
+            if (col < kw) tile[jj * 33 + col] = vb[(int64_t)jj * K + k0 + col];
         }
-        if (k < K) d0 += dl[k] * tile[lane * KS + k];
-        dw += d0 + d1;
+        if (lane < kw) dl[lane] = drow[k0 + lane];
+        if (valid) {
+          float d0 = 0.0f, d1 = 0.0f;
+          int k = 0;
+          for (; k + 1 < kw; k += 2) {
+            d0 += dl[k] * tile[lane * KS + k];
+            d1 += dl[k + 1] * tile[lane * KS + k + 1];
+          }
+          if (k < kw) d0 += dl[k] * tile[lane * KS + k];
+          dw += d0 + d1;
+        }
       }
     }
     float p = dw * w;
@@ -983,10 +992,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         const int k = kc + lane;
         const bool kv = k < K;
         const float d = kv ? drow[k] : 0.0f;
-        for (int j = 0; j < nvalid; ++j) {
-          const float wj = __shfl(ws, j, 64);  // all lanes take part in the shuffle
-          if (kv) dv[(int64_t)j * K + k] = wj * d;
-        }
+        for (int j = 0; j < nvalid; ++j)
+          if (kv) dv[(int64_t)j * K + k] = wsl[j] * d;  // 256-byte row segments; the row's weight comes from LDS
       }
     }
   }
