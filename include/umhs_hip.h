@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 3
+#define UMHS_ABI_VERSION 4
 
 enum {
   UMHS_OK = 0,
@@ -265,6 +265,21 @@ int umhs_ray_train_tail(const float* spectral, const float* M, const float* endm
                         float w_spectral, float w_rgb, int rgb_loss, float* rgb, float* depth_clipped, float* seg_probs,
                         float* seg_raw, float* seg_pred, float* losses2, float* d_spectral, float* d_accumulation,
                         void* scratch, size_t scratch_bytes, umhs_stream_t stream);
+
+/* umhs_ray_train_fused: the whole per-ray part of a TRAINING step in one launch = umhs_composite_fwd (all streams; stream 0 is   */
+/*   the spectral stream that carries the losses, umhs_model.py:245-304) + umhs_ray_train_tail (:254-313,358-370) +               */
+/*   umhs_composite_bwd of stream 0 incl. scale_gradients_by_distance_squared (:241-242).  Same arguments as those three; outputs  */
+/*   weights [N], accumulation [R], depth_raw [R] (optional, unclipped), every streams->out[s] [R,k_s], the tail's rgb /           */
+/*   depth_clipped / seg_*, losses2, and the gradients d_values0 [N,k_0], d_sigma [N], d_accumulation [R] (rgb_loss only).        */
+/*   scratch: umhs_ray_train_fused_scratch_bytes() bytes, ZERO before the first call (left zeroed again).  k_0 <= 256.           */
+size_t umhs_ray_train_fused_scratch_bytes(void);
+int umhs_ray_train_fused(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info, int64_t n_rays,
+                         int64_t n, const umhs_value_streams* streams, const float* M, const float* endmembers,
+                         const float* tmid_minmax2, const float* class_colors, const float* gt_spectral, const float* gt_rgb,
+                         const float* background, int n_classes, float alpha, float w_spectral, float w_rgb, int rgb_loss,
+                         int grad_scaling, float* weights, float* accumulation, float* depth_raw, float* rgb, float* depth_clipped,
+                         float* seg_probs, float* seg_raw, float* seg_pred, float* losses2, float* d_values0, float* d_sigma,
+                         float* d_accumulation, void* scratch, size_t scratch_bytes, umhs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* occupancy-grid ray marcher.  Replaces nerfacc.OccGridEstimator.sampling (traverse_grids +        */

@@ -1406,21 +1406,38 @@ __device__ __forceinline__ v4s pack_hi16(const v4f& v) {  // the four values ARE
   return __builtin_bit_cast(v4s, make_uint2(a, b));
 }
 
-// "samples on lanes" tile (4 registers: features 4q+r of a 16-feature tile, this lane's sample) -> swapped bf16 tile.
-// COLSUM: also adds this lane's share of the column sums (sum over its 4 samples; the 4 lane quarters are added by the reduce).
+// "samples on lanes" tiles (4 registers each: features 4q+r of a 16-feature tile, this lane's sample) -> swapped bf16 tiles.
+// NTILE tiles at once, in three phases -- split every value into its bf16 pieces (VALU), all 2*NTILE transposing MFMAs back to
+// back, then pack the results: with one wave per SIMD nothing else hides an MFMA's latency, so a tile-by-tile split -> MFMA ->
+// pack chain would stall on every tile (PMC of the first version: SQ_WAIT_INST_ANY 36-44 % of the wave cycles).
+// COLSUM: also adds each lane's share of the column sums (sum over its 4 samples; the 4 lane quarters are added by the reduce).
+template <int NTILE, bool COLSUM>
+__device__ __forceinline__ void to_swapped_n(STile* __restrict__ out, const float* __restrict__ x, const v4s& ident,
+                                             float* __restrict__ colsum = nullptr) {
+  v4s hi[NTILE], lo[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const short h = bf_bits(x[4 * t + r]);
+      hi[t][r] = h, lo[t][r] = bf_bits(x[4 * t + r] - bf_val(h));
+    }
+  const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+  v4f dh[NTILE], dl[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) dh[t] = MFMA_BF(hi[t], ident, z);
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) dl[t] = MFMA_BF(lo[t], ident, z);
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    if (COLSUM) colsum[t] += ((dh[t][0] + dh[t][1]) + (dh[t][2] + dh[t][3])) + ((dl[t][0] + dl[t][1]) + (dl[t][2] + dl[t][3]));
+    out[t].hi = pack_hi16(dh[t]), out[t].lo = pack_hi16(dl[t]);
+  }
+}
 template <bool COLSUM>
 __device__ __forceinline__ STile to_swapped(const float* __restrict__ x4, const v4s& ident, float* colsum = nullptr) {
-  v4s hi, lo;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const short h = bf_bits(x4[r]);
-    hi[r] = h, lo[r] = bf_bits(x4[r] - bf_val(h));
-  }
-  const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
-  const v4f dh = MFMA_BF(hi, ident, z), dl = MFMA_BF(lo, ident, z);
-  if (COLSUM) *colsum += ((dh[0] + dh[1]) + (dh[2] + dh[3])) + ((dl[0] + dl[1]) + (dl[2] + dl[3]));
   STile s;
-  s.hi = pack_hi16(dh), s.lo = pack_hi16(dl);
+  to_swapped_n<1, COLSUM>(&s, x4, ident, colsum);
   return s;
 }
 
@@ -1547,25 +1564,21 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       STile zS[4], xS[4];
       STile z1[1];
       z1[0] = to_swapped<true>(dzo[0], ident, db2);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xS[t] = to_swapped<false>(&a2[0][4 * t], ident);
+      to_swapped_n<4, false>(xS, a2[0], ident);
       dw_pairs<1, 4>(acc2, z1, xS);
       v4f g4[NT][4];
       gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
       float dz1[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dz1[0][4 * t], ident, db1 + t);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xS[t] = to_swapped<false>(&a1[0][4 * t], ident);
+      to_swapped_n<4, true>(zS, dz1[0], ident, db1);
+      to_swapped_n<4, false>(xS, a1[0], ident);
       dw_pairs<4, 4>(acc1, zS, xS);
       gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
       float dz0[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dz0[0][4 * t], ident, db0 + t);
+      to_swapped_n<4, true>(zS, dz0[0], ident, db0);
       dw_pairs<4, 2>(acc0, zS, x27S);
       gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
     };
@@ -1727,8 +1740,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       {
         STile z1[1], hS[4];
         z1[0] = to_swapped<true>(dzb1[0], ident, &db_[SL::D_B1 - DB0]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) hS[t] = to_swapped<false>(&h[0][4 * t], ident);
+        to_swapped_n<4, false>(hS, h[0], ident);
         dw_pairs<1, 4>(&acc_[SL::A_B1 - A0], z1, hS);
       }
       v4f g4[NT][4];
@@ -1738,10 +1750,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
       {
         STile zS[4], eS[2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) zS[t] = to_swapped<true>(&dzb0[0][4 * t], ident, &db_[SL::D_B0 - DB0 + t]);
-        eS[0] = to_swapped<false>(&encf[0][0], ident);  // column c = 4q'+u <-> hash feature 8q'+u
-        eS[1] = to_swapped<false>(&encf[0][4], ident);  //                    <-> hash feature 8q'+4+u
+        to_swapped_n<4, true>(zS, dzb0[0], ident, &db_[SL::D_B0 - DB0]);
+        to_swapped_n<2, false>(eS, encf[0], ident);  // column c = 4q'+u <-> hash feature 8q'+u ([0]) / 8q'+4+u ([1])
         dw_pairs<4, 2>(&acc_[SL::A_B0 - A0], zS, eS);
       }
       v4f de4[NT][2];

@@ -425,22 +425,29 @@ class UMHSModel(ModelBase):
             main.wait_event(ev_ready)
         fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
         values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
-        weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
         if side is None:
             mm = ops.tmid_minmax(t0, t1)
-        spectral = comp[0]
         M = _hip.f32c(self.converter.transform_matrix)
         hs, image = _hip.f32c(batch["hs_image"].to(self.device)), _hip.f32c(batch["image"].to(self.device))
         both = c.method == "rgb+spectral"
         bg = (background if background is not None else torch.rand_like(image)) if (both and self.background_color == "random") else None
         w = (5.0, float(c.rgb_loss_weight)) if both else (1.0, 0.0)
-        # ray epilogue + both losses + their backward down to d_spectral / d_accumulation: one launch
-        rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(
-            spectral, M, f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), hs, image if both else None, bg, 0.2,
-            w[0], w[1], both)
-        d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
-                                              bool(c.use_gradient_scaling))
-        left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_values[0], None,
+        if os.environ.get("UMHS_FUSED_RAY", "1") != "0" and L.wavelengths <= 256:
+            # everything that is local to a ray -- compositing forward, epilogue + losses + their backward, compositing backward -- in
+            # one launch (same arithmetic as the three kernels below; tests/test_hip_parity.py)
+            weights, acc, comp, rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spectral_samples, d_sigma = ops.ray_train_fused(
+                fo["sigma"], t0, t1, packed_info, values, M, f.endmembers.detach(), mm, _hip.f32c(self.class_colors), hs,
+                image if both else None, bg, 0.2, w[0], w[1], both, bool(c.use_gradient_scaling))
+        else:
+            weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
+            # ray epilogue + both losses + their backward down to d_spectral / d_accumulation: one launch
+            rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(
+                comp[0], M, f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), hs, image if both else None, bg, 0.2,
+                w[0], w[1], both)
+            d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
+                                                  bool(c.use_gradient_scaling))
+            d_spectral_samples = d_values[0]
+        left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_spectral_samples, None,
                                        prepared=prepared, feat_logits=fo["feat_logits"], hash_ready=ev_done if side is not None else None)
         assert left is None  # direct_step_supported() guarantees the sink owned this backward
         outputs = self._assemble_outputs(acc.view(-1, 1), depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights.view(-1, 1),
