@@ -1603,22 +1603,23 @@ struct FusedArgs {
   TailArgs tail;            // spec / acc / depth inputs are this kernel's own outputs (unused fields: spec, acc, depth, d_spec)
   float* d_values0;         // [N,B] gradient w.r.t. stream 0's per-sample values
   float* d_sigma;           // [N]
-  int grad_scaling, nblocks_partial;
+  int grad_scaling, nblocks_partial, kpad;
 };
 
-__global__ __launch_bounds__(256) void ray_train_fused_kernel(FusedArgs a) {
-  __shared__ float lds_tile[4][64 * 33 + 64];  // per wave: [64][33] value tile, 64 weights
-  __shared__ float srow[4][256], drow_s[4][256];  // per wave: the ray's composited spectrum and its gradient
+// (4 waves per SIMD: at 4096 rays every ray's wave is resident at once -- the kernel is one latency chain per ray, so a second round of
+// waves would double it; 128 VGPRs and <= 40 KiB of LDS per workgroup keep it at one)
+__global__ __launch_bounds__(256, 4) void ray_train_fused_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float fused_lds[];  // per wave: [64][33] value tile, 64 weights, 2 rows of kpad floats
   __shared__ float ee_inv[16];
   __shared__ float part[2][4];
   __shared__ bool last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15;
   const TailArgs& ta = a.tail;
   const int B = ta.B, C = ta.C;
-  float* const tile = lds_tile[wv];
+  float* const tile = fused_lds + wv * (64 * 33 + 64 + 2 * a.kpad);
   float* const wsl = tile + 64 * 33;
-  float* const sr = srow[wv];
-  float* const dr = drow_s[wv];
+  float* const sr = wsl + 64;       // the ray's composited spectrum
+  float* const dr = sr + a.kpad;    // ... and its gradient
   {  // 1 / max(||E_c||, 1e-12) once per block, 16 lanes per class (as ray_train_tail_kernel)
     const int grp = tid >> 4;
     float ee = 0.0f;
@@ -1928,7 +1929,9 @@ extern "C" int umhs_ray_train_fused(const float* sigma, const float* t_starts, c
   t.counter = reinterpret_cast<uint32_t*>(scratch), t.partial = reinterpret_cast<float*>(scratch) + 16;
   const int64_t blocks = (n_rays + 3) / 4;
   a.nblocks_partial = (int)(blocks < UMHS_FUSED_MAX_BLOCKS ? blocks : UMHS_FUSED_MAX_BLOCKS);
-  hipLaunchKernelGGL(ray_train_fused_kernel, dim3((unsigned)a.nblocks_partial), dim3(256), 0, umhs_s(stream), a);
+  a.kpad = (a.st.k[0] + 31) & ~31;
+  const size_t lds = (size_t)4 * (64 * 33 + 64 + 2 * a.kpad) * sizeof(float);  // 35.3 KiB at 31 bands, 39.9 KiB at 141
+  hipLaunchKernelGGL(ray_train_fused_kernel, dim3((unsigned)a.nblocks_partial), dim3(256), lds, umhs_s(stream), a);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }

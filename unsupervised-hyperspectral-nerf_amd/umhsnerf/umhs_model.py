@@ -432,9 +432,12 @@ class UMHSModel(ModelBase):
         both = c.method == "rgb+spectral"
         bg = (background if background is not None else torch.rand_like(image)) if (both and self.background_color == "random") else None
         w = (5.0, float(c.rgb_loss_weight)) if both else (1.0, 0.0)
-        if os.environ.get("UMHS_FUSED_RAY", "1") != "0" and L.wavelengths <= 256:
-            # everything that is local to a ray -- compositing forward, epilogue + losses + their backward, compositing backward -- in
-            # one launch (same arithmetic as the three kernels below; tests/test_hip_parity.py)
+        if os.environ.get("UMHS_FUSED_RAY", "0") == "1" and L.wavelengths <= 256:
+            # Everything that is local to a ray -- compositing forward, epilogue + losses + their backward, compositing backward -- in
+            # one launch (umhs_ray_train_fused; equal to the three kernels below, tests/test_hip_trajectory.py).  Measured at C2 on one
+            # MI355X, A/B/A/B in one session: 0.966 / 0.967 ms per step fused vs 0.934 / 0.936 with the three kernels.  Each of the three
+            # is already ONE latency chain per ray with every ray's wave resident (4 per SIMD); fused, the chains add up in one wave
+            # (and the tail's 16-lane group leaves 48 lanes idle), so the two saved launches buy nothing.  Kept as an opt-in.
             weights, acc, comp, rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spectral_samples, d_sigma = ops.ray_train_fused(
                 fo["sigma"], t0, t1, packed_info, values, M, f.endmembers.detach(), mm, _hip.f32c(self.class_colors), hs,
                 image if both else None, bg, 0.2, w[0], w[1], both, bool(c.use_gradient_scaling))
