@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Hash-grid gather alone on the bench batch's positions (C2: 4096 rays x 64 samples) and on uniform random ones.  GPU box."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd")]
+import torch
+import bench
+from umhsnerf import ops
+dev = torch.device("cuda", 0)
+layout = ops.FieldLayout(6, 31, True, 19)
+flat = ((torch.rand(layout.total) - 0.5) * 0.5).to(dev)
+fs = ops.FieldSpec(layout, 0.4, True, scalings=ops.hash_scalings().to(dev))
+b = bench.synthetic_batch(4096, 64, 31, seed=42, device=dev)
+_, pos_ray, _ = ops.positions_fwd(b["origins"], b["directions"], b["starts"].view(-1), b["ends"].view(-1), fs)
+table = layout.view(flat, "mlp_base.encoder.hash_table")
+for name, pos in (("ray batch", pos_ray), ("uniform", torch.rand(262144, 3, device=dev))):
+    for _ in range(3):
+        ops.hashgrid_fwd(pos, table, fs.scalings, 19, True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        ops.hashgrid_fwd(pos, table, fs.scalings, 19, True)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"UMHS_HG_LPT={os.environ.get('UMHS_HG_LPT', '1')} {name:10s}: hashgrid_fwd {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us", flush=True)

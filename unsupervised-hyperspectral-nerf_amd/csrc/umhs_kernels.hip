@@ -2,6 +2,8 @@
 // multires hash-grid encode fwd/bwd (R2), packed transmittance + per-ray band accumulation fwd/bwd
 // (R11-R13), spectrum->sRGB fwd/bwd (R14) and the fused Adam step.  The MFMA field kernels live in
 // umhs_field.hip.  Reference citations are in include/umhs_hip.h.
+#include <cstdlib>
+
 #include "umhs_common.h"
 #include <atomic>
 
@@ -79,26 +81,35 @@ extern "C" int umhs_positions_fwd(const float* origins, const float* directions,
 // level-major and the resident waves of an XCD gather from one 4 MiB level slab (= one XCD L2) at
 // a time instead of from the whole 64 MiB table.
 // =============================================================================================
+template <int LPT>  // levels per thread: blockIdx.y covers levels [LPT*y, LPT*y + LPT); all their gathers are in flight together
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restrict__ pos01,
                                                            const float2* __restrict__ table,
-                                                           const float* __restrict__ scalings, int64_t n,
+                                                           const float* __restrict__ scalings, int64_t n, int n_levels,
                                                            int log2_T, float* __restrict__ enc, int64_t stride_n,
                                                            int64_t stride_l) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  int l = blockIdx.y;
-  float s = scalings[l];
-  HashCorners h = hash_corners(pos01[3 * i], pos01[3 * i + 1], pos01[3 * i + 2], s, (1u << log2_T) - 1u,
-                               (uint32_t)l << log2_T);
-  float2 f[8];
-  hash_gather8(table, h, f);
-  const float2 r = hash_trilerp(f, h.ox, h.oy, h.oz);
-  const float out[2] = {r.x, r.y};
-  float* o = enc + i * stride_n + (int64_t)l * stride_l;
-  if (((stride_n | stride_l) & 1) == 0) {
-    *reinterpret_cast<float2*>(o) = make_float2(out[0], out[1]);
-  } else {
-    o[0] = out[0], o[1] = out[1];
+  const float px = pos01[3 * i], py = pos01[3 * i + 1], pz = pos01[3 * i + 2];
+  float2 f[LPT][8];
+  float off[LPT][3];
+#pragma unroll
+  for (int k = 0; k < LPT; ++k) {
+    const int l = min((int)blockIdx.y * LPT + k, n_levels - 1);
+    const HashCorners h = hash_corners(px, py, pz, scalings[l], (1u << log2_T) - 1u, (uint32_t)l << log2_T);
+    off[k][0] = h.ox, off[k][1] = h.oy, off[k][2] = h.oz;
+    hash_gather8(table, h, f[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < LPT; ++k) {
+    const int l = (int)blockIdx.y * LPT + k;
+    if (l >= n_levels) break;
+    const float2 r = hash_trilerp(f[k], off[k][0], off[k][1], off[k][2]);
+    float* o = enc + i * stride_n + (int64_t)l * stride_l;
+    if (((stride_n | stride_l) & 1) == 0) {
+      *reinterpret_cast<float2*>(o) = r;
+    } else {
+      o[0] = r.x, o[1] = r.y;
+    }
   }
 }
 
@@ -109,9 +120,23 @@ extern "C" int umhs_hashgrid_fwd(const float* pos01, const float* table, const f
   if (n_levels < 1 || n_levels > 32 || log2_T < 1 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
   if (((uintptr_t)table & 15) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;  // (16-byte slot pairs are fetched with one load)
   if (n == 0) return UMHS_OK;
-  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
-  hipLaunchKernelGGL(hashgrid_fwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01,
-                     reinterpret_cast<const float2*>(table), scalings, n, log2_T, enc, stride_n, stride_l);
+  // Levels per thread (tuning knob UMHS_HG_LPT): 2 shares the position loads / address set-up between two levels and doubles the
+  // gathers in flight per thread at half the threads.  Measured on one MI355X at C2 (tools/bench_field.py): see DESIGN.md section 5.
+  static const int lpt = getenv("UMHS_HG_LPT") ? atoi(getenv("UMHS_HG_LPT")) : 1;
+  const float2* t2 = reinterpret_cast<const float2*>(table);
+  if (lpt == 2) {
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n_levels + 1) / 2));
+    hipLaunchKernelGGL(hashgrid_fwd_kernel<2>, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n,
+                       stride_l);
+  } else if (lpt == 4) {
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n_levels + 3) / 4));
+    hipLaunchKernelGGL(hashgrid_fwd_kernel<4>, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n,
+                       stride_l);
+  } else {
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
+    hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n,
+                       stride_l);
+  }
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
