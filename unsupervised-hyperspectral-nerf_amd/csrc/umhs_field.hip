@@ -1583,6 +1583,16 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
     };
     if constexpr (PART == 0) {
+      // This tile's upstream gradients, all band tiles: requested here, consumed after the head MLP's forward recompute (with one
+      // wave per SIMD a load issued next to its use costs its whole latency: one band tile ahead was 585 us at 128 bands)
+      float dall[TBMAX][4];
+#pragma unroll
+      for (int t = 0; t < TBMAX; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = 16 * t + 4 * q + r;
+          dall[t][r] = (t < TB && ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
+        }
       // =================== forward recompute: head MLP, directional hidden layer (feature logits come from the forward) ===
 #pragma unroll
       for (int r = 0; r < 4; ++r) in27[0][3 + r] = cur.emb[r];
@@ -1628,23 +1638,13 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       float ds1 = 0.0f;
-      auto load_dsp = [&](int t, float(&g)[4]) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = 16 * t + 4 * q + r;
-          g[r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
-        }
-      };
-      float dnext[4];
-      load_dsp(0, dnext);
 #pragma unroll
       for (int t = 0; t < TBMAX; ++t) {
         if (TBMAX > 2) __builtin_amdgcn_sched_barrier(0);  // band tiles one after the other: hoisting across them only spills
         if (t < TB) {
           float dsp[NT][4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dsp[0][r] = dnext[r];
-          if (t + 1 < TB) load_dsp(t + 1, dnext);
+          for (int r = 0; r < 4; ++r) dsp[0][r] = dall[t][r];
           gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
           STile dspS[1];
           dspS[0] = to_swapped<false>(dsp[0], ident);
@@ -1823,22 +1823,40 @@ __device__ __forceinline__ int tf_col(int kind, int ti, int c) {
   }
 }
 
-__global__ __launch_bounds__(256) void field_reduce_tf_kernel(const float* __restrict__ slabs, int nslabs, TfMap mp,
-                                                                   PackDesc pd, GradPtrs gp) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+// 64 outputs per workgroup; its 8 waves each sum an eighth of the slabs (8 loads in flight), LDS combines (one thread per output
+// walking all 256 slabs was 82 us at 128 bands: 90 workgroups of serial loads)
+__global__ __launch_bounds__(512) void field_reduce_tf_kernel(const float* __restrict__ slabs, int nslabs, TfMap mp, PackDesc pd,
+                                                              GradPtrs gp) {
+  __shared__ float part[8][64];
+  const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   const int nw = mp.nacc * 256, nb = mp.ndb * 16;
   const size_t stride = (size_t)mp.nitems * 256;
-  if (e < nw) {
-    float a[8];
+  const int per = (nslabs + 7) / 8, w0 = pw * per, w1 = min(nslabs, w0 + per);
+  float a[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = 0.0f;
-    int w = 0;
-    for (; w + 7 < nslabs; w += 8) {
+  for (int k = 0; k < 8; ++k) a[k] = 0.0f;
+  if (e < nw) {
+    int w = w0;
+    for (; w + 7 < w1; w += 8) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) a[k] += slabs[(size_t)(w + k) * stride + e];
     }
-    for (; w < nslabs; ++w) a[0] += slabs[(size_t)w * stride + e];
-    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (; w < w1; ++w) a[0] += slabs[(size_t)w * stride + e];
+  } else if (e < nw + nb) {
+    const int k = e - nw, T = k >> 4, c = k & 15;  // bias tile T (slot in db[]), column c: sum over slabs and the 4 lane quarters
+    const size_t off = (size_t)(mp.nacc + (T >> 2)) * 256 + (T & 3);
+    for (int w = w0; w < w1; ++w) {
+      const float* p = slabs + (size_t)w * stride + off;
+      a[w & 7] += (p[(c)*4] + p[(16 + c) * 4]) + (p[(32 + c) * 4] + p[(48 + c) * 4]);
+    }
+  }
+  part[pw][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (pw != 0 || e >= nw + nb) return;
+  const float s = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+                  ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
+  if (e < nw) {
     const int item = e >> 8, rel = e & 255, r = rel & 3, ln = rel >> 2;
     const int l = mp.layer[item];
     if (l < 0) return;
@@ -1851,16 +1869,10 @@ __global__ __launch_bounds__(256) void field_reduce_tf_kernel(const float* __res
     }
     const int in = tf_col(L.kind, mp.ti[item], ln & 15);
     if (out < L.OUT && in >= 0 && in < L.IN && gp.W[l]) gp.W[l][(size_t)out * L.IN + in] = s;
-  } else if (e < nw + nb) {
-    const int k = e - nw, T = k >> 4, c = k & 15;  // bias tile T (slot in db[]), column c: sum over slabs and the 4 lane quarters
+  } else {
+    const int k = e - nw, T = k >> 4, c = k & 15;
     const int l = mp.db_layer[T];
     if (l < 0) return;
-    const size_t off = (size_t)(mp.nacc + (T >> 2)) * 256 + (T & 3);
-    float s = 0.0f;
-    for (int w = 0; w < nslabs; ++w) {
-      const float* p = slabs + (size_t)w * stride + off;
-      s += (p[(c)*4] + p[(16 + c) * 4]) + (p[(32 + c) * 4] + p[(48 + c) * 4]);
-    }
     const int o = 16 * mp.db_tile[T] + c;
     if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
   }
@@ -2407,7 +2419,7 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], FieldIO io, boo
   TfMap mp;
   fill_tf_map<TBMAX>(&mp, spec, pl.TB);
   const int items = SL::NACC * 256 + SL::NDB * 16;
-  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3((items + 255) / 256), dim3(256), 0, umhs_s(stream), (const float*)slabs, (int)grid, mp,
+  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3((items + 63) / 64), dim3(512), 0, umhs_s(stream), (const float*)slabs, (int)grid, mp,
                      pl.pd_all, gp);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
