@@ -1634,18 +1634,17 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         }
       }
       // =================== band tiles: mixing and the specular tail (the next tile's gradients are requested a tile ahead) ===
-      v4f dm4[NT][1], dhd4[NT][1];
-      dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      // (two accumulators each for d m and d hdir, even / odd band tiles: consecutive tiles do not wait for each other's MFMAs)
+      v4f dm4[NT][1], dhd4[NT][1], dm4b[NT][1], dhd4b[NT][1];
+      dm4[0][0] = dhd4[0][0] = dm4b[0][0] = dhd4b[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       float ds1 = 0.0f;
 #pragma unroll
       for (int t = 0; t < TBMAX; ++t) {
-        if (TBMAX > 2) __builtin_amdgcn_sched_barrier(0);  // band tiles one after the other: hoisting across them only spills
         if (t < TB) {
           float dsp[NT][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) dsp[0][r] = dall[t][r];
-          gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+          gemm_pack<1, 4, NT, 0>((t & 1) ? dm4b : dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
           STile dspS[1];
           dspS[0] = to_swapped<false>(dsp[0], ident);
           dw_pairs<1, 1>(&acc_[SL::A_MX - A0 + t], dspS, mS);  // dE^T[b][c] += sum_n d_spectral[n][b] m[n][c]
@@ -1659,7 +1658,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
               ds1 += dsp[0][r] * sp;
               dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
             }
-            gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
+            gemm_pack<1, 4, NT, 0>((t & 1) ? dhd4b : dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
             STile dzdS[1];
             dzdS[0] = to_swapped<true>(dzd[0], ident, &db_[SL::D_D1 - DB0 + t]);
             dw_pairs<1, 1>(&acc_[SL::A_D1 - A0 + t], dzdS, hdirS);
@@ -1667,6 +1666,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         }
       }
       ds1 = xq_sum(ds1);
+      dm4[0][0] += dm4b[0][0], dhd4[0][0] += dhd4b[0][0];
       // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
       float dhs[NT][4], dfl[NT][4];
       {
@@ -1823,16 +1823,16 @@ __device__ __forceinline__ int tf_col(int kind, int ti, int c) {
   }
 }
 
-// 64 outputs per workgroup; its 8 waves each sum an eighth of the slabs (8 loads in flight), LDS combines (one thread per output
+// 64 outputs per workgroup; its 16 waves each sum a sixteenth of the slabs (8 loads in flight), LDS combines (one thread per output
 // walking all 256 slabs was 82 us at 128 bands: 90 workgroups of serial loads)
-__global__ __launch_bounds__(512) void field_reduce_tf_kernel(const float* __restrict__ slabs, int nslabs, TfMap mp, PackDesc pd,
+__global__ __launch_bounds__(1024) void field_reduce_tf_kernel(const float* __restrict__ slabs, int nslabs, TfMap mp, PackDesc pd,
                                                               GradPtrs gp) {
-  __shared__ float part[8][64];
+  __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
   const int nw = mp.nacc * 256, nb = mp.ndb * 16;
   const size_t stride = (size_t)mp.nitems * 256;
-  const int per = (nslabs + 7) / 8, w0 = pw * per, w1 = min(nslabs, w0 + per);
+  const int per = (nslabs + 15) / 16, w0 = pw * per, w1 = min(nslabs, w0 + per);
   float a[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) a[k] = 0.0f;
@@ -1854,8 +1854,9 @@ __global__ __launch_bounds__(512) void field_reduce_tf_kernel(const float* __res
   part[pw][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   if (pw != 0 || e >= nw + nb) return;
-  const float s = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
-                  ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) s += (part[k][lane] + part[k + 1][lane]) + (part[k + 2][lane] + part[k + 3][lane]);
   if (e < nw) {
     const int item = e >> 8, rel = e & 255, r = rel & 3, ln = rel >> 2;
     const int l = mp.layer[item];
@@ -2419,7 +2420,7 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], FieldIO io, boo
   TfMap mp;
   fill_tf_map<TBMAX>(&mp, spec, pl.TB);
   const int items = SL::NACC * 256 + SL::NDB * 16;
-  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3((items + 63) / 64), dim3(512), 0, umhs_s(stream), (const float*)slabs, (int)grid, mp,
+  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3((items + 63) / 64), dim3(1024), 0, umhs_s(stream), (const float*)slabs, (int)grid, mp,
                      pl.pd_all, gp);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
@@ -2509,12 +2510,12 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
     for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
   }
   // ---- transpose-free kernels (default; they need the forward's feature logits like the split kernels below) ---------------
-  // Measured (tools/bench_fbwd.py, one MI355X): 128 bands 951 vs 1454 us, 141 bands 895 vs 1243 us for the LDS-staged kernels below
-  // (whose fused heads kernel spills and keeps its transposed packs in L2 at B > 32); at B <= 32 the split LDS-staged kernels, two
-  // waves per SIMD, are still ahead (351 vs 392 us), so the default is: transpose-free above 32 bands.  UMHS_BWD_TF=1 / 0 forces.
-  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : -1;
+  // Measured (tools/bench_fbwd.py, one MI355X, whole backward): C2 328 vs 351 us, 128 bands 833 vs 1454 us, 141 bands 660 vs 1243 us
+  // for the LDS-staged kernels below (whose fused heads kernel spills and keeps its transposed packs in L2 above 32 bands); in the
+  // full C2 step 0.903 / 0.908 vs 0.917 / 0.916 ms (A/B/A/B).  UMHS_BWD_TF=0 forces the staged kernels.
+  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : 1;
   const int tbmax = tf_tbmax(pl.TB);
-  const bool want_tf = tf_mode < 0 ? pl.TB > 2 : tf_mode != 0;
+  const bool want_tf = tf_mode != 0;
   if (want_tf && feat_logits != nullptr && tbmax != 0) {
     TfPart part[2];
     if (tf_part(pl, 0, &part[0]) && tf_part(pl, 1, &part[1])) {
