@@ -183,3 +183,24 @@ def test_eval_image_path_and_metrics():
     assert md2["num_rays"] == 24 * 32 and np.isfinite(list(md2.values())).all()
     _, loss_dict, metrics = pipe.get_eval_loss_dict(0)
     assert np.isfinite(float(sum(loss_dict.values()))) and pipe.training
+
+
+def test_host_resident_stacks_give_the_same_batches():
+    """--pipeline.datamanager.images-on-gpu False (scripts/pinecone.sh:14, rgb+spectral.sh:15): the stacks stay in host memory and only
+    the batch rows travel; same indices, same rows, same rays as the device-resident stacks (fp32 and uint8 images)."""
+    from umhsnerf.data.umhs_datamanager import ResidentSplit, UMHSDataManager, UMHSDataManagerConfig
+
+    dev_split, rgb, hs, _ = _split(n=5, B=21, seed=9)
+    for img in (rgb, (rgb * 255).to(torch.uint8)):
+        a = ResidentSplit(dev_split.cameras, img, hs, DEV, on_gpu=True)
+        b = ResidentSplit(dev_split.cameras, img, hs, DEV, on_gpu=False)
+        assert not b.image.is_cuda and not b.hs_image.is_cuda and a.image.is_cuda
+        dma = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=777), device=DEV, seed=4, train=a)
+        dmb = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=777, images_on_gpu=False), device=DEV, seed=4, train=b)
+        for step in range(3):
+            (ra, ba), (rb, bb) = dma.next_train(step), dmb.next_train(step)
+            assert torch.equal(ba["indices"], bb["indices"]) and torch.equal(ra.origins, rb.origins) and torch.equal(ra.directions, rb.directions)
+            assert bb["image"].is_cuda and torch.equal(ba["image"], bb["image"]) and torch.equal(ba["hs_image"], bb["hs_image"])
+        ca, fa = dma.next_eval_image(0)
+        cb, fb = dmb.next_eval_image(0)
+        assert torch.equal(fa["hs_image"], fb["hs_image"]) and fb["image"].is_cuda and torch.equal(ca.directions, cb.directions)

@@ -40,14 +40,18 @@ class _DatasetView:
 
 
 class ResidentSplit:
-    """One split: cameras + contiguous [n,H,W,K] stacks on the device."""
+    """One split: cameras + contiguous [n,H,W,K] stacks -- on the device (``--images-on-gpu True``, scripts/hotdog.sh:8: the batch
+    rows are gathered by ``umhs_pixel_gather``), or in host memory (``False``, scripts/pinecone.sh:14: the rows of a batch are indexed
+    on the host, as the reference's dataloader does, and only they travel to the device)."""
 
-    def __init__(self, cameras: Cameras, image: torch.Tensor, hs_image: Optional[torch.Tensor], device):
+    def __init__(self, cameras: Cameras, image: torch.Tensor, hs_image: Optional[torch.Tensor], device, on_gpu: bool = True):
+        self.device, self.on_gpu = torch.device(device), on_gpu
         self.cameras = cameras.to(device)
         self.c2w = self.cameras.camera_to_worlds.float().contiguous()
         self.intrinsics = self.cameras.intrinsics
-        self.image = image.to(device).contiguous()
-        self.hs_image = hs_image.to(device).contiguous() if hs_image is not None else None
+        place = (lambda t: t.to(device).contiguous()) if on_gpu else (lambda t: t.cpu().contiguous())
+        self.image = place(image)
+        self.hs_image = place(hs_image) if hs_image is not None else None
         n, h, w = self.image.shape[:3]
         if (h, w) != (cameras.height, cameras.width) or n != len(cameras):
             raise ValueError(f"stack {tuple(self.image.shape)} does not match {n} cameras of {cameras.height}x{cameras.width}")
@@ -57,14 +61,23 @@ class ResidentSplit:
 
     def sample(self, num_rays: int, generator=None) -> Tuple[RayBundle, Dict]:
         n, h, w = self.image.shape[:3]
-        u = torch.rand((num_rays, 3), device=self.image.device, generator=generator)
+        u = torch.rand((num_rays, 3), device=self.device, generator=generator)
         indices = ops.pixel_indices(u, n, h, w)
         return self.rays(indices), self.batch(indices)
 
+    def _rows(self, indices: torch.Tensor, stack: torch.Tensor) -> torch.Tensor:
+        if self.on_gpu:
+            return ops.pixel_gather(indices, stack)
+        n, h, w = stack.shape[:3]
+        i = indices.cpu()  # same clamping as umhs_pixel_gather (a uniform draw of exactly 1.0 rounds up to the extent)
+        rows = stack[i[:, 0].clamp(0, n - 1), i[:, 1].clamp(0, h - 1), i[:, 2].clamp(0, w - 1)]
+        rows = rows.float() / 255.0 if stack.dtype == torch.uint8 else rows.float()
+        return rows.to(self.device, non_blocking=True)
+
     def batch(self, indices: torch.Tensor) -> Dict:
-        b = {"image": ops.pixel_gather(indices, self.image), "indices": indices}
+        b = {"image": self._rows(indices, self.image), "indices": indices}
         if self.hs_image is not None:
-            b["hs_image"] = ops.pixel_gather(indices, self.hs_image)
+            b["hs_image"] = self._rows(indices, self.hs_image)
         return b
 
     def rays(self, indices: torch.Tensor) -> RayBundle:
@@ -75,7 +88,7 @@ class ResidentSplit:
     def image_rays(self, camera_index: int) -> RayBundle:
         """``cameras.generate_rays(camera_indices=i, keep_shape=True)``: one ray per pixel, [H,W,...]."""
         _, h, w = self.image.shape[:3]
-        dev = self.image.device
+        dev = self.device
         yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
         idx = torch.stack([torch.full_like(yy, camera_index), yy, xx], -1).reshape(-1, 3).contiguous()
         rb = self.rays(idx)
@@ -90,8 +103,6 @@ class UMHSDataManager:
     def __init__(self, config: UMHSDataManagerConfig, device="cpu", test_mode: str = "val", world_size: int = 1, local_rank: int = 0,
                  num_classes: int = 5, seed: int = 42, train: Optional[ResidentSplit] = None, eval: Optional[ResidentSplit] = None,
                  metadata: Optional[Dict] = None, **kwargs):
-        if not config.images_on_gpu:
-            raise NotImplementedError("the gather kernels read resident stacks: images_on_gpu must be True (scripts/hotdog.sh:8)")
         if config.patch_size != 1:
             raise NotImplementedError("patch_size > 1 (PatchPixelSampler) is not used by the reference's scripts")
         self.config, self.device, self.world_size, self.local_rank = config, torch.device(device), world_size, local_rank
@@ -100,11 +111,11 @@ class UMHSDataManager:
             parser = config.dataparser.setup()
             self.train_dataparser_outputs: DataparserOutputs = parser.get_dataparser_outputs("train")
             tr = HyperspectralDataset(self.train_dataparser_outputs)
-            train = ResidentSplit(tr.cameras, tr.image, tr.hs_image, self.device)
+            train = ResidentSplit(tr.cameras, tr.image, tr.hs_image, self.device, on_gpu=config.images_on_gpu)
             ev_out = parser.get_dataparser_outputs("val" if test_mode != "test" else "test")
             if len(ev_out.image_filenames):
                 ev = HyperspectralDataset(ev_out)
-                eval = ResidentSplit(ev.cameras, ev.image, ev.hs_image, self.device)
+                eval = ResidentSplit(ev.cameras, ev.image, ev.hs_image, self.device, on_gpu=config.images_on_gpu)
             metadata = self.train_dataparser_outputs.metadata
             self.scene_box = self.train_dataparser_outputs.scene_box
         self.train_split, self.eval_split, self.metadata = train, eval, metadata or {}
@@ -141,7 +152,7 @@ class UMHSDataManager:
         split = self.eval_split or self.train_split
         i = self._eval_cursor % len(split)
         self._eval_cursor += 1
-        batch = {"image": split.image[i], "image_idx": i}
+        batch = {"image": split.image[i].to(self.device), "image_idx": i}
         if split.hs_image is not None:
-            batch["hs_image"] = split.hs_image[i]
+            batch["hs_image"] = split.hs_image[i].to(self.device)
         return split.image_rays(i), batch
