@@ -1441,22 +1441,65 @@ __device__ __forceinline__ STile to_swapped(const float* __restrict__ x4, const 
   return s;
 }
 
-// acc[to * TI + ti] += Z[to]^T X[ti]  (three bf16 products per tile pair; the passes run over all pairs so that no MFMA waits
-// for the one before it on the same accumulator)
+// acc[to * TI + ti] += Z[to]^T X[ti]: three bf16 products per tile pair (hi*hi, hi*lo, lo*hi), the passes run over the ti's of a row so
+// that no MFMA waits for the one before it on the same accumulator.
+// These MFMAs are written as inline asm with the accumulators constrained to AGPRs ("+a"), and this file is compiled with
+// -amdgpu-mfma-vgpr-form: a kernel whose register budget exceeds 256 otherwise gets the AGPR form of EVERY MFMA, and each result the
+// VALU touches (every ReLU input, every transposed tile: 516 of the 2,066 instructions of part 1's loop) is first copied out of the
+// accumulator file with v_accvgpr_read.  With the flag the builtin MFMAs (fp32 chain, transposes) write VGPRs; only the dW
+// accumulators, which nothing but these MFMAs touches until the end of the launch, live in AGPRs.
+// Hazards the compiler cannot see inside the string: the A / B operands come out of v_perm_b32 (VALU write -> MFMA read: 2 wait
+// states = the leading s_nop 1); an MFMA accumulating onto the previous one's D needs none; D is next read by v_accvgpr_read after
+// the loop.
+template <int TI>
+__device__ __forceinline__ void dw_row(v4f* __restrict__ acc, const STile& z, const STile* __restrict__ X);
+template <>
+__device__ __forceinline__ void dw_row<1>(v4f* __restrict__ acc, const STile& z, const STile* __restrict__ X) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %1, %3, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %1, %4, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %2, %3, %0"
+      : "+a"(acc[0])
+      : "v"(z.hi), "v"(z.lo), "v"(X[0].hi), "v"(X[0].lo));
+}
+template <>
+__device__ __forceinline__ void dw_row<2>(v4f* __restrict__ acc, const STile& z, const STile* __restrict__ X) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %2, %4, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %1, %2, %6, %1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %2, %5, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %1, %2, %7, %1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %3, %4, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %1, %3, %6, %1"
+      : "+a"(acc[0]), "+a"(acc[1])
+      : "v"(z.hi), "v"(z.lo), "v"(X[0].hi), "v"(X[0].lo), "v"(X[1].hi), "v"(X[1].lo));
+}
+template <>
+__device__ __forceinline__ void dw_row<4>(v4f* __restrict__ acc, const STile& z, const STile* __restrict__ X) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %4, %6, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %1, %4, %8, %1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %2, %4, %10, %2\n\t"
+      "v_mfma_f32_16x16x16_bf16 %3, %4, %12, %3\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %4, %7, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %1, %4, %9, %1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %2, %4, %11, %2\n\t"
+      "v_mfma_f32_16x16x16_bf16 %3, %4, %13, %3\n\t"
+      "v_mfma_f32_16x16x16_bf16 %0, %5, %6, %0\n\t"
+      "v_mfma_f32_16x16x16_bf16 %1, %5, %8, %1\n\t"
+      "v_mfma_f32_16x16x16_bf16 %2, %5, %10, %2\n\t"
+      "v_mfma_f32_16x16x16_bf16 %3, %5, %12, %3"
+      : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3])
+      : "v"(z.hi), "v"(z.lo), "v"(X[0].hi), "v"(X[0].lo), "v"(X[1].hi), "v"(X[1].lo), "v"(X[2].hi), "v"(X[2].lo), "v"(X[3].hi),
+        "v"(X[3].lo));
+}
 template <int TO, int TI>
 __device__ __forceinline__ void dw_pairs(v4f* __restrict__ acc, const STile (&Z)[TO], const STile (&X)[TI]) {
 #pragma unroll
-  for (int to = 0; to < TO; ++to)
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti) acc[to * TI + ti] = MFMA_BF(Z[to].hi, X[ti].hi, acc[to * TI + ti]);
-#pragma unroll
-  for (int to = 0; to < TO; ++to)
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti) acc[to * TI + ti] = MFMA_BF(Z[to].hi, X[ti].lo, acc[to * TI + ti]);
-#pragma unroll
-  for (int to = 0; to < TO; ++to)
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti) acc[to * TI + ti] = MFMA_BF(Z[to].lo, X[ti].hi, acc[to * TI + ti]);
+  for (int to = 0; to < TO; ++to) dw_row<TI>(acc + to * TI, Z[to], X);
 }
 
 // accumulator / bias-sum slots of a wave (items of 64 lanes x 4 floats; the slab keeps this order).  Part 0 owns the accumulator

@@ -11,6 +11,9 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libumhs_hip.so")
 SOURCES = ("umhs_kernels.hip", "umhs_field.hip", "umhs_sampler.hip", "umhs_data.hip", "umhs_metrics.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-munsafe-fp-atomics", "-std=c++17"]
+# umhs_field.hip: MFMAs written as builtins get the VGPR C/D form even in the kernels whose register budget exceeds 256 (the
+# transpose-free backward); their long-lived dW accumulators are inline-asm MFMAs on AGPRs (see dw_row in that file)
+EXTRA_FLAGS = {"umhs_field.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale() -> bool:
@@ -29,7 +32,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
