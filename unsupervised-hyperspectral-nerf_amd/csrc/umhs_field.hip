@@ -203,13 +203,23 @@ __device__ __forceinline__ void relu_to(float (&x)[NT][OT * 4], const v4f (&acc)
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoidf_(float x) { return frcp(1.0f + fexp(-x)); }
+// Reductions over the 4 lane quarters (lanes l, l^16, l^32, l^48).  gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd
+// 16-lane rows (resp. the upper 32 lanes) of one operand with the even rows (lower half) of the other: called with v for both,
+// the two results are v's even-row and odd-row (lower / upper half) copies, i.e. {v, v from the partner quarter} in every lane --
+// pure VALU, where __shfl_xor compiles to ds_bpermute_b32 and pays an LDS round trip (9 of them per tile of the backward, with
+// nothing else on the SIMD to cover them).  Same values, same association as the shuffles they replace.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float xq_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  v2u a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
 }
 __device__ __forceinline__ float xq_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  v2u a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
 __device__ __forceinline__ float sel4(const v4f& v, int r) { return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3])); }
 
