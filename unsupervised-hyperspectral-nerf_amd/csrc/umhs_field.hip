@@ -1408,8 +1408,25 @@ __device__ __forceinline__ v4s ident_frag(int lane) {  // B operand of the trans
   for (int u = 0; u < 4; ++u) f[u] = ((c >> 2) == q && (c & 3) == u) ? (short)0x3F80 : (short)0;
   return f;
 }
-__device__ __forceinline__ short bf_bits(float x) { return __builtin_bit_cast(short, (__bf16)x); }  // round to nearest even
-__device__ __forceinline__ float bf_val(short h) { return __uint_as_float(((uint32_t)(uint16_t)h) << 16); }
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+// two floats -> their bf16 roundings (nearest even) in one dword (v_cvt_pk_bf16_f32), low half = a
+__device__ __forceinline__ uint32_t cvt_pk_bf(float a, float b) {
+  const v2f v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v2bf));
+}
+// (x0, x1) -> packed bf16 pieces: h = rne(x), m = rne(x - h) [, l = rne(x - h - m)]; the subtractions are exact.  The transposes of
+// the dW operands and the chain's three-piece products call this on the same registers: the compiler keeps one computation.
+__device__ __forceinline__ void bf_split_pair(float x0, float x1, uint32_t& h, uint32_t& m, float& r0, float& r1) {
+  h = cvt_pk_bf(x0, x1);
+  r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf(r0, r1);
+}
+__device__ __forceinline__ void bf_split_pair3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  float r0, r1;
+  bf_split_pair(x0, x1, h, m, r0, r1);
+  l = cvt_pk_bf(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
 __device__ __forceinline__ v4s pack_hi16(const v4f& v) {  // the four values ARE bf16 numbers: keep their upper halves
   const uint32_t a = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
   const uint32_t b = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
@@ -1426,12 +1443,13 @@ __device__ __forceinline__ void to_swapped_n(STile* __restrict__ out, const floa
                                              float* __restrict__ colsum = nullptr) {
   v4s hi[NTILE], lo[NTILE];
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t)
+  for (int t = 0; t < NTILE; ++t) {
+    uint32_t h[2], m[2];
+    float r0, r1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const short h = bf_bits(x[4 * t + r]);
-      hi[t][r] = h, lo[t][r] = bf_bits(x[4 * t + r] - bf_val(h));
-    }
+    for (int e = 0; e < 2; ++e) bf_split_pair(x[4 * t + 2 * e], x[4 * t + 2 * e + 1], h[e], m[e], r0, r1);
+    hi[t] = __builtin_bit_cast(v4s, make_uint2(h[0], h[1])), lo[t] = __builtin_bit_cast(v4s, make_uint2(m[0], m[1]));
+  }
   const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
   v4f dh[NTILE], dl[NTILE];
 #pragma unroll
@@ -1512,6 +1530,107 @@ __device__ __forceinline__ void dw_pairs(v4f* __restrict__ acc, const STile (&Z)
   for (int to = 0; to < TO; ++to) dw_row<TI>(acc + to * TI, Z[to], X);
 }
 
+// ---- the exact fp32 chain on the bf16 MFMA: x = hi + mid + lo (three bf16 pieces, |x - hi - mid - lo| <= 2^-25 |x|), a product
+// a*b = hh + hm + mh + hl + lh + mm (the three terms left out are <= 2^-24 |ab|: fp32's own rounding), exact bf16 products,
+// fp32 accumulation.  v_mfma_f32_16x16x32_bf16 issues in half the cycles of v_mfma_f32_16x16x4_f32 for 8x its K, so a 64-wide
+// layer costs 12 bf16 MFMAs per output tile instead of 16 fp32 ones at half the cycles each: 0.375x the matrix time.
+// Pack images: the fp32 images re-laid for K = 32 (lane (out, q) holds the weights of k-slots 8S+u, u < 8: the SAME k-slots as
+// steps 8S .. 8S+7 of the fp32 form, so the activation registers are used in the order they are) and split into the three pieces:
+//   wbf[off + ((((t*K8 + S)*3 + piece)*64 + lane)*4 + u/2] = pack(piece(w(t, 8S+u, lane)), piece(w(t, 8S+u+1, lane)))      (dwords)
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+struct BfConv {  // one converted layer: where its fp32 pack sits in its source image, where the bf16x3 pack goes
+  int src_img, src_off, KS4, OT, dst_off;  // src_img 0: forward pack image, 1: transposed pack image
+};
+struct BfPlan {
+  int n, total;  // dwords
+  BfConv c[16];
+};
+__device__ __forceinline__ void bf_split3_scalar(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const __bf16 bh = (__bf16)x;
+  const float r1 = x - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  h = (uint16_t)__builtin_bit_cast(short, bh), m = (uint16_t)__builtin_bit_cast(short, bm), l = (uint16_t)__builtin_bit_cast(short, bl);
+}
+__global__ __launch_bounds__(256) void field_pack_bf_kernel(BfPlan bp, const float* __restrict__ img_f, const float* __restrict__ img_t,
+                                                            uint32_t* __restrict__ dst) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < bp.total; idx += gridDim.x * 256) {
+    int ci = 0;
+    while (ci + 1 < bp.n && idx >= bp.c[ci + 1].dst_off) ++ci;
+    const BfConv& c = bp.c[ci];
+    const int rel = idx - c.dst_off;
+    const int up = rel & 3, lane = (rel >> 2) & 63, blk = rel >> 8;  // blk = (t*K8 + S)*3 + piece
+    const int piece = blk % 3, ts = blk / 3;
+    const int K8 = (c.KS4 + 1) >> 1, t = ts / K8, S = ts % K8;
+    const float* src = (c.src_img ? img_t : img_f) + c.src_off;
+    uint32_t out = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int u = 2 * up + e, s4 = 2 * S + (u >> 2);
+      const float w = s4 < c.KS4 ? src[((t * c.KS4 + s4) * 64 + lane) * 4 + (u & 3)] : 0.0f;
+      uint32_t h, m, l;
+      bf_split3_scalar(w, h, m, l);
+      out |= (piece == 0 ? h : (piece == 1 ? m : l)) << (16 * e);
+    }
+    dst[idx] = out;
+  }
+}
+
+// acc[0][t] (+)= W-pack(t, :) x b[0][:] with the three-piece bf16 products (NT = 1 form of gemm_pack; same INIT meaning, same result
+// tile layout -- the C/D map of the MFMA does not depend on the input type)
+template <int OT, int KS, int INIT>
+__device__ __forceinline__ void gemm_bf(v4f (&acc)[1][OT], const float (&b)[1][KS], const uint32_t* __restrict__ w,
+                                        const float* __restrict__ bias, int lane) {
+  constexpr int K8 = (KS + 7) / 8;
+  v4u B[3][K8];
+#pragma unroll
+  for (int S = 0; S < K8; ++S)
+#pragma unroll
+    for (int up = 0; up < 4; ++up) {
+      const int s0 = 8 * S + 2 * up;  // KS is even or the last slot is a zero pad
+      uint32_t h, m, l;
+      bf_split_pair3(s0 < KS ? b[0][s0 < KS ? s0 : 0] : 0.0f, s0 + 1 < KS ? b[0][s0 + 1 < KS ? s0 + 1 : 0] : 0.0f, h, m, l);
+      B[0][S][up] = h, B[1][S][up] = m, B[2][S][up] = l;
+    }
+  if (INIT != 0) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (INIT == 2) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+      acc[0][t] = bv;
+    }
+  }
+  auto mf = [](const v4u& a, const v4u& bb, const v4f& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, bb), c, 0, 0, 0);
+  };
+  constexpr int NF = OT * K8;  // fragment f = S * OT + t: three 16-byte pieces each, requested one fragment ahead
+  v4u A[2][3];
+  auto load = [&](int f, int slot) __attribute__((always_inline)) {
+    const int t = f % OT, S = f / OT;
+    const uint32_t* pw = w + (((t * K8 + S) * 3) * 64 + lane) * 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) A[slot][p] = *reinterpret_cast<const v4u*>(pw + p * 256);
+  };
+  load(0, 0);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if (f + 1 < NF) load(f + 1, (f + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
+    const int t = f % OT, S = f / OT, k = f & 1;
+    v4f c = acc[0][t];
+    c = mf(A[k][0], B[0][S], c);
+    c = mf(A[k][0], B[1][S], c);
+    c = mf(A[k][1], B[0][S], c);
+    c = mf(A[k][0], B[2][S], c);
+    c = mf(A[k][2], B[0][S], c);
+    c = mf(A[k][1], B[1][S], c);
+    acc[0][t] = c;
+  }
+}
+
 // accumulator / bias-sum slots of a wave (items of 64 lanes x 4 floats; the slab keeps this order).  Part 0 owns the accumulator
 // items [0, A1) and the bias tiles [0, D1S); part 1 the rest.
 template <int TBMAX>
@@ -1529,16 +1648,39 @@ struct TfSlots {
 };
 constexpr int TF_CHUNK = 32;  // items per round of the end-of-launch reduction over the 4 waves (4 x 32 x 1 KiB = 128 KiB of LDS)
 
-template <int PART, bool SPEC, int TBMAX>
+struct BfOffs {  // LDS dword offsets (from the bf16 region) of the converted layers' bf16x3 packs, -1: layer keeps its fp32 pack
+  int f[NLAYERS], t[NTLAYERS];
+};
+
+// BF: the fp32 chain (forward recompute + dX) of every layer with >= 7 k-steps runs as three-piece bf16 products (gemm_bf); the
+// 4-step layers (the band tiles' products, the out-layer transposes) keep the fp32 MFMA.
+template <int PART, bool SPEC, int TBMAX, bool BF>
 __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDesc pd, TPackDesc td, const float* __restrict__ image,
                                                               const float* __restrict__ wT_image, ImgSegs seg_f, ImgSegs seg_t,
-                                                              int wt_off, float* __restrict__ slabs) {
+                                                              int wt_off, const float* __restrict__ bf_image, ImgSegs seg_b, int bf_off,
+                                                              BfOffs bo, float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef TfSlots<TBMAX> SL;
   copy_segs(lds, image, seg_f);  // pd / td carry offsets local to this part's LDS image
   copy_segs(lds + wt_off, wT_image, seg_t);
+  if (BF) copy_segs(lds + bf_off, bf_image, seg_b);
   __syncthreads();
   const float* const wT = lds + wt_off;
+  const uint32_t* const wbf = reinterpret_cast<const uint32_t*>(lds + bf_off);
+#define TF_GEMM_F(OT_, KS_, INIT_, ACC_, B_, LID_)                                                             \
+  do {                                                                                                          \
+    if constexpr (BF)                                                                                           \
+      gemm_bf<OT_, KS_, INIT_>(ACC_, B_, wbf + bo.f[LID_], lds + pd.L[LID_].off_b, lane);                       \
+    else                                                                                                        \
+      gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, lds + pd.L[LID_].off_w, lds + pd.L[LID_].off_b, lane);           \
+  } while (0)
+#define TF_GEMM_T(OT_, KS_, INIT_, ACC_, B_, TID_)                                            \
+  do {                                                                                         \
+    if constexpr (BF)                                                                          \
+      gemm_bf<OT_, KS_, INIT_>(ACC_, B_, wbf + bo.t[TID_], nullptr, lane);                      \
+    else                                                                                       \
+      gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, wT + td.L[TID_].off, nullptr, lane);            \
+  } while (0)
   constexpr int NT = 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const v4s ident = ident_frag(lane);
@@ -1627,13 +1769,13 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       to_swapped_n<4, true>(zS, dz1[0], ident, db1);
       to_swapped_n<4, false>(xS, a1[0], ident);
       dw_pairs<4, 4>(acc1, zS, xS);
-      gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
+      TF_GEMM_T(4, 16, 1, g4, dz1, t1);
       float dz0[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
       to_swapped_n<4, true>(zS, dz0[0], ident, db0);
       dw_pairs<4, 2>(acc0, zS, x27S);
-      gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
+      TF_GEMM_T(1, 16, 0, dbo4, dz0, t0);
     };
     if constexpr (PART == 0) {
       // This tile's upstream gradients, all band tiles: requested here, consumed after the head MLP's forward recompute (with one
@@ -1660,18 +1802,18 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       }
       float a1h[NT][16], a2h[NT][16];
       v4f hd4[NT][1], fl4[NT][1];
-      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+      TF_GEMM_F(4, 7, 2, t4, in27, L_H0);
       relu_to<4, NT>(a1h, t4);
-      gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+      TF_GEMM_F(4, 16, 2, t4, a1h, L_H1);
       relu_to<4, NT>(a2h, t4);
-      gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
+      TF_GEMM_F(1, 16, 2, hd4, a2h, L_H2);
       fl4[0][0] = cur.x0;
       HeadState<NT> hs;
       head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
       float hdir[NT][4];
       if (SPEC) {
         v4f d4[NT][1];
-        gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
+        TF_GEMM_F(1, 7, 2, d4, dir28, L_D0);
         relu_to<1, NT>(hdir, d4);
       }
       STile x27S[2], dirS[2], hdirS[1], mS[1];  // dirS[0]: SH c, dirS[1]: the positional encoding again
@@ -1761,16 +1903,16 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
 #pragma unroll
       for (int lv = 0; lv < 4; ++lv) encf[0][2 * lv] = cur.e[lv].x, encf[0][2 * lv + 1] = cur.e[lv].y;
       float h[NT][16];
-      gemm_pack<4, 8, NT, 2>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+      TF_GEMM_F(4, 8, 2, t4, encf, L_B0);
       relu_to<4, NT>(h, t4);
       v4f bo4[NT][1];
-      gemm_pack<1, 16, NT, 2>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+      TF_GEMM_F(1, 16, 2, bo4, h, L_B1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) in27[0][3 + r] = bo4[0][0][r];  // slot 0 (sigma_raw) meets a zero weight column
       float a1f[NT][16], a2f[NT][16];
-      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+      TF_GEMM_F(4, 7, 2, t4, in27, L_F0);
       relu_to<4, NT>(a1f, t4);
-      gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+      TF_GEMM_F(4, 16, 2, t4, a1f, L_F1);
       relu_to<4, NT>(a2f, t4);
       STile x27S[2];
       {
@@ -1808,7 +1950,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         dw_pairs<4, 2>(&acc_[SL::A_B0 - A0], zS, eS);
       }
       v4f de4[NT][2];
-      gemm_pack<2, 16, NT, 1>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
+      TF_GEMM_T(2, 16, 1, de4, dzb0, T_B0);
       if (ok && io.d_enc) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -1853,6 +1995,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     }
   }
 }
+#undef TF_GEMM_F
+#undef TF_GEMM_T
 
 struct GradPtrs {
   float* W[NLAYERS];
@@ -2360,18 +2504,60 @@ static size_t bwd_slab_floats(const BwdPlan& pl, int64_t n) {  // room for eithe
   const size_t tf = (size_t)tf_grid(n) * tf_nitems(tf_tbmax(pl.TB) ? tf_tbmax(pl.TB) : 16) * 256;
   return staged > tf ? staged : tf;
 }
+static int bf_image_dwords(const BwdPlan& pl);
 static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
-  return ((size_t)pl.td.total + bwd_slab_floats(pl, n) + (size_t)n * 48 + pl.pd_all.total) * 4 + 4096;
+  return ((size_t)pl.td.total + bwd_slab_floats(pl, n) + (size_t)n * 48 + pl.pd_all.total + bf_image_dwords(pl)) * 4 + 4096 + 1024;
 }
 
 struct TfPart {  // one transpose-free kernel: descriptors rebased to its own LDS image + how to assemble that image
   PackDesc pd;
   TPackDesc td;
-  ImgSegs seg_f, seg_t;
-  int wt_off;
+  ImgSegs seg_f, seg_t, seg_b;
+  BfOffs bo;
+  int wt_off, bf_off;
   size_t lds;
 };
-static bool tf_part(const BwdPlan& pl, int part, TfPart* pp) {
+
+// The layers whose products run as three-piece bf16 MFMAs (every layer with >= 7 k-steps), in the order of the global bf16x3 image:
+// part 0's first (head MLP, directional hidden layer, their transposes), then part 1's.
+static const int BF_F0[] = {L_H0, L_H1, L_H2, L_D0}, BF_T0[] = {T_H1, T_H0};
+static const int BF_F1[] = {L_B0, L_B1, L_F0, L_F1}, BF_T1[] = {T_B0, T_F1, T_F0};
+static void build_bf_plan(const BwdPlan& pl, BfPlan* bp, int (&dst_f)[NLAYERS], int (&dst_t)[NTLAYERS], int (&part_range)[2][2]) {
+  for (int l = 0; l < NLAYERS; ++l) dst_f[l] = -1;
+  for (int l = 0; l < NTLAYERS; ++l) dst_t[l] = -1;
+  bp->n = 0;
+  int off = 0;
+  auto addf = [&](int l) {
+    const LayerDesc& L = pl.pd_all.L[l];
+    if (L.OT == 0) return;
+    const int KS4 = (L.KS + 3) / 4;
+    bp->c[bp->n++] = BfConv{0, L.off_w, KS4, L.OT, off};
+    dst_f[l] = off, off += L.OT * ((KS4 + 1) / 2) * 3 * 256;
+  };
+  auto addt = [&](int l) {
+    const TDesc& T = pl.td.L[l];
+    if (T.OT == 0) return;
+    const int KS4 = (T.KS + 3) / 4;
+    bp->c[bp->n++] = BfConv{1, T.off, KS4, T.OT, off};
+    dst_t[l] = off, off += T.OT * ((KS4 + 1) / 2) * 3 * 256;
+  };
+  part_range[0][0] = off;
+  for (int l : BF_F0) addf(l);
+  for (int l : BF_T0) addt(l);
+  part_range[0][1] = part_range[1][0] = off;
+  for (int l : BF_F1) addf(l);
+  for (int l : BF_T1) addt(l);
+  part_range[1][1] = off;
+  bp->total = off;
+}
+static int bf_image_dwords(const BwdPlan& pl) {
+  BfPlan bp;
+  int df[NLAYERS], dt[NTLAYERS], pr[2][2];
+  build_bf_plan(pl, &bp, df, dt, pr);
+  return bp.total;
+}
+
+static bool tf_part(const BwdPlan& pl, int part, bool bf, TfPart* pp) {
   const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
   const int fl1[] = {L_B0, L_B1, L_F0, L_F1}, tl1[] = {T_B1, T_B0, T_F2, T_F1, T_F0};
   const int* fl = part == 0 ? fl0 : fl1;
@@ -2379,7 +2565,12 @@ static bool tf_part(const BwdPlan& pl, int part, TfPart* pp) {
   const int* tl = part == 0 ? tl0 : tl1;
   const int ntl = 5;
   pp->pd = pl.pd_all, pp->td = pl.td;
-  pp->seg_f.n = pp->seg_t.n = 0;
+  pp->seg_f.n = pp->seg_t.n = pp->seg_b.n = 0;
+  BfPlan bp;
+  int dst_f[NLAYERS], dst_t[NTLAYERS], pr[2][2];
+  build_bf_plan(pl, &bp, dst_f, dst_t, pr);
+  for (int l = 0; l < NLAYERS; ++l) pp->bo.f[l] = (bf && dst_f[l] >= pr[part][0] && dst_f[l] < pr[part][1]) ? dst_f[l] - pr[part][0] : -1;
+  for (int l = 0; l < NTLAYERS; ++l) pp->bo.t[l] = (bf && dst_t[l] >= pr[part][0] && dst_t[l] < pr[part][1]) ? dst_t[l] - pr[part][0] : -1;
   bool ok = true;
   auto add = [&](ImgSegs& sg, int src, int dst, int len) {
     if (len == 0) return;
@@ -2394,8 +2585,9 @@ static bool tf_part(const BwdPlan& pl, int part, TfPart* pp) {
     sg.src[sg.n] = src, sg.dst[sg.n] = dst, sg.len[sg.n] = len, ++sg.n;
   };
   int cur = 0;
-  for (int i = 0; i < nfl; ++i) {  // weights, then biases, in the kernel's own compact image
+  for (int i = 0; i < nfl; ++i) {  // fp32 weights (of the layers that keep them), then biases, in the kernel's own compact image
     const LayerDesc& L = pl.pd_all.L[fl[i]];
+    if (pp->bo.f[fl[i]] >= 0) continue;
     const int len = L.OT * ((L.KS + 3) / 4) * 256;
     add(pp->seg_f, L.off_w, cur, len);
     pp->pd.L[fl[i]].off_w = cur, cur += len;
@@ -2409,11 +2601,15 @@ static bool tf_part(const BwdPlan& pl, int part, TfPart* pp) {
   cur = 0;
   for (int i = 0; i < ntl; ++i) {
     const TDesc& T = pl.td.L[tl[i]];
+    if (pp->bo.t[tl[i]] >= 0) continue;
     const int len = T.OT * ((T.KS + 3) / 4) * 256;
     add(pp->seg_t, T.off, cur, len);
     pp->td.L[tl[i]].off = cur, cur += len;
   }
-  pp->lds = (size_t)(pp->wt_off + cur) * 4;
+  pp->bf_off = (pp->wt_off + cur + 3) & ~3;
+  cur = 0;
+  if (bf) add(pp->seg_b, pr[part][0], 0, pr[part][1] - pr[part][0]), cur = pr[part][1] - pr[part][0];
+  pp->lds = (size_t)(pp->bf_off + cur) * 4;
   if (pp->lds < (size_t)4 * TF_CHUNK * 256 * 4) pp->lds = (size_t)4 * TF_CHUNK * 256 * 4;  // the end-of-launch reduction's rounds
   return ok && pp->lds <= 160 * 1024;
 }
@@ -2449,25 +2645,36 @@ static void fill_tf_map(TfMap* mp, bool spec, int TB) {
 }
 
 template <int TBMAX>
-static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], FieldIO io, bool spec, const float* img, const float* wT, float* slabs,
-                     const GradPtrs& gp, int64_t n, umhs_stream_t stream) {
+static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, FieldIO io, bool spec, const float* img, const float* wT,
+                     const float* bfimg, float* slabs, const GradPtrs& gp, int64_t n, umhs_stream_t stream) {
   typedef TfSlots<TBMAX> SL;
   const unsigned grid = tf_grid(n);
   int rc;
-#define LAUNCH_TF(P_, S_)                                                                                                         \
+#define LAUNCH_TF(P_, S_, BF_)                                                                                                    \
   do {                                                                                                                            \
-    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX>, part[P_].lds);                                                               \
+    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX, BF_>, part[P_].lds);                                                          \
     if (rc) return rc;                                                                                                            \
-    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io, part[P_].pd, \
-                       part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, slabs);                             \
+    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX, BF_>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io,        \
+                       part[P_].pd, part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, bfimg, part[P_].seg_b,  \
+                       part[P_].bf_off, part[P_].bo, slabs);                                                                      \
   } while (0)
-  if (spec) {
-    LAUNCH_TF(0, true);
-    LAUNCH_TF(1, true);
-  } else {
-    LAUNCH_TF(0, false);
-    LAUNCH_TF(1, false);
-  }
+#define LAUNCH_TF_P(P_)                \
+  do {                                 \
+    if (spec) {                        \
+      if (bf_mask >> P_ & 1)           \
+        LAUNCH_TF(P_, true, true);     \
+      else                             \
+        LAUNCH_TF(P_, true, false);    \
+    } else {                           \
+      if (bf_mask >> P_ & 1)           \
+        LAUNCH_TF(P_, false, true);    \
+      else                             \
+        LAUNCH_TF(P_, false, false);   \
+    }                                  \
+  } while (0)
+  LAUNCH_TF_P(0);
+  LAUNCH_TF_P(1);
+#undef LAUNCH_TF_P
 #undef LAUNCH_TF
   UMHS_CHECK_LAUNCH();
   TfMap mp;
@@ -2477,6 +2684,17 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], FieldIO io, boo
                      pl.pd_all, gp);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
+}
+
+static void launch_bwd_packs(const BwdPlan& pl, float* wT, float* img, float* bfimg, umhs_stream_t stream) {
+  hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
+  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all, img);
+  BfPlan bp;
+  int df[NLAYERS], dt[NTLAYERS], pr[2][2];
+  build_bf_plan(pl, &bp, df, dt, pr);  // the three-piece bf16 images are derived from the two fp32 images just queued
+  if (bp.total > 0)
+    hipLaunchKernelGGL(field_pack_bf_kernel, dim3((bp.total + 255) / 256), dim3(256), 0, umhs_s(stream), bp, (const float*)img,
+                       (const float*)wT, reinterpret_cast<uint32_t*>(bfimg));
 }
 
 // The weight images of the backward (transposed packs + forward pack image) depend on the parameters only: a caller may build
@@ -2494,9 +2712,8 @@ extern "C" int umhs_field_bwd_prepare(const umhs_field_cfg* cfg, const umhs_fiel
   if (!workspace || workspace_bytes < bwd_workspace_need(pl, 1)) return UMHS_ERR_WORKSPACE;
   float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   float* img = wT + ((pl.td.total + 63) & ~63);
-  hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
-  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all,
-                     img);
+  float* bfimg = img + ((pl.pd_all.total + 63) & ~63);
+  launch_bwd_packs(pl, wT, img, bfimg, stream);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
@@ -2532,19 +2749,18 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   if (rc) return rc;
   const unsigned grid = bwd_grid(n, pl.S);
   if (!workspace || workspace_bytes < bwd_workspace_need(pl, n)) return UMHS_ERR_WORKSPACE;
-  // workspace: [transposed packs][forward pack image] (both independent of n: umhs_field_bwd_prepare fills them) [slabs][d_bo]
+  // workspace: [transposed packs][forward pack image][bf16x3 images] (independent of n: umhs_field_bwd_prepare fills them) [slabs][d_bo]
   float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   float* img = wT + ((pl.td.total + 63) & ~63);
-  float* slabs = img + ((pl.pd_all.total + 63) & ~63);
+  float* bfimg = img + ((pl.pd_all.total + 63) & ~63);
+  float* slabs = bfimg + ((bf_image_dwords(pl) + 63) & ~63);
   float* d_bo = slabs + ((bwd_slab_floats(pl, n) + 63) & ~(size_t)63);
   float* d_bo2 = d_bo + (((size_t)n * 16 + 63) & ~(size_t)63);
   float* d_fl = d_bo2 + (((size_t)n * 16 + 63) & ~(size_t)63);
   static const int no_split = getenv("UMHS_BWD_NO_SPLIT") ? atoi(getenv("UMHS_BWD_NO_SPLIT")) : 0;  // A/B knob
   const bool split = pl.split && feat_logits != nullptr && !no_split;
   if (!packs_ready) {
-    hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
-    hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all,
-                       img);
+    launch_bwd_packs(pl, wT, img, bfimg, stream);
     UMHS_CHECK_LAUNCH();
   }
   FieldIO io = {};
@@ -2566,19 +2782,30 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
   // Measured (tools/bench_fbwd.py, one MI355X, whole backward): C2 328 vs 351 us, 128 bands 833 vs 1454 us, 141 bands 660 vs 1243 us
   // for the LDS-staged kernels below (whose fused heads kernel spills and keeps its transposed packs in L2 above 32 bands); in the
   // full C2 step 0.903 / 0.908 vs 0.917 / 0.916 ms (A/B/A/B).  UMHS_BWD_TF=0 forces the staged kernels.
-  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : 1;
+  // UMHS_BWD_TF: 0 = the LDS-staged kernels, 1 = transpose-free with the fp32 MFMA chain, 2 = transpose-free with the chain as
+  // three-piece bf16 products (gemm_bf)
+  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : 3;
+  static const int bf_env = getenv("UMHS_BWD_BF") ? atoi(getenv("UMHS_BWD_BF")) : -1;  // A/B knob: bit p = part p on the bf16x3 chain
   const int tbmax = tf_tbmax(pl.TB);
-  const bool want_tf = tf_mode != 0;
-  if (want_tf && feat_logits != nullptr && tbmax != 0) {
+  if (tf_mode != 0 && feat_logits != nullptr && tbmax != 0) {
+    // mode 3 (default): the bf16x3 chain where its kernel holds its registers -- part 1 always, part 0 up to 128 bands or without
+    // the directional MLP (resource usage: the part-0 kernels with specular above 128 bands spill into scratch)
+    int bf_mask = tf_mode == 2 ? 3 : tf_mode == 3 ? (2 | ((!spec || tbmax <= 8) ? 1 : 0)) : 0;
+    if (bf_env >= 0) bf_mask = bf_env & 3;
     TfPart part[2];
-    if (tf_part(pl, 0, &part[0]) && tf_part(pl, 1, &part[1])) {
+    bool ok = true;
+    for (int p = 0; p < 2; ++p) {
+      if ((bf_mask >> p & 1) && !tf_part(pl, p, true, &part[p])) bf_mask &= ~(1 << p);  // LDS: fall back to the fp32 chain
+      if (!(bf_mask >> p & 1)) ok = ok && tf_part(pl, p, false, &part[p]);
+    }
+    if (ok) {
       io.feat_logits_in = feat_logits, io.d_fl = d_fl;
       switch (tbmax) {
-        case 2: return launch_tf<2>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
-        case 4: return launch_tf<4>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
-        case 8: return launch_tf<8>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
-        case 12: return launch_tf<12>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
-        default: return launch_tf<16>(pl, part, io, spec, img, wT, slabs, gp, n, stream);
+        case 2: return launch_tf<2>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
+        case 4: return launch_tf<4>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
+        case 8: return launch_tf<8>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
+        case 12: return launch_tf<12>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
+        default: return launch_tf<16>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
       }
     }
   }
