@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Field backward alone (all kernels of umhs_field_bwd) at the bench shapes; UMHS_BWD_TF=0/1 selects the kernel family.  GPU box."""
+"""Field forward alone at the bench shapes; UMHS_FWD_VARIANT=0/2 selects the bf16x3 / fp32 chain.  GPU box."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd"), os.path.join(ROOT, "tools")]
@@ -20,10 +20,7 @@ for name in os.environ.get("CASES", "C2,C3,C5").split(","):
     wpos = torch.rand(N, 3, device=dev) * 2 - 1
     dirs = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
     sel = torch.ones(N, device=dev)
-    out = ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True, want_logits=True)
-    dsig, dspec = torch.rand(N, device=dev), torch.rand(N, B, device=dev)
-    dflat = torch.zeros_like(flat)
-    fn = lambda: ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, out["sigma_raw"], out["emb"], dsig, dspec, None, dflat, feat_logits=out["feat_logits"])
+    fn = lambda: ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True, want_logits=True)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -34,4 +31,4 @@ for name in os.environ.get("CASES", "C2,C3,C5").split(","):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"{name}: N={N} B={B} C={C} spec={spec} TF={os.environ.get('UMHS_BWD_TF', '1')}: field_bwd {us:8.1f} us = {us * 1e3 / N:.2f} ns/sample", flush=True)
+    print(f"{name}: N={N} B={B} C={C} spec={spec} variant={os.environ.get('UMHS_FWD_VARIANT', '0')}: field_fwd {us:8.1f} us = {us * 1e3 / N:.2f} ns/sample", flush=True)

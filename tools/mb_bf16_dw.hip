@@ -87,6 +87,13 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters) {
       if (KIND == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a), "v"(b));
       if (KIND == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(pa), "v"(pb));
       if (KIND == 2) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(qa), "v"(qb));
+      // dependent chains: every MFMA accumulates onto the previous one's result (1 accumulator), or 2 alternating accumulators
+      if (KIND == 3) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(pa), "v"(pb));
+      if (KIND == 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m & 1]) : "v"(pa), "v"(pb));
+      if (KIND == 5) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b));
+      if (KIND == 6) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(qa), "v"(qb));
+      if (KIND == 7) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+a"(acc[0]) : "v"(qa), "v"(qb));
+      if (KIND == 8) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(qa), "v"(qb));
     }
   }
   float s = 0;
@@ -136,5 +143,11 @@ int main() {
   rate<0>("v_mfma_f32_16x16x4_f32", out);
   rate<1>("v_mfma_f32_16x16x32_bf16", out);
   rate<2>("v_mfma_f32_16x16x16_bf16", out);
+  rate<3>("16x16x32_bf16, 1 accumulator", out);
+  rate<4>("16x16x32_bf16, 2 accumulators", out);
+  rate<5>("16x16x4_f32, 1 accumulator", out);
+  rate<6>("16x16x16_bf16, 1 accumulator", out);
+  rate<7>("16x16x16_bf16, 1 acc (AGPR)", out);
+  rate<8>("16x16x16_bf16, 4 acc (AGPR)", out);
   return (e_t < 1e-5 && e_w / m_w < 5e-5) ? 0 : 1;
 }

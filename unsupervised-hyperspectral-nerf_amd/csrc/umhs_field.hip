@@ -353,14 +353,182 @@ __device__ __forceinline__ void store_density(const FieldIO& io, const v4f (&bo4
 }
 
 // =============================================================================================
+// Shared by the forward and the transpose-free backward: LDS image segments, the three-piece bf16 form of the fp32 GEMM chain
+// =============================================================================================
+struct ImgSegs {
+  int n, src[6], dst[6], len[6];  // float offsets / lengths, multiples of 4
+};
+__device__ __forceinline__ void copy_segs(float* dst, const float* __restrict__ src, const ImgSegs& sg) {
+  for (int k = 0; k < sg.n; ++k)
+    for (int i = threadIdx.x; i < (sg.len[k] >> 2); i += blockDim.x)
+      reinterpret_cast<float4*>(dst + sg.dst[k])[i] = reinterpret_cast<const float4*>(src + sg.src[k])[i];
+}
+
+
+enum TLayerId { T_B1 = 0, T_B0, T_H2, T_H1, T_H0, T_F2, T_F1, T_F0, T_D1, T_MX, NTLAYERS };
+
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+// two floats -> their bf16 roundings (nearest even) in one dword (v_cvt_pk_bf16_f32), low half = a
+__device__ __forceinline__ uint32_t cvt_pk_bf(float a, float b) {
+  const v2f v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v2bf));
+}
+// (x0, x1) -> packed bf16 pieces: h = rne(x), m = rne(x - h) [, l = rne(x - h - m)]; the subtractions are exact.  The transposes of
+// the dW operands and the chain's three-piece products call this on the same registers: the compiler keeps one computation.
+__device__ __forceinline__ void bf_split_pair(float x0, float x1, uint32_t& h, uint32_t& m, float& r0, float& r1) {
+  h = cvt_pk_bf(x0, x1);
+  r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf(r0, r1);
+}
+__device__ __forceinline__ void bf_split_pair3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  float r0, r1;
+  bf_split_pair(x0, x1, h, m, r0, r1);
+  l = cvt_pk_bf(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+
+// ---- the exact fp32 chain on the bf16 MFMA: x = hi + mid + lo (three bf16 pieces, |x - hi - mid - lo| <= 2^-25 |x|), a product
+// a*b = hh + hm + mh + hl + lh + mm (the three terms left out are <= 2^-24 |ab|: fp32's own rounding), exact bf16 products,
+// fp32 accumulation.  v_mfma_f32_16x16x32_bf16 issues in half the cycles of v_mfma_f32_16x16x4_f32 for 8x its K, so a 64-wide
+// layer costs 12 bf16 MFMAs per output tile instead of 16 fp32 ones at half the cycles each: 0.375x the matrix time.
+// Pack images: the fp32 images re-laid for K = 32 (lane (out, q) holds the weights of k-slots 8S+u, u < 8: the SAME k-slots as
+// steps 8S .. 8S+7 of the fp32 form, so the activation registers are used in the order they are) and split into the three pieces:
+//   wbf[off + ((((t*K8 + S)*3 + piece)*64 + lane)*4 + u/2] = pack(piece(w(t, 8S+u, lane)), piece(w(t, 8S+u+1, lane)))      (dwords)
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+struct BfConv {  // one converted layer: where its fp32 pack sits in its source image, where the bf16x3 pack goes
+  int src_img, src_off, KS4, OT, dst_off;  // src_img 0: forward pack image, 1: transposed pack image
+};
+struct BfPlan {
+  int n, total;  // dwords
+  BfConv c[16];
+};
+__device__ __forceinline__ void bf_split3_scalar(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const __bf16 bh = (__bf16)x;
+  const float r1 = x - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  h = (uint16_t)__builtin_bit_cast(short, bh), m = (uint16_t)__builtin_bit_cast(short, bm), l = (uint16_t)__builtin_bit_cast(short, bl);
+}
+__global__ __launch_bounds__(256) void field_pack_bf_kernel(BfPlan bp, const float* __restrict__ img_f, const float* __restrict__ img_t,
+                                                            uint32_t* __restrict__ dst) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < bp.total; idx += gridDim.x * 256) {
+    int ci = 0;
+    while (ci + 1 < bp.n && idx >= bp.c[ci + 1].dst_off) ++ci;
+    const BfConv& c = bp.c[ci];
+    const int rel = idx - c.dst_off;
+    const int up = rel & 3, lane = (rel >> 2) & 63, blk = rel >> 8;  // blk = (t*K8 + S)*3 + piece
+    const int piece = blk % 3, ts = blk / 3;
+    const int K8 = (c.KS4 + 1) >> 1, t = ts / K8, S = ts % K8;
+    const float* src = (c.src_img ? img_t : img_f) + c.src_off;
+    uint32_t out = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int u = 2 * up + e, s4 = 2 * S + (u >> 2);
+      const float w = s4 < c.KS4 ? src[((t * c.KS4 + s4) * 64 + lane) * 4 + (u & 3)] : 0.0f;
+      uint32_t h, m, l;
+      bf_split3_scalar(w, h, m, l);
+      out |= (piece == 0 ? h : (piece == 1 ? m : l)) << (16 * e);
+    }
+    dst[idx] = out;
+  }
+}
+
+// acc[ct][t] (+)= W-pack(t, :) x b[ct][:] with the three-piece bf16 products (same INIT meaning and result tile layout as gemm_pack
+// -- the C/D map of the MFMA does not depend on the input type; the NT sample tiles share every weight fragment)
+#ifndef BF_PF
+#define BF_PF 2
+#endif
+template <int OT, int KS, int NT, int INIT>
+__device__ __forceinline__ void gemm_bf(v4f (&acc)[NT][OT], const float (&b)[NT][KS], const uint32_t* __restrict__ w,
+                                        const float* __restrict__ bias, int lane) {
+  constexpr int K8 = (KS + 7) / 8;
+  v4u B[NT][3][K8];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int S = 0; S < K8; ++S)
+#pragma unroll
+      for (int up = 0; up < 4; ++up) {
+        const int s0 = 8 * S + 2 * up;  // KS is even or the last slot is a zero pad
+        uint32_t h, m, l;
+        bf_split_pair3(s0 < KS ? b[ct][s0 < KS ? s0 : 0] : 0.0f, s0 + 1 < KS ? b[ct][s0 + 1 < KS ? s0 + 1 : 0] : 0.0f, h, m, l);
+        B[ct][0][S][up] = h, B[ct][1][S][up] = m, B[ct][2][S][up] = l;
+      }
+  if (INIT != 0) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (INIT == 2) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct][t] = bv;
+    }
+  }
+  auto mf = [](const v4u& a, const v4u& bb, const v4f& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, bb), c, 0, 0, 0);
+  };
+  constexpr int NF = OT * K8;  // fragment f = S * OT + t: three 16-byte pieces each, requested BF_PF fragments ahead
+  constexpr int PF = BF_PF < NF ? BF_PF : NF;
+  v4u A[PF + 1][3];
+  auto load = [&](int f, int slot) __attribute__((always_inline)) {
+    const int t = f % OT, S = f / OT;
+    const uint32_t* pw = w + (((t * K8 + S) * 3) * 64 + lane) * 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) A[slot][p] = *reinterpret_cast<const v4u*>(pw + p * 256);
+  };
+#pragma unroll
+  for (int f = 0; f < PF; ++f) load(f, f);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if (f + PF < NF) load(f + PF, (f + PF) % (PF + 1));
+    __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
+    const int t = f % OT, S = f / OT, k = f % (PF + 1);
+    constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};  // hh, hm, mh, hl, lh, mm
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct][t] = mf(A[k][PA[p]], B[ct][PB[p]][S], acc[ct][t]);
+  }
+}
+
+struct BfOffs {  // LDS dword offsets (from the bf16 region) of the converted layers' bf16x3 packs, -1: layer keeps its fp32 pack
+  int f[NLAYERS], t[NTLAYERS];
+};
+
+
+// =============================================================================================
 // Forward
 // =============================================================================================
-template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES, bool HASH = false>
-__global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(FieldIO io, PackDesc pd,
-                                                                               const float* __restrict__ image) {
+// BF: the layers with >= 7 k-steps (everything but the band tiles and the directional hidden layer) run as three-piece bf16
+// products (gemm_bf): 6 v_mfma_f32_16x16x32_bf16 per 8 k-slots instead of 8 v_mfma_f32_16x16x4_f32 at twice the cycles each.  Their
+// bf16x3 packs (1.5x the fp32 bytes) make the image ~110 KB: one 8-wave workgroup per CU instead of two 4-wave ones.
+struct FwdBfArgs {
+  ImgSegs seg_f, seg_b;  // fp32 part (packs of the other layers + every bias) and bf16x3 part of the LDS image
+  int bf_off;            // dword offset of the bf16x3 part in LDS
+  BfOffs bo;
+  const float* bf_image;
+};
+template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES, bool HASH = false, bool BF = false>
+__global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void field_fwd_kernel(FieldIO io, PackDesc pd,
+                                                                                        const float* __restrict__ image, FwdBfArgs fb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  load_fwd_image(lds, pd, image, 0);
+  if (BF) {
+    copy_segs(lds, image, fb.seg_f);  // pd carries offsets local to this compact image
+    copy_segs(lds + fb.bf_off, fb.bf_image, fb.seg_b);
+  } else {
+    load_fwd_image(lds, pd, image, 0);
+  }
   __syncthreads();
+  const uint32_t* const wbf = reinterpret_cast<const uint32_t*>(lds + fb.bf_off);
+#define FWD_GEMM(OT_, KS_, ACC_, B_, LID_)                                                                     \
+  do {                                                                                                          \
+    if constexpr (BF)                                                                                           \
+      gemm_bf<OT_, KS_, NT, 2>(ACC_, B_, wbf + fb.bo.f[LID_], lds + pd.L[LID_].off_b, lane);                    \
+    else                                                                                                        \
+      gemm_pack<OT_, KS_, NT, 2>(ACC_, B_, lds + pd.L[LID_].off_w, lds + pd.L[LID_].off_b, lane);               \
+  } while (0)
   constexpr int TILE = 16 * NT * WAVES;  // samples per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int64_t ntiles = (io.n + TILE - 1) / TILE;
@@ -417,11 +585,11 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
     }
     // ---- mlp_base: 32 -> 64 -> 16 -------------------------------------------------------------
     v4f h4[NT][4];
-    gemm_pack<4, 8, NT, 2>(h4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
+    FWD_GEMM(4, 8, h4, encf, L_B0);
     float h[NT][16];
     relu_to<4, NT>(h, h4);
     v4f bo4[NT][1];
-    gemm_pack<1, 16, NT, 2>(bo4, h, lds + pd.L[L_B1].off_w, lds + pd.L[L_B1].off_b, lane);
+    FWD_GEMM(1, 16, bo4, h, L_B1);
     if (DENSITY_ONLY) {
       store_density<NT>(io, bo4, nn, ok, q);
       continue;
@@ -443,16 +611,16 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
     // ---- mlp_head / feature_mlp: 27 -> 64 -> 64 -> C(+1) ----------------------------------------
     v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
     float a1[NT][16], a2[NT][16];
-    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
+    FWD_GEMM(4, 7, t4, in27, L_H0);
     relu_to<4, NT>(a1, t4);
-    gemm_pack<4, 16, NT, 2>(t4, a1, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
+    FWD_GEMM(4, 16, t4, a1, L_H1);
     relu_to<4, NT>(a2, t4);
-    gemm_pack<1, 16, NT, 2>(hd4, a2, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
-    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
+    FWD_GEMM(1, 16, hd4, a2, L_H2);
+    FWD_GEMM(4, 7, t4, in27, L_F0);
     relu_to<4, NT>(a1, t4);
-    gemm_pack<4, 16, NT, 2>(t4, a1, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
+    FWD_GEMM(4, 16, t4, a1, L_F1);
     relu_to<4, NT>(a2, t4);
-    gemm_pack<1, 16, NT, 2>(fl4, a2, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
+    FWD_GEMM(1, 16, fl4, a2, L_F2);
     if (io.feat_logits) {  // saved for the split backward: [N,16] rows 4q..4q+3 of the logit tile, 64 B per sample
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
@@ -507,6 +675,7 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
     }
   }
 }
+#undef FWD_GEMM
 
 // =============================================================================================
 // Backward.  Two kernels so that each fits 2 waves per SIMD (8-wave workgroups, <= 256 VGPRs):
@@ -516,7 +685,6 @@ __global__ __launch_bounds__(64 * WAVES, (2 * WAVES) / 4) void field_fwd_kernel(
 //   base : mlp_base.  Recomputes its hidden layer from the hash features, consumes d_bo + d_sigma, emits d_enc.
 // Transposed pack images (A operands of the dX chain) are built once per call in global memory (L2-resident).
 // =============================================================================================
-enum TLayerId { T_B1 = 0, T_B0, T_H2, T_H1, T_H0, T_F2, T_F1, T_F0, T_D1, T_MX, NTLAYERS };
 struct TDesc {
   const float* W;
   int OUT, IN, KS, OT, rowmap, off;  // rowmap 0: in = rho, 1: emb slots of the 27-d input, 2: L_MX (E[c=rho][b=k])
@@ -981,15 +1149,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(
 // part keeps BOTH its forward packs and its transposed packs in LDS beside the staging buffers (the fused kernel reads the
 // transposed packs from L2), holds half the dW accumulators, and recomputes nothing twice.
 // ---------------------------------------------------------------------------------------------
-struct ImgSegs {
-  int n, src[6], dst[6], len[6];  // float offsets / lengths, multiples of 4
-};
-__device__ __forceinline__ void copy_segs(float* dst, const float* __restrict__ src, const ImgSegs& sg) {
-  for (int k = 0; k < sg.n; ++k)
-    for (int i = threadIdx.x; i < (sg.len[k] >> 2); i += blockDim.x)
-      reinterpret_cast<float4*>(dst + sg.dst[k])[i] = reinterpret_cast<const float4*>(src + sg.src[k])[i];
-}
-
 template <int PART, bool SPEC>
 __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, PackDesc pd, TPackDesc td, SlabLayout sl,
                                                                 float* __restrict__ slabs, int wt_off, int stage_off, int FSd,
@@ -1408,25 +1567,6 @@ __device__ __forceinline__ v4s ident_frag(int lane) {  // B operand of the trans
   for (int u = 0; u < 4; ++u) f[u] = ((c >> 2) == q && (c & 3) == u) ? (short)0x3F80 : (short)0;
   return f;
 }
-typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-// two floats -> their bf16 roundings (nearest even) in one dword (v_cvt_pk_bf16_f32), low half = a
-__device__ __forceinline__ uint32_t cvt_pk_bf(float a, float b) {
-  const v2f v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v2bf));
-}
-// (x0, x1) -> packed bf16 pieces: h = rne(x), m = rne(x - h) [, l = rne(x - h - m)]; the subtractions are exact.  The transposes of
-// the dW operands and the chain's three-piece products call this on the same registers: the compiler keeps one computation.
-__device__ __forceinline__ void bf_split_pair(float x0, float x1, uint32_t& h, uint32_t& m, float& r0, float& r1) {
-  h = cvt_pk_bf(x0, x1);
-  r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  m = cvt_pk_bf(r0, r1);
-}
-__device__ __forceinline__ void bf_split_pair3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-  float r0, r1;
-  bf_split_pair(x0, x1, h, m, r0, r1);
-  l = cvt_pk_bf(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
-}
 __device__ __forceinline__ v4s pack_hi16(const v4f& v) {  // the four values ARE bf16 numbers: keep their upper halves
   const uint32_t a = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
   const uint32_t b = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
@@ -1530,107 +1670,6 @@ __device__ __forceinline__ void dw_pairs(v4f* __restrict__ acc, const STile (&Z)
   for (int to = 0; to < TO; ++to) dw_row<TI>(acc + to * TI, Z[to], X);
 }
 
-// ---- the exact fp32 chain on the bf16 MFMA: x = hi + mid + lo (three bf16 pieces, |x - hi - mid - lo| <= 2^-25 |x|), a product
-// a*b = hh + hm + mh + hl + lh + mm (the three terms left out are <= 2^-24 |ab|: fp32's own rounding), exact bf16 products,
-// fp32 accumulation.  v_mfma_f32_16x16x32_bf16 issues in half the cycles of v_mfma_f32_16x16x4_f32 for 8x its K, so a 64-wide
-// layer costs 12 bf16 MFMAs per output tile instead of 16 fp32 ones at half the cycles each: 0.375x the matrix time.
-// Pack images: the fp32 images re-laid for K = 32 (lane (out, q) holds the weights of k-slots 8S+u, u < 8: the SAME k-slots as
-// steps 8S .. 8S+7 of the fp32 form, so the activation registers are used in the order they are) and split into the three pieces:
-//   wbf[off + ((((t*K8 + S)*3 + piece)*64 + lane)*4 + u/2] = pack(piece(w(t, 8S+u, lane)), piece(w(t, 8S+u+1, lane)))      (dwords)
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-
-struct BfConv {  // one converted layer: where its fp32 pack sits in its source image, where the bf16x3 pack goes
-  int src_img, src_off, KS4, OT, dst_off;  // src_img 0: forward pack image, 1: transposed pack image
-};
-struct BfPlan {
-  int n, total;  // dwords
-  BfConv c[16];
-};
-__device__ __forceinline__ void bf_split3_scalar(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
-  const __bf16 bh = (__bf16)x;
-  const float r1 = x - (float)bh;
-  const __bf16 bm = (__bf16)r1;
-  const float r2 = r1 - (float)bm;
-  const __bf16 bl = (__bf16)r2;
-  h = (uint16_t)__builtin_bit_cast(short, bh), m = (uint16_t)__builtin_bit_cast(short, bm), l = (uint16_t)__builtin_bit_cast(short, bl);
-}
-__global__ __launch_bounds__(256) void field_pack_bf_kernel(BfPlan bp, const float* __restrict__ img_f, const float* __restrict__ img_t,
-                                                            uint32_t* __restrict__ dst) {
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < bp.total; idx += gridDim.x * 256) {
-    int ci = 0;
-    while (ci + 1 < bp.n && idx >= bp.c[ci + 1].dst_off) ++ci;
-    const BfConv& c = bp.c[ci];
-    const int rel = idx - c.dst_off;
-    const int up = rel & 3, lane = (rel >> 2) & 63, blk = rel >> 8;  // blk = (t*K8 + S)*3 + piece
-    const int piece = blk % 3, ts = blk / 3;
-    const int K8 = (c.KS4 + 1) >> 1, t = ts / K8, S = ts % K8;
-    const float* src = (c.src_img ? img_t : img_f) + c.src_off;
-    uint32_t out = 0;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int u = 2 * up + e, s4 = 2 * S + (u >> 2);
-      const float w = s4 < c.KS4 ? src[((t * c.KS4 + s4) * 64 + lane) * 4 + (u & 3)] : 0.0f;
-      uint32_t h, m, l;
-      bf_split3_scalar(w, h, m, l);
-      out |= (piece == 0 ? h : (piece == 1 ? m : l)) << (16 * e);
-    }
-    dst[idx] = out;
-  }
-}
-
-// acc[0][t] (+)= W-pack(t, :) x b[0][:] with the three-piece bf16 products (NT = 1 form of gemm_pack; same INIT meaning, same result
-// tile layout -- the C/D map of the MFMA does not depend on the input type)
-template <int OT, int KS, int INIT>
-__device__ __forceinline__ void gemm_bf(v4f (&acc)[1][OT], const float (&b)[1][KS], const uint32_t* __restrict__ w,
-                                        const float* __restrict__ bias, int lane) {
-  constexpr int K8 = (KS + 7) / 8;
-  v4u B[3][K8];
-#pragma unroll
-  for (int S = 0; S < K8; ++S)
-#pragma unroll
-    for (int up = 0; up < 4; ++up) {
-      const int s0 = 8 * S + 2 * up;  // KS is even or the last slot is a zero pad
-      uint32_t h, m, l;
-      bf_split_pair3(s0 < KS ? b[0][s0 < KS ? s0 : 0] : 0.0f, s0 + 1 < KS ? b[0][s0 + 1 < KS ? s0 + 1 : 0] : 0.0f, h, m, l);
-      B[0][S][up] = h, B[1][S][up] = m, B[2][S][up] = l;
-    }
-  if (INIT != 0) {
-#pragma unroll
-    for (int t = 0; t < OT; ++t) {
-      v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (INIT == 2) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
-      acc[0][t] = bv;
-    }
-  }
-  auto mf = [](const v4u& a, const v4u& bb, const v4f& c) __attribute__((always_inline)) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, bb), c, 0, 0, 0);
-  };
-  constexpr int NF = OT * K8;  // fragment f = S * OT + t: three 16-byte pieces each, requested one fragment ahead
-  v4u A[2][3];
-  auto load = [&](int f, int slot) __attribute__((always_inline)) {
-    const int t = f % OT, S = f / OT;
-    const uint32_t* pw = w + (((t * K8 + S) * 3) * 64 + lane) * 4;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) A[slot][p] = *reinterpret_cast<const v4u*>(pw + p * 256);
-  };
-  load(0, 0);
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    if (f + 1 < NF) load(f + 1, (f + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
-    const int t = f % OT, S = f / OT, k = f & 1;
-    v4f c = acc[0][t];
-    c = mf(A[k][0], B[0][S], c);
-    c = mf(A[k][0], B[1][S], c);
-    c = mf(A[k][1], B[0][S], c);
-    c = mf(A[k][0], B[2][S], c);
-    c = mf(A[k][2], B[0][S], c);
-    c = mf(A[k][1], B[1][S], c);
-    acc[0][t] = c;
-  }
-}
-
 // accumulator / bias-sum slots of a wave (items of 64 lanes x 4 floats; the slab keeps this order).  Part 0 owns the accumulator
 // items [0, A1) and the bias tiles [0, D1S); part 1 the rest.
 template <int TBMAX>
@@ -1648,9 +1687,28 @@ struct TfSlots {
 };
 constexpr int TF_CHUNK = 32;  // items per round of the end-of-launch reduction over the 4 waves (4 x 32 x 1 KiB = 128 KiB of LDS)
 
-struct BfOffs {  // LDS dword offsets (from the bf16 region) of the converted layers' bf16x3 packs, -1: layer keeps its fp32 pack
-  int f[NLAYERS], t[NTLAYERS];
-};
+// In-kernel phase stamps of the transpose-free backward (tools/stamp_fbwd.py builds this file with -DUMHS_TF_STAMP into its own
+// library): s_memtime at the phase boundaries of every tile, pinned by scheduling barriers, summed per phase by wave 0 of workgroup 0.
+#ifdef UMHS_TF_STAMP
+__device__ unsigned long long g_tf_stamp[2][24];
+#define TF_STAMP(k_)                                  \
+  do {                                                \
+    __builtin_amdgcn_sched_barrier(0);                \
+    stamp_[k_] = __builtin_readcyclecounter();        \
+    __builtin_amdgcn_sched_barrier(0);                \
+  } while (0)
+extern "C" int umhs_debug_tf_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tf_stamp), sizeof(unsigned long long) * 48);
+}
+extern "C" int umhs_debug_tf_stamps_clear() {
+  unsigned long long z[48] = {};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tf_stamp), z, sizeof(z));
+}
+#else
+#define TF_STAMP(k_) \
+  do {               \
+  } while (0)
+#endif
 
 // BF: the fp32 chain (forward recompute + dX) of every layer with >= 7 k-steps runs as three-piece bf16 products (gemm_bf); the
 // 4-step layers (the band tiles' products, the out-layer transposes) keep the fp32 MFMA.
@@ -1670,14 +1728,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
 #define TF_GEMM_F(OT_, KS_, INIT_, ACC_, B_, LID_)                                                             \
   do {                                                                                                          \
     if constexpr (BF)                                                                                           \
-      gemm_bf<OT_, KS_, INIT_>(ACC_, B_, wbf + bo.f[LID_], lds + pd.L[LID_].off_b, lane);                       \
+      gemm_bf<OT_, KS_, NT, INIT_>(ACC_, B_, wbf + bo.f[LID_], lds + pd.L[LID_].off_b, lane);                       \
     else                                                                                                        \
       gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, lds + pd.L[LID_].off_w, lds + pd.L[LID_].off_b, lane);           \
   } while (0)
 #define TF_GEMM_T(OT_, KS_, INIT_, ACC_, B_, TID_)                                            \
   do {                                                                                         \
     if constexpr (BF)                                                                          \
-      gemm_bf<OT_, KS_, INIT_>(ACC_, B_, wbf + bo.t[TID_], nullptr, lane);                      \
+      gemm_bf<OT_, KS_, NT, INIT_>(ACC_, B_, wbf + bo.t[TID_], nullptr, lane);                      \
     else                                                                                       \
       gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, wT + td.L[TID_].off, nullptr, lane);            \
   } while (0)
@@ -1741,6 +1799,12 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     const bool ok = n < io.n;
     if (!ok) n = io.n - 1;
     if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
+#ifdef UMHS_TF_STAMP
+    unsigned long long stamp_[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) stamp_[k] = 0;
+#endif
+    TF_STAMP(0);
     v4f t4[NT][4];
     float in27[NT][7];
     float pe[3];
@@ -1761,21 +1825,28 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       z1[0] = to_swapped<true>(dzo[0], ident, db2);
       to_swapped_n<4, false>(xS, a2[0], ident);
       dw_pairs<1, 4>(acc2, z1, xS);
+      TF_STAMP(8);
       v4f g4[NT][4];
       gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
       float dz1[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+      TF_STAMP(9);
       to_swapped_n<4, true>(zS, dz1[0], ident, db1);
       to_swapped_n<4, false>(xS, a1[0], ident);
+      TF_STAMP(10);
       dw_pairs<4, 4>(acc1, zS, xS);
+      TF_STAMP(11);
       TF_GEMM_T(4, 16, 1, g4, dz1, t1);
       float dz0[NT][16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
+      TF_STAMP(12);
       to_swapped_n<4, true>(zS, dz0[0], ident, db0);
       dw_pairs<4, 2>(acc0, zS, x27S);
+      TF_STAMP(13);
       TF_GEMM_T(1, 16, 0, dbo4, dz0, t0);
+      TF_STAMP(14);
     };
     if constexpr (PART == 0) {
       // This tile's upstream gradients, all band tiles: requested here, consumed after the head MLP's forward recompute (with one
@@ -1807,6 +1878,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       TF_GEMM_F(4, 16, 2, t4, a1h, L_H1);
       relu_to<4, NT>(a2h, t4);
       TF_GEMM_F(1, 16, 2, hd4, a2h, L_H2);
+      TF_STAMP(1);
       fl4[0][0] = cur.x0;
       HeadState<NT> hs;
       head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
@@ -1828,6 +1900,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
           hdirS[0] = to_swapped<false>(hdir[0], ident);
         }
       }
+      TF_STAMP(2);
       // =================== band tiles: mixing and the specular tail (the next tile's gradients are requested a tile ahead) ===
       // (two accumulators each for d m and d hdir, even / odd band tiles: consecutive tiles do not wait for each other's MFMAs)
       v4f dm4[NT][1], dhd4[NT][1], dm4b[NT][1], dhd4b[NT][1];
@@ -1860,6 +1933,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
           }
         }
       }
+      TF_STAMP(3);
       ds1 = xq_sum(ds1);
       dm4[0][0] += dm4b[0][0], dhd4[0][0] += dhd4b[0][0];
       // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
@@ -1894,6 +1968,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         dzS[0] = to_swapped<true>(dz, ident, &db_[SL::D_D0 - DB0]);
         dw_pairs<1, 2>(&acc_[SL::A_D0 - A0], dzS, dirS);
       }
+      TF_STAMP(7);
       mlp3_bwd(dhs, a2h, a1h, x27S, &acc_[SL::A_H2 - A0], &acc_[SL::A_H1 - A0], &acc_[SL::A_H0 - A0], &db_[SL::D_H2 - DB0], &db_[SL::D_H1 - DB0], &db_[SL::D_H0 - DB0], T_H2,
                T_H1, T_H0);
       if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
@@ -1909,11 +1984,13 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       TF_GEMM_F(1, 16, 2, bo4, h, L_B1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) in27[0][3 + r] = bo4[0][0][r];  // slot 0 (sigma_raw) meets a zero weight column
+      TF_STAMP(1);
       float a1f[NT][16], a2f[NT][16];
       TF_GEMM_F(4, 7, 2, t4, in27, L_F0);
       relu_to<4, NT>(a1f, t4);
       TF_GEMM_F(4, 16, 2, t4, a1f, L_F1);
       relu_to<4, NT>(a2f, t4);
+      TF_STAMP(2);
       STile x27S[2];
       {
         const float pe4[4] = {pe[0], pe[1], pe[2], 0.0f};
@@ -1923,6 +2000,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       float dfl[NT][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) dfl[0][r] = cur.x0[r];
+      TF_STAMP(7);
       mlp3_bwd(dfl, a2f, a1f, x27S, &acc_[SL::A_F2 - A0], &acc_[SL::A_F1 - A0], &acc_[SL::A_F0 - A0], &db_[SL::D_F2 - DB0], &db_[SL::D_F1 - DB0], &db_[SL::D_F0 - DB0], T_F2,
                T_F1, T_F0);
       // =================== mlp_base ======================================================================================
@@ -1938,6 +2016,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         to_swapped_n<4, false>(hS, h[0], ident);
         dw_pairs<1, 4>(&acc_[SL::A_B1 - A0], z1, hS);
       }
+      TF_STAMP(15);
       v4f g4[NT][4];
       gemm_pack<4, 4, NT, 1>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
       float dzb0[NT][16];
@@ -1949,8 +2028,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         to_swapped_n<2, false>(eS, encf[0], ident);  // column c = 4q'+u <-> hash feature 8q'+u ([0]) / 8q'+4+u ([1])
         dw_pairs<4, 2>(&acc_[SL::A_B0 - A0], zS, eS);
       }
+      TF_STAMP(16);
       v4f de4[NT][2];
       TF_GEMM_T(2, 16, 1, de4, dzb0, T_B0);
+      TF_STAMP(17);
       if (ok && io.d_enc) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -1961,6 +2042,15 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
           }
       }
     }
+    TF_STAMP(18);
+#ifdef UMHS_TF_STAMP
+    if (blockIdx.x == 0 && tid == 0) {
+      unsigned long long last = stamp_[0];
+      for (int k = 1; k < 19; ++k)
+        if (stamp_[k]) g_tf_stamp[PART][k] += stamp_[k] - last, last = stamp_[k];
+      g_tf_stamp[PART][0] += 1;
+    }
+#endif
     cur = nxt;
   }
   // =================== sum the four waves' accumulators through LDS (the pack images are dead), one slab per workgroup ======
@@ -2212,6 +2302,83 @@ static int set_lds(K kernel, size_t bytes) {
   return UMHS_OK;
 }
 
+// ---- forward on the bf16x3 chain: which layers convert, the compact LDS image, the global bf16x3 image ---------------------------
+struct FwdBfPlan {
+  PackDesc pd;  // offsets local to the compact fp32 part
+  FwdBfArgs args;
+  BfPlan bp;
+  size_t lds;
+};
+static bool fwd_bf_plan(const PackDesc& pd_all, FwdBfPlan* fp) {
+  const int conv[] = {L_B0, L_B1, L_H0, L_H1, L_H2, L_F0, L_F1, L_F2};
+  fp->pd = pd_all;
+  BfOffs& bo = fp->args.bo;
+  for (int l = 0; l < NLAYERS; ++l) bo.f[l] = -1;
+  for (int l = 0; l < NTLAYERS; ++l) bo.t[l] = -1;
+  fp->bp.n = 0;
+  int off = 0;
+  for (int l : conv) {
+    const LayerDesc& L = pd_all.L[l];
+    if (L.OT == 0) continue;
+    const int KS4 = (L.KS + 3) / 4;
+    fp->bp.c[fp->bp.n++] = BfConv{0, L.off_w, KS4, L.OT, off};
+    bo.f[l] = off, off += L.OT * ((KS4 + 1) / 2) * 3 * 256;
+  }
+  fp->bp.total = off;
+  ImgSegs& sf = fp->args.seg_f;
+  sf.n = 0;
+  bool ok = true;
+  auto add = [&](int src, int dst, int len) {
+    if (len == 0) return;
+    if (sf.n && sf.src[sf.n - 1] + sf.len[sf.n - 1] == src && sf.dst[sf.n - 1] + sf.len[sf.n - 1] == dst) {
+      sf.len[sf.n - 1] += len;
+      return;
+    }
+    if (sf.n == 6) {
+      ok = false;
+      return;
+    }
+    sf.src[sf.n] = src, sf.dst[sf.n] = dst, sf.len[sf.n] = len, ++sf.n;
+  };
+  int cur = 0;
+  for (int l = 0; l < NLAYERS; ++l) {
+    const LayerDesc& L = pd_all.L[l];
+    if (bo.f[l] >= 0 || L.OT == 0) continue;
+    const int len = L.OT * ((L.KS + 3) / 4) * 256;
+    add(L.off_w, cur, len);
+    fp->pd.L[l].off_w = cur, cur += len;
+  }
+  for (int l = 0; l < NLAYERS; ++l) {
+    const LayerDesc& L = pd_all.L[l];
+    if (l == L_MX || L.OT == 0) continue;
+    add(L.off_b, cur, 16 * L.OT);
+    fp->pd.L[l].off_b = cur, cur += 16 * L.OT;
+  }
+  fp->args.bf_off = (cur + 3) & ~3;
+  fp->args.seg_b.n = 1, fp->args.seg_b.src[0] = 0, fp->args.seg_b.dst[0] = 0, fp->args.seg_b.len[0] = off;
+  fp->args.bf_image = nullptr;
+  fp->lds = (size_t)(fp->args.bf_off + off) * 4;
+  return ok && fp->lds <= 160 * 1024;
+}
+// workspace of the forward: [fp32 pack image][bf16x3 image of the converted layers]
+static size_t fwd_ws_need(const PackDesc& pd, bool dens) {
+  size_t need = (size_t)((pd.total + 63) & ~63) * 4 + 512;
+  if (!dens) {
+    FwdBfPlan fp;
+    fwd_bf_plan(pd, &fp);
+    need += (size_t)fp.bp.total * 4;
+  }
+  return need;
+}
+static void launch_fwd_packs(const PackDesc& pd, bool dens, float* img, umhs_stream_t stream) {
+  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
+  if (dens) return;
+  FwdBfPlan fp;
+  fwd_bf_plan(pd, &fp);
+  hipLaunchKernelGGL(field_pack_bf_kernel, dim3((fp.bp.total + 255) / 256), dim3(256), 0, umhs_s(stream), fp.bp, (const float*)img,
+                     (const float*)nullptr, reinterpret_cast<uint32_t*>(img + ((pd.total + 63) & ~63)));
+}
+
 extern "C" size_t umhs_field_fwd_workspace_bytes(const umhs_field_cfg* cfg) {
   if (check_cfg(cfg)) return 0;
   umhs_field_params dummy = {};
@@ -2221,7 +2388,7 @@ extern "C" size_t umhs_field_fwd_workspace_bytes(const umhs_field_cfg* cfg) {
   PackDesc pd;
   int TB;
   if (build_pack_desc(cfg, &dummy, &pd, &TB)) return 0;
-  return (size_t)pd.total * 4 + 512;
+  return fwd_ws_need(pd, cfg->density_only != 0);
 }
 
 // Builds the forward pack image into the workspace ahead of time (depends on the parameters only); pass pack_ready = 1 and
@@ -2235,9 +2402,9 @@ extern "C" int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_fiel
   int TB;
   rc = build_pack_desc(cfg, params, &pd, &TB);
   if (rc) return rc;
-  if (workspace_bytes < (size_t)pd.total * 4 + 512) return UMHS_ERR_WORKSPACE;
+  if (workspace_bytes < fwd_ws_need(pd, cfg->density_only != 0)) return UMHS_ERR_WORKSPACE;
   float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
+  launch_fwd_packs(pd, cfg->density_only != 0, img, stream);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
@@ -2277,41 +2444,57 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances, io.feat_logits = dens ? nullptr : feat_logits;
   const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
-  static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;  // tuning knob
-  const int tile_samples = 128;  // every variant processes 128 samples per workgroup iteration
-  const int64_t ntiles = (n + tile_samples - 1) / tile_samples;
+  // UMHS_FWD_VARIANT (tuning knob): 0 = bf16x3 chain where it applies (default), 1 = fp32 chain with 8-wave workgroups, 2 = fp32 chain
+  static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;
   const float* image = nullptr;
   if (workspace) {  // optional: prebuilt pack image (without it every workgroup gathers the image itself)
-    if (workspace_bytes < (size_t)pd.total * 4 + 512) return UMHS_ERR_WORKSPACE;
+    if (workspace_bytes < fwd_ws_need(pd, dens)) return UMHS_ERR_WORKSPACE;
     float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (!pack_ready) {  // else: umhs_field_fwd_prepare already built it in this workspace
-      hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
+      launch_fwd_packs(pd, dens, img, stream);
       UMHS_CHECK_LAUNCH();
     }
     image = img;
   }
+  FwdBfPlan fp;
+  FwdBfArgs no_bf = {};
+  const bool bf = !dens && image && (fwd_variant == 0 || fwd_variant >= 3) && fwd_bf_plan(pd, &fp);
+  if (bf) fp.args.bf_image = image + ((pd.total + 63) & ~63);
+  // samples per workgroup iteration: 16 x NT x waves
+  const int tile_samples = bf ? (fwd_variant == 3 ? 192 : 256) : 128;
+  const int64_t ntiles = (n + tile_samples - 1) / tile_samples;
   // the fused density query gathers from the hash table inside the kernel: it wants every wave slot its 112 VGPRs allow (4 per SIMD)
-  const int blocks_per_cu = (hash && lds_bytes <= 36 * 1024) ? 4 : (lds_bytes <= 78 * 1024 ? 2 : 1);
+  const int blocks_per_cu = bf ? 1 : ((hash && lds_bytes <= 36 * 1024) ? 4 : (lds_bytes <= 78 * 1024 ? 2 : 1));
   const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
-  const size_t lds_launch = lds_bytes;
+  const size_t lds_launch = bf ? fp.lds : lds_bytes;
 #define LAUNCH_FWD(S, D, NT_, W_, ...)                                                                                       \
   do {                                                                                                                       \
     rc = set_lds(field_fwd_kernel<S, D, NT_, W_, ##__VA_ARGS__>, lds_launch);                                                 \
     if (rc) return rc;                                                                                                       \
     hipLaunchKernelGGL((field_fwd_kernel<S, D, NT_, W_, ##__VA_ARGS__>), dim3(grid), dim3(64 * W_), lds_launch, umhs_s(stream), \
-                       io, pd, image);                                                                                       \
+                       io, bf ? fp.pd : pd, image, bf ? fp.args : no_bf);                                                    \
   } while (0)
   if (dens && hash)
     LAUNCH_FWD(false, true, 2, 4, true);
   else if (dens)
     LAUNCH_FWD(false, true, 2, 4);
   else if (spec) {
-    if (fwd_variant == 1)
+    if (bf && fwd_variant == 3)
+      LAUNCH_FWD(true, false, 1, 12, false, true);
+    else if (bf && fwd_variant == 4)
+      LAUNCH_FWD(true, false, 1, 16, false, true);
+    else if (bf)
+      LAUNCH_FWD(true, false, 2, 8, false, true);
+    else if (fwd_variant == 1)
       LAUNCH_FWD(true, false, 1, 8);
     else
       LAUNCH_FWD(true, false, 2, 4);
-  } else
-    LAUNCH_FWD(false, false, 2, 4);
+  } else {
+    if (bf)
+      LAUNCH_FWD(false, false, 2, 8, false, true);
+    else
+      LAUNCH_FWD(false, false, 2, 4);
+  }
 #undef LAUNCH_FWD
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
