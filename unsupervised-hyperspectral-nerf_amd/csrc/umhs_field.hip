@@ -92,19 +92,6 @@ __device__ __forceinline__ void build_fwd_image(float* lds, const PackDesc& pd) 
   }
 }
 
-// The same image built ONCE per call into global memory (each workgroup then copies it with float4 loads instead
-// of re-gathering ~19k weights through the index maps: that gather cost ~60 us per launch when done per workgroup).
-__global__ __launch_bounds__(256) void field_pack_fwd_kernel(PackDesc pd, float* __restrict__ dst) {
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < pd.total_w; idx += gridDim.x * 256) dst[idx] = fwd_pack_value(pd, idx);
-  if (blockIdx.x == 0) {
-    for (int li = 0; li < NLAYERS; ++li) {
-      const LayerDesc& L = pd.L[li];
-      if (li == L_MX) continue;
-      for (int o = threadIdx.x; o < 16 * L.OT; o += 256) dst[L.off_b + o] = (L.b && o < L.OUT) ? L.b[o] : 0.0f;
-    }
-  }
-}
-
 // LDS image = image[first .. total): copy when a prebuilt image is given, else gather-build in place
 __device__ __forceinline__ void load_fwd_image(float* lds, const PackDesc& pd, const float* __restrict__ image, int first) {
   if (image) {
@@ -412,30 +399,6 @@ __device__ __forceinline__ void bf_split3_scalar(float x, uint32_t& h, uint32_t&
   const __bf16 bl = (__bf16)r2;
   h = (uint16_t)__builtin_bit_cast(short, bh), m = (uint16_t)__builtin_bit_cast(short, bm), l = (uint16_t)__builtin_bit_cast(short, bl);
 }
-__global__ __launch_bounds__(256) void field_pack_bf_kernel(BfPlan bp, const float* __restrict__ img_f, const float* __restrict__ img_t,
-                                                            uint32_t* __restrict__ dst) {
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < bp.total; idx += gridDim.x * 256) {
-    int ci = 0;
-    while (ci + 1 < bp.n && idx >= bp.c[ci + 1].dst_off) ++ci;
-    const BfConv& c = bp.c[ci];
-    const int rel = idx - c.dst_off;
-    const int up = rel & 3, lane = (rel >> 2) & 63, blk = rel >> 8;  // blk = (t*K8 + S)*3 + piece
-    const int piece = blk % 3, ts = blk / 3;
-    const int K8 = (c.KS4 + 1) >> 1, t = ts / K8, S = ts % K8;
-    const float* src = (c.src_img ? img_t : img_f) + c.src_off;
-    uint32_t out = 0;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int u = 2 * up + e, s4 = 2 * S + (u >> 2);
-      const float w = s4 < c.KS4 ? src[((t * c.KS4 + s4) * 64 + lane) * 4 + (u & 3)] : 0.0f;
-      uint32_t h, m, l;
-      bf_split3_scalar(w, h, m, l);
-      out |= (piece == 0 ? h : (piece == 1 ? m : l)) << (16 * e);
-    }
-    dst[idx] = out;
-  }
-}
-
 // acc[ct][t] (+)= W-pack(t, :) x b[ct][:] with the three-piece bf16 products (same INIT meaning and result tile layout as gemm_pack
 // -- the C/D map of the MFMA does not depend on the input type; the NT sample tiles share every weight fragment)
 #ifndef BF_PF
@@ -695,26 +658,79 @@ struct TPackDesc {
 };
 
 //   wT[off + ((t*KS4 + s4)*64 + lane)*4 + ss] = W[k(4*s4+ss, lane>>4)][rowmap(16t + (lane&15))]
-__global__ __launch_bounds__(256) void field_pack_T_kernel(TPackDesc td, float* __restrict__ dst) {
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < td.total; idx += gridDim.x * 256) {
-    int li = 0;
-    while (li + 1 < NTLAYERS && idx >= td.L[li + 1].off) ++li;
-    const TDesc& L = td.L[li];
-    const int rel = idx - L.off;
-    const int ss = rel & 3, ln = (rel >> 2) & 63, blk = rel >> 8;
-    const int KS4 = (L.KS + 3) >> 2;
-    const int t = blk / KS4, s = (blk % KS4) * 4 + ss;
-    const int rho = 16 * t + (ln & 15), q = ln >> 4;
-    const int k = 16 * (s >> 2) + 4 * q + (s & 3);  // dZ row held by (step s, quarter q)
-    float v = 0.0f;
-    if (L.rowmap == 2) {
-      if (rho < L.OUT && k < L.IN) v = L.W[(size_t)rho * L.IN + k];  // E[c][b], OUT=C, IN=B
-    } else if (s < L.KS && k < L.OUT) {
-      int in = rho;
-      if (L.rowmap == 1) in = (rho >= 1 && rho <= 15) ? 12 + rho - 1 : -1;
-      if (in >= 0 && in < L.IN) v = L.W[(size_t)k * L.IN + in];
+__device__ __forceinline__ float t_pack_value(const TPackDesc& td, int idx) {
+  int li = 0;
+  while (li + 1 < NTLAYERS && idx >= td.L[li + 1].off) ++li;
+  const TDesc& L = td.L[li];
+  const int rel = idx - L.off;
+  const int ss = rel & 3, ln = (rel >> 2) & 63, blk = rel >> 8;
+  const int KS4 = (L.KS + 3) >> 2;
+  const int t = blk / KS4, s = (blk % KS4) * 4 + ss;
+  const int rho = 16 * t + (ln & 15), q = ln >> 4;
+  const int k = 16 * (s >> 2) + 4 * q + (s & 3);  // dZ row held by (step s, quarter q)
+  float v = 0.0f;
+  if (L.rowmap == 2) {
+    if (rho < L.OUT && k < L.IN) v = L.W[(size_t)rho * L.IN + k];  // E[c][b], OUT=C, IN=B
+  } else if (s < L.KS && k < L.OUT) {
+    int in = rho;
+    if (L.rowmap == 1) in = (rho >= 1 && rho <= 15) ? 12 + rho - 1 : -1;
+    if (in >= 0 && in < L.IN) v = L.W[(size_t)k * L.IN + in];
+  }
+  return v;
+}
+
+// Every weight image of one direction in ONE launch, each dword computed straight from the parameters: the fp32 forward image
+// (weights + biases), the transposed image, the bf16x3 image of the converted layers.  (As three dependent launches -- fp32 images,
+// then the bf16x3 image read back from them -- the packs of a step cost 26 us of small kernels; 2 x 6 us like this.)
+struct PackJob {
+  PackDesc pd;
+  TPackDesc td;
+  BfPlan bp;
+  float* img;    // [pd.total] or null
+  float* wT;     // [td.total] or null
+  uint32_t* bf;  // [bp.total] or null
+};
+__global__ __launch_bounds__(256) void field_pack_all_kernel(PackJob jb) {
+  const int n_img = jb.img ? jb.pd.total : 0, n_wT = jb.wT ? jb.td.total : 0, n_bf = jb.bf ? jb.bp.total : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_img + n_wT + n_bf; i += gridDim.x * 256) {
+    if (i < n_img) {
+      float v = 0.0f;
+      if (i < jb.pd.total_w) {
+        v = fwd_pack_value(jb.pd, i);
+      } else {
+        int li = 0;
+        while (li + 1 < NLAYERS && i >= jb.pd.L[li + 1].off_b) ++li;  // off_b is non-decreasing (L_MX has no bias tile)
+        const LayerDesc& L = jb.pd.L[li];
+        const int o = i - L.off_b;
+        v = (li != L_MX && L.b && o < L.OUT) ? L.b[o] : 0.0f;
+      }
+      jb.img[i] = v;
+    } else if (i < n_img + n_wT) {
+      jb.wT[i - n_img] = t_pack_value(jb.td, i - n_img);
+    } else {
+      const int idx = i - n_img - n_wT;
+      int ci = 0;
+      while (ci + 1 < jb.bp.n && idx >= jb.bp.c[ci + 1].dst_off) ++ci;
+      const BfConv& c = jb.bp.c[ci];
+      const int rel = idx - c.dst_off;
+      const int up = rel & 3, lane = (rel >> 2) & 63, blk = rel >> 8;  // blk = (t*K8 + S)*3 + piece
+      const int piece = blk % 3, ts = blk / 3;
+      const int K8 = (c.KS4 + 1) >> 1, t = ts / K8, S = ts % K8;
+      uint32_t out = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int u = 2 * up + e, s4 = 2 * S + (u >> 2);
+        float w = 0.0f;
+        if (s4 < c.KS4) {
+          const int src = c.src_off + ((t * c.KS4 + s4) * 64 + lane) * 4 + (u & 3);
+          w = c.src_img ? t_pack_value(jb.td, src) : fwd_pack_value(jb.pd, src);
+        }
+        uint32_t h, m, l;
+        bf_split3_scalar(w, h, m, l);
+        out |= (piece == 0 ? h : (piece == 1 ? m : l)) << (16 * e);
+      }
+      jb.bf[idx] = out;
     }
-    dst[idx] = v;
   }
 }
 
@@ -2371,12 +2387,15 @@ static size_t fwd_ws_need(const PackDesc& pd, bool dens) {
   return need;
 }
 static void launch_fwd_packs(const PackDesc& pd, bool dens, float* img, umhs_stream_t stream) {
-  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pd.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pd, img);
-  if (dens) return;
-  FwdBfPlan fp;
-  fwd_bf_plan(pd, &fp);
-  hipLaunchKernelGGL(field_pack_bf_kernel, dim3((fp.bp.total + 255) / 256), dim3(256), 0, umhs_s(stream), fp.bp, (const float*)img,
-                     (const float*)nullptr, reinterpret_cast<uint32_t*>(img + ((pd.total + 63) & ~63)));
+  PackJob jb = {};
+  jb.pd = pd, jb.img = img;
+  int n = pd.total;
+  if (!dens) {
+    FwdBfPlan fp;
+    fwd_bf_plan(pd, &fp);
+    jb.bp = fp.bp, jb.bf = reinterpret_cast<uint32_t*>(img + ((pd.total + 63) & ~63)), n += fp.bp.total;
+  }
+  hipLaunchKernelGGL(field_pack_all_kernel, dim3((n + 255) / 256), dim3(256), 0, umhs_s(stream), jb);
 }
 
 extern "C" size_t umhs_field_fwd_workspace_bytes(const umhs_field_cfg* cfg) {
@@ -2444,7 +2463,8 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances, io.feat_logits = dens ? nullptr : feat_logits;
   const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
-  // UMHS_FWD_VARIANT (tuning knob): 0 = bf16x3 chain where it applies (default), 1 = fp32 chain with 8-wave workgroups, 2 = fp32 chain
+  // UMHS_FWD_VARIANT (tuning knob): 0 = bf16x3 chain where it applies (default), 1 = fp32 chain with 8-wave workgroups, 2 = fp32 chain,
+  // 3 / 4 / 5 = bf16x3 chain forced to 12 x 1 / 16 x 1 / 8 x 2 (waves x sample tiles per wave)
   static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;
   const float* image = nullptr;
   if (workspace) {  // optional: prebuilt pack image (without it every workgroup gathers the image itself)
@@ -2458,7 +2478,7 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   }
   FwdBfPlan fp;
   FwdBfArgs no_bf = {};
-  const bool bf = !dens && image && (fwd_variant == 0 || fwd_variant >= 3) && fwd_bf_plan(pd, &fp);
+  const bool bf = !dens && image && (fwd_variant == 0 || fwd_variant >= 3) && fwd_bf_plan(pd, &fp);  // no image: each workgroup gathers fp32 packs
   if (bf) fp.args.bf_image = image + ((pd.total + 63) & ~63);
   // samples per workgroup iteration: 16 x NT x waves
   const int tile_samples = bf ? (fwd_variant == 3 ? 192 : 256) : 128;
@@ -2481,7 +2501,7 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   else if (spec) {
     if (bf && fwd_variant == 3)
       LAUNCH_FWD(true, false, 1, 12, false, true);
-    else if (bf && fwd_variant == 4)
+    else if (bf && fwd_variant == 4)  // 16 x 1: alone 90 vs 97 us at C2, but inside the step (side-stream kernels beside it) 0.875 vs 0.846 ms
       LAUNCH_FWD(true, false, 1, 16, false, true);
     else if (bf)
       LAUNCH_FWD(true, false, 2, 8, false, true);
@@ -2870,14 +2890,13 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
 }
 
 static void launch_bwd_packs(const BwdPlan& pl, float* wT, float* img, float* bfimg, umhs_stream_t stream) {
-  hipLaunchKernelGGL(field_pack_T_kernel, dim3((pl.td.total + 255) / 256), dim3(256), 0, umhs_s(stream), pl.td, wT);
-  hipLaunchKernelGGL(field_pack_fwd_kernel, dim3((pl.pd_all.total_w + 255) / 256), dim3(256), 0, umhs_s(stream), pl.pd_all, img);
-  BfPlan bp;
+  PackJob jb = {};
+  jb.pd = pl.pd_all, jb.td = pl.td, jb.img = img, jb.wT = wT;
   int df[NLAYERS], dt[NTLAYERS], pr[2][2];
-  build_bf_plan(pl, &bp, df, dt, pr);  // the three-piece bf16 images are derived from the two fp32 images just queued
-  if (bp.total > 0)
-    hipLaunchKernelGGL(field_pack_bf_kernel, dim3((bp.total + 255) / 256), dim3(256), 0, umhs_s(stream), bp, (const float*)img,
-                       (const float*)wT, reinterpret_cast<uint32_t*>(bfimg));
+  build_bf_plan(pl, &jb.bp, df, dt, pr);
+  if (jb.bp.total > 0) jb.bf = reinterpret_cast<uint32_t*>(bfimg);
+  const int n = pl.pd_all.total + pl.td.total + jb.bp.total;
+  hipLaunchKernelGGL(field_pack_all_kernel, dim3((n + 255) / 256), dim3(256), 0, umhs_s(stream), jb);
 }
 
 // The weight images of the backward (transposed packs + forward pack image) depend on the parameters only: a caller may build
