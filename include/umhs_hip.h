@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 4
+#define UMHS_ABI_VERSION 5
 
 enum {
   UMHS_OK = 0,
@@ -155,6 +155,26 @@ int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
 int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* pos01, const float* table,
                        const float* scalings, int log2_T, const float* selector, int64_t n, float* sigma, float* sigma_raw,
                        float* emb, void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
+/* The training step's forward as two launches with the rendering weights known in between (umhs_model.py:239-327: field ->    */
+/* renderers; here the per-ray band sums of the [N,B] outputs are formed inside the heads kernel, so spectral2 / specular --     */
+/* which carry no loss, umhs_model.py:373-374 -- never exist per sample):                                                        */
+/*   umhs_field_base_fwd : mlp_base only (sigma, sigma_raw, emb as umhs_field_fwd writes them) from the FULL configuration's      */
+/*                         workspace (umhs_field_fwd_workspace_bytes / umhs_field_fwd_prepare: one set of pack images for both).  */
+/*   umhs_composite_fwd with no value streams: weights, accumulation, depth.                                                     */
+/*   umhs_field_heads_fwd: everything after mlp_base from emb [N,15]; comp_*[r][b] = sum_{n in ray r} weights[n] stream[n][b]    */
+/*                         (SpectralRenderer, renderers.py:18-53) for spectral / spectral2 / specular ([R,B]; the last two NULL   */
+/*                         without the specular head), abundances [N,C], feat_logits [N,16]; spectral [N,B] per sample only when  */
+/*                         given.  ray_indices [N] non-decreasing; packed_info [R,2] as umhs_pack_info.  The sums are taken in a  */
+/*                         fixed order (per 16-sample tile, then tile by tile): same bits every run.                             */
+int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
+                        int64_t stride_l, const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
+                        void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
+size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n);
+int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb, const float* world_pos,
+                         const float* directions, int64_t n, const float* weights, const int64_t* ray_indices,
+                         const int64_t* packed_info, int64_t n_rays, float* spectral, float* abundances, float* feat_logits,
+                         float* comp_spectral, float* comp_spectral2, float* comp_specular, void* scratch, size_t scratch_bytes,
+                         void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
 /* feat_logits (optional, [N,16]): the feature_mlp logits, saved so that umhs_field_bwd can run its heads as two kernels   */
 /* (head MLP + directional + mixing / feature MLP) with every weight pack LDS-resident; NULL there = one fused kernel.       */
 /* builds the pack image ahead of time (parameters only): then pass pack_ready = 1 with the same workspace */

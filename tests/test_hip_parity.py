@@ -643,3 +643,49 @@ def test_field_bwd_overwrites_every_parameter_gradient(C, B, spec):
             assert torch.equal(got, want), name
         # without the specular head nothing reaches mlp_directional: the entries the reduce does not visit stay at their initial zero
         assert all(n.startswith("mlp_directional") for n in untouched) and (not spec or not untouched), untouched
+
+
+@pytest.mark.parametrize("C,B,spec", [(6, 31, True), (4, 40, False), (9, 128, True)])
+def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
+    """umhs_field_base_fwd -> weights -> umhs_field_heads_fwd against umhs_field_fwd + umhs_composite_fwd: per-sample outputs bit for
+    bit (same kernels' arithmetic), per-ray band sums to rounding (another, fixed, summation order), run-to-run identical.  Rays with
+    no samples, rays shorter than a 16-sample tile (several inside one tile), rays across many tiles, N not a multiple of 16."""
+    ops = _ops()
+    _, _, layout, flat, fs = make_case(C, B, spec, 8, 8, log2_T=12)
+    g = torch.Generator().manual_seed(B)
+    counts = torch.tensor([0, 3, 2, 0, 1, 40, 17, 16, 5, 4, 3, 200, 0, 7, 33, 1, 1, 1, 90, 0], dtype=torch.int64)
+    R, n = counts.numel(), int(counts.sum())
+    assert n % 16 != 0
+    starts = torch.cumsum(counts, 0) - counts
+    packed_info = torch.stack([starts, counts], 1).contiguous().to(DEV)
+    ray_idx = torch.repeat_interleave(torch.arange(R), counts).to(DEV)
+    enc = ((torch.rand(16, n, 2, generator=g) - 0.5)).to(DEV)
+    wpos = (torch.rand(n, 3, generator=g) * 2 - 1).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    sel = (torch.rand(n, generator=g) > 0.1).float().to(DEV)
+    t0 = torch.rand(n, generator=g).to(DEV)
+    t1 = t0 + 0.05
+    ref = ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True, want_logits=True)
+    vals = [ref["spectral"]] + ([ref["spectral2"], ref["specular"]] if spec else [])
+    w_ref, acc_ref, depth_ref, comp_ref = ops.composite_fwd(ref["sigma"], t0, t1, packed_info, vals)
+    base = ops.field_base_fwd(fs, flat, enc, True, sel)
+    for k in ("sigma", "sigma_raw", "emb"):
+        assert torch.equal(base[k], ref[k]), k
+    w, acc, depth, none = ops.composite_fwd(base["sigma"], t0, t1, packed_info, [])
+    assert none == [] and torch.equal(w, w_ref) and torch.equal(acc, acc_ref) and torch.equal(depth, depth_ref)
+    runs = []
+    for rep in range(2):
+        ho = ops.field_heads_fwd(fs, flat, base["emb"], wpos, dirs, w, ray_idx, packed_info, pack_ready=True, release=False)
+        for k in ("spectral", "abundances", "feat_logits"):
+            assert torch.equal(ho[k], ref[k]), k
+        assert len(ho["comp"]) == len(comp_ref)
+        for i, (a, b) in enumerate(zip(ho["comp"], comp_ref)):
+            assert_close(f"comp[{i}]", a, b, 2e-6)
+        runs.append([c.clone() for c in ho["comp"]])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    ho = ops.field_heads_fwd(fs, flat, base["emb"], wpos, dirs, w, ray_idx, packed_info, want_spectral=False, want_logits=False,
+                             pack_ready=True, release=False)
+    assert ho["spectral"] is None and ho["feat_logits"] is None
+    for a, b in zip(ho["comp"], runs[0]):
+        assert torch.equal(a, b)

@@ -233,6 +233,12 @@ struct FieldIO {
   const float* feat_logits_in;         // split backward, part 0
   float* d_fl;                         // [N,16] gradient w.r.t. the feature logits (part 0 -> part 1)
   float* d_bo2;                        // [N,16] part 1's share of d_bo (base kernel adds the two)
+  // heads-only forward with the per-ray band sums taken inside the kernel (field_fwd_kernel<.., HEADS = true>)
+  const float* weights;                // [N] rendering weights of the samples
+  const int64_t* ray_of;               // [N] ray of each sample (non-decreasing)
+  float* part;                         // per-16-sample-tile partial sums, see HeadsComp
+  float* comp[3];                      // [R,B] band sums of spectral / spectral2 / specular (rays inside one tile are written here directly)
+  int n_streams;                       // 1 without the specular head, else 3
 };
 
 // NeRF positional encoding slots of quarter q (3 per lane) and SH slots (4 per lane)
@@ -473,7 +479,16 @@ struct FwdBfArgs {
   BfOffs bo;
   const float* bf_image;
 };
-template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES, bool HASH = false, bool BF = false>
+// HEADS: the kernel starts from the base MLP's saved outputs (emb) instead of the hash features -- the density half ran as its own
+// launch, so the rendering weights of every sample are known -- and forms the per-ray band sums of its outputs itself (HeadsComp
+// below): the [N,B] streams that carry no loss (spectral2, specular) are never written, the third only if the caller wants it.
+//
+// Per-ray sums without atomics, same bits every run: a wave's 16-sample tile g = n/16 covers at most a tail of one ray, whole rays,
+// and a head of another.  It stores  A[g][stream][b] = sum over the samples of the tile's FIRST sample's ray,
+// Z[g][stream][b] = the same for its LAST sample's ray (when that is another ray), and writes rays that lie strictly inside the
+// tile straight to comp (no other tile contributes to them).  field_heads_finish_kernel then adds, for every other ray, the A / Z
+// entries of its tiles in tile order.  part[((g*2 + az)*n_streams + stream)*16*TB + b].
+template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES, bool HASH = false, bool BF = false, bool HEADS = false>
 __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void field_fwd_kernel(FieldIO io, PackDesc pd,
                                                                                         const float* __restrict__ image, FwdBfArgs fb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -505,7 +520,9 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
       nn[ct] = ok[ct] ? n : io.n - 1;
     }
     float encf[NT][8];
-    if (HASH) {
+    if (HEADS) {
+      // nothing to load here: the base MLP's outputs are read below
+    } else if (HASH) {
       // The lane's operand slots are the features of levels 4q .. 4q+3 of its sample: it gathers exactly those (8 corners x 4
       // levels, all 32 loads of a sample in flight together) -- the [N,32] feature array never exists.  16 consecutive samples
       // of a ray per quad and level: the same line reuse as the stand-alone gather kernel.
@@ -547,12 +564,22 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
       }
     }
     // ---- mlp_base: 32 -> 64 -> 16 -------------------------------------------------------------
-    v4f h4[NT][4];
-    FWD_GEMM(4, 8, h4, encf, L_B0);
-    float h[NT][16];
-    relu_to<4, NT>(h, h4);
     v4f bo4[NT][1];
-    FWD_GEMM(1, 16, bo4, h, L_B1);
+    if constexpr (HEADS) {
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = 4 * q + r - 1;
+          bo4[ct][0][r] = e >= 0 ? io.emb_in[nn[ct] * 15 + e] : 0.0f;  // slot 0 (sigma_raw) meets a zero weight column
+        }
+    } else {
+      v4f h4[NT][4];
+      FWD_GEMM(4, 8, h4, encf, L_B0);
+      float h[NT][16];
+      relu_to<4, NT>(h, h4);
+      FWD_GEMM(1, 16, bo4, h, L_B1);
+    }
     if (DENSITY_ONLY) {
       store_density<NT>(io, bo4, nn, ok, q);
       continue;
@@ -599,6 +626,25 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
       relu_to<1, NT>(hdir, d4);
     }
     // ---- per 16-band tile: mixing (K = classes) and specular (K = 16 hidden) -------------------------
+    // HEADS: this lane's four rows (samples 4q..4q+3 of each tile): weight, ray; the tile's first / last ray (wave-uniform)
+    float w4[NT][4];
+    int r4[NT][4], rfirst[NT], rlast[NT];
+    if constexpr (HEADS) {
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const int64_t nb0 = tile * TILE + wave * (16 * NT) + ct * 16;  // first sample of the tile
+        const int64_t last = nb0 + 15 < io.n ? nb0 + 15 : io.n - 1;
+        rfirst[ct] = nb0 < io.n ? __builtin_amdgcn_readfirstlane((int)io.ray_of[nb0]) : -1;
+        rlast[ct] = nb0 < io.n ? __builtin_amdgcn_readfirstlane((int)io.ray_of[last]) : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t sidx = nb0 + 4 * q + r;
+          const bool v = sidx < io.n;
+          w4[ct][r] = v ? io.weights[sidx] : 0.0f;
+          r4[ct][r] = v ? (int)io.ray_of[sidx] : -2;
+        }
+      }
+    }
 #pragma unroll 1  // a runtime loop: left alone hipcc unrolls the (small) no-specular body 8x and spills 200+ registers
     for (int t = 0; t < io.TB; ++t) {
       // transposed tiles: rows = samples 4q+r of the column tile, lanes&15 = bands 16t..16t+15 -> 64-byte row segments
@@ -609,26 +655,62 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
         const int64_t nb = tile * TILE + wave * (16 * NT) + ct * 16 + 4 * q;  // first sample of this lane's 4 rows
+        float val[3][4];  // spectral, spectral2 (mixing only), specular
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float s1r = SPEC ? __shfl(hs.s1[ct], 4 * q + r, 64) : 0.0f;  // s1 lives on lane&15 = sample
+          const float spec = sp[ct][0][r];
+          const float spl = SPEC ? s1r * sigmoidf_(sc[ct][0][r]) : 0.0f;
+          val[0][r] = SPEC ? spec + spl : spec, val[1][r] = spec, val[2][r] = spl;
 #ifdef UMHS_ABL_NO_STORE
           if (nb + r < io.n && b < io.B && sp[ct][0][r] == 1.2345e30f) {
 #else
           if (nb + r < io.n && b < io.B) {
 #endif
-            const float spec = sp[ct][0][r];
-            const float spl = SPEC ? s1r * sigmoidf_(sc[ct][0][r]) : 0.0f;
             const int64_t o = (nb + r) * io.B + b;
-            io.spectral[o] = SPEC ? spec + spl : spec;
-            if (SPEC && io.spectral2) io.spectral2[o] = spec;
-            if (SPEC && io.specular) io.specular[o] = spl;
+            if (!HEADS || io.spectral) io.spectral[o] = val[0][r];
+            if (!HEADS && SPEC && io.spectral2) io.spectral2[o] = spec;
+            if (!HEADS && SPEC && io.specular) io.specular[o] = spl;
+          }
+        }
+        if constexpr (HEADS) {
+          const int64_t g = (tile * TILE + wave * (16 * NT) + ct * 16) >> 4;
+          const int NS = SPEC ? 3 : 1, BP = 16 * io.TB;
+          if (rfirst[ct] >= 0) {
+#pragma unroll
+            for (int sidx = 0; sidx < NS; ++sidx) {
+              float a = 0.0f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) a += (r4[ct][r] == rfirst[ct]) ? w4[ct][r] * val[sidx][r] : 0.0f;
+              a = xq_sum(a);
+              if (q == 0) io.part[((g * 2 + 0) * NS + sidx) * BP + b] = a;
+            }
+            if (rlast[ct] != rfirst[ct]) {  // wave-uniform
+#pragma unroll
+              for (int sidx = 0; sidx < NS; ++sidx) {
+                float z = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z += (r4[ct][r] == rlast[ct]) ? w4[ct][r] * val[sidx][r] : 0.0f;
+                z = xq_sum(z);
+                if (q == 0) io.part[((g * 2 + 1) * NS + sidx) * BP + b] = z;
+              }
+              for (int m = rfirst[ct] + 1; m < rlast[ct]; ++m) {  // rays strictly inside this tile (short rays; rare)
+#pragma unroll
+                for (int sidx = 0; sidx < NS; ++sidx) {
+                  float v = 0.0f;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) v += (r4[ct][r] == m) ? w4[ct][r] * val[sidx][r] : 0.0f;
+                  v = xq_sum(v);
+                  if (q == 0 && b < io.B && io.comp[sidx]) io.comp[sidx][(int64_t)m * io.B + b] = v;
+                }
+              }
+            }
           }
         }
       }
     }
     // ---- per-sample scalars last (conditional stores = branches) -----------------------------------
-    store_density<NT>(io, bo4, nn, ok, q);
+    if (!HEADS) store_density<NT>(io, bo4, nn, ok, q);
     if (io.abund) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
@@ -2325,7 +2407,8 @@ struct FwdBfPlan {
   BfPlan bp;
   size_t lds;
 };
-static bool fwd_bf_plan(const PackDesc& pd_all, FwdBfPlan* fp) {
+static bool fwd_bf_plan(const PackDesc& pd_all, FwdBfPlan* fp, bool base_only = false) {
+  // base_only: the LDS image of the density half run from the FULL image (umhs_field_base_fwd): mlp_base's two packs and biases
   const int conv[] = {L_B0, L_B1, L_H0, L_H1, L_H2, L_F0, L_F1, L_F2};
   fp->pd = pd_all;
   BfOffs& bo = fp->args.bo;
@@ -2359,18 +2442,19 @@ static bool fwd_bf_plan(const PackDesc& pd_all, FwdBfPlan* fp) {
   int cur = 0;
   for (int l = 0; l < NLAYERS; ++l) {
     const LayerDesc& L = pd_all.L[l];
-    if (bo.f[l] >= 0 || L.OT == 0) continue;
+    if (bo.f[l] >= 0 || L.OT == 0 || base_only) continue;
     const int len = L.OT * ((L.KS + 3) / 4) * 256;
     add(L.off_w, cur, len);
     fp->pd.L[l].off_w = cur, cur += len;
   }
   for (int l = 0; l < NLAYERS; ++l) {
     const LayerDesc& L = pd_all.L[l];
-    if (l == L_MX || L.OT == 0) continue;
+    if (l == L_MX || L.OT == 0 || (base_only && l > L_B1)) continue;
     add(L.off_b, cur, 16 * L.OT);
     fp->pd.L[l].off_b = cur, cur += 16 * L.OT;
   }
   fp->args.bf_off = (cur + 3) & ~3;
+  if (base_only) off = bo.f[L_H0] >= 0 ? bo.f[L_H0] : off;  // mlp_base's packs open the bf16x3 image
   fp->args.seg_b.n = 1, fp->args.seg_b.src[0] = 0, fp->args.seg_b.dst[0] = 0, fp->args.seg_b.len[0] = off;
   fp->args.bf_image = nullptr;
   fp->lds = (size_t)(fp->args.bf_off + off) * 4;
@@ -2539,6 +2623,134 @@ extern "C" int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_pa
   const HashIn hash = {pos01, table, scalings, log2_T};
   return run_field_fwd(cfg, params, nullptr, &hash, 0, 0, nullptr, nullptr, selector, n, sigma, sigma_raw, emb, nullptr, nullptr,
                        nullptr, nullptr, nullptr, workspace, workspace_bytes, pack_ready, stream);
+}
+
+// ---- the forward as two launches with the rendering weights known in between (training step) --------------------------------
+// umhs_field_base_fwd: mlp_base only (sigma, sigma_raw, emb) from the FULL configuration's prepared workspace (the same pack
+// images umhs_field_heads_fwd uses, built once by umhs_field_fwd_prepare).
+extern "C" int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
+                                   int64_t stride_l, const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
+                                   void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
+  if (!params || !enc || !selector || !sigma || !workspace || n < 0) return UMHS_ERR_ARG;
+  if ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;
+  if (n == 0) return UMHS_OK;
+  PackDesc pd;
+  int TB;
+  rc = build_pack_desc(cfg, params, &pd, &TB);
+  if (rc) return rc;
+  if (workspace_bytes < fwd_ws_need(pd, false)) return UMHS_ERR_WORKSPACE;
+  float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  if (!pack_ready) {
+    launch_fwd_packs(pd, false, img, stream);
+    UMHS_CHECK_LAUNCH();
+  }
+  FwdBfPlan fp;
+  if (!fwd_bf_plan(pd, &fp, true)) return UMHS_ERR_UNSUPPORTED;
+  fp.args.bf_image = img + ((pd.total + 63) & ~63);
+  FieldIO io = {};
+  io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.sel = selector, io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = 0;
+  io.temperature = cfg->temperature, io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb;
+  const int64_t ntiles = (n + 127) / 128;
+  const unsigned grid = (unsigned)(ntiles < 256 * 8 ? ntiles : 256 * 8);
+  rc = set_lds(field_fwd_kernel<false, true, 2, 4, false, true>, fp.lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((field_fwd_kernel<false, true, 2, 4, false, true>), dim3(grid), dim3(256), fp.lds, umhs_s(stream), io, fp.pd,
+                     (const float*)img, fp.args);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// Adds the tile partials of umhs_field_heads_fwd ray by ray (see field_fwd_kernel, HEADS): one workgroup per ray, threads over
+// (stream, band), tiles in order.
+__global__ __launch_bounds__(128) void field_heads_finish_kernel(const float* __restrict__ part, const int64_t* __restrict__ ray_of,
+                                                                const int64_t* __restrict__ pinfo, int64_t n, int B, int BP, int NS,
+                                                                float* __restrict__ c0, float* __restrict__ c1,
+                                                                float* __restrict__ c2) {
+  const int64_t ray = blockIdx.x;
+  const int64_t s0 = pinfo[2 * ray], cnt = pinfo[2 * ray + 1];
+  const int64_t ts = s0 >> 4, te = cnt > 0 ? (s0 + cnt - 1) >> 4 : ts - 1;
+  if (cnt > 0 && ts == te) {  // inside one tile: its first or last ray (-> A / Z), or strictly inside (-> the heads kernel wrote it)
+    const int64_t l = 16 * ts + 15 < n ? 16 * ts + 15 : n - 1;
+    if (ray_of[16 * ts] != ray && ray_of[l] != ray) return;
+  }
+  for (int i = threadIdx.x; i < NS * B; i += 128) {
+    const int sidx = i / B, b = i - sidx * B;
+    float acc = 0.0f;
+    for (int64_t t = ts; t <= te; ++t) {
+      const int az = ray_of[16 * t] == ray ? 0 : 1;
+      acc += part[((t * 2 + az) * NS + sidx) * BP + b];
+    }
+    float* const c = sidx == 0 ? c0 : (sidx == 1 ? c1 : c2);
+    if (c) c[ray * B + b] = acc;
+  }
+}
+
+extern "C" size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n) {
+  if (check_cfg(cfg) || cfg->density_only || n <= 0) return 0;
+  const int TB = (cfg->n_bands + 15) / 16, NS = cfg->pred_specular ? 3 : 1;
+  return (size_t)((n + 15) / 16) * 2 * NS * 16 * TB * sizeof(float) + 256;
+}
+
+// umhs_field_heads_fwd: everything after mlp_base from its saved outputs emb [N,15], with the per-ray band sums
+// comp_*[r][b] = sum over the samples n of ray r of weights[n] * stream[n][b] formed inside the kernel; spectral [N,B] (per sample) is
+// written only when given.  ray_indices [N] non-decreasing, packed_info [R,2] = (first sample, count) as umhs_pack_info makes them.
+extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb,
+                                    const float* world_pos, const float* directions, int64_t n, const float* weights,
+                                    const int64_t* ray_indices, const int64_t* packed_info, int64_t n_rays, float* spectral,
+                                    float* abundances, float* feat_logits, float* comp_spectral, float* comp_spectral2,
+                                    float* comp_specular, void* scratch, size_t scratch_bytes, void* workspace, size_t workspace_bytes,
+                                    int pack_ready, umhs_stream_t stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
+  const bool spec = cfg->pred_specular != 0;
+  if (!params || !workspace || n < 0 || n_rays < 0 || !packed_info || !comp_spectral) return UMHS_ERR_ARG;
+  if (n > 0 && (!emb || !world_pos || !weights || !ray_indices || !scratch || (spec && !directions))) return UMHS_ERR_ARG;
+  if (n_rays == 0) return UMHS_OK;
+  PackDesc pd;
+  int TB;
+  rc = build_pack_desc(cfg, params, &pd, &TB);
+  if (rc) return rc;
+  if (workspace_bytes < fwd_ws_need(pd, false)) return UMHS_ERR_WORKSPACE;
+  if (n > 0 && (scratch_bytes < umhs_field_heads_fwd_scratch_bytes(cfg, n) || ((uintptr_t)scratch & 15))) return UMHS_ERR_WORKSPACE;
+  float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  if (!pack_ready) {
+    launch_fwd_packs(pd, false, img, stream);
+    UMHS_CHECK_LAUNCH();
+  }
+  const int NS = spec ? 3 : 1;
+  if (n > 0) {
+    FwdBfPlan fp;
+    if (!fwd_bf_plan(pd, &fp)) return UMHS_ERR_UNSUPPORTED;
+    fp.args.bf_image = img + ((pd.total + 63) & ~63);
+    FieldIO io = {};
+    io.wpos = world_pos, io.dirs = directions, io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB;
+    io.temperature = cfg->temperature, io.emb_in = emb, io.spectral = spectral, io.abund = abundances, io.feat_logits = feat_logits;
+    io.weights = weights, io.ray_of = ray_indices, io.part = reinterpret_cast<float*>(scratch);
+    io.comp[0] = comp_spectral, io.comp[1] = comp_spectral2, io.comp[2] = comp_specular, io.n_streams = NS;
+    const int64_t ntiles = (n + 255) / 256;
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    if (spec) {
+      rc = set_lds(field_fwd_kernel<true, false, 2, 8, false, true, true>, fp.lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((field_fwd_kernel<true, false, 2, 8, false, true, true>), dim3(grid), dim3(512), fp.lds, umhs_s(stream), io,
+                         fp.pd, (const float*)img, fp.args);
+    } else {
+      rc = set_lds(field_fwd_kernel<false, false, 2, 8, false, true, true>, fp.lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((field_fwd_kernel<false, false, 2, 8, false, true, true>), dim3(grid), dim3(512), fp.lds, umhs_s(stream), io,
+                         fp.pd, (const float*)img, fp.args);
+    }
+    UMHS_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(field_heads_finish_kernel, dim3((unsigned)n_rays), dim3(128), 0, umhs_s(stream),
+                     reinterpret_cast<const float*>(scratch), ray_indices, packed_info, n, cfg->n_bands, 16 * TB, NS, comp_spectral,
+                     spec ? comp_spectral2 : nullptr, spec ? comp_specular : nullptr);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
 }
 
 struct PartPlan {  // one half of the split heads backward: rebased descriptors + how to assemble its LDS image

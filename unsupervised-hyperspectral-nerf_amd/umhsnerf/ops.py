@@ -294,6 +294,55 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
     return o
 
 
+def field_base_fwd(spec: FieldSpec, flat, enc, level_major, sel, pack_ready=False):
+    """mlp_base only, from the full configuration's pack images (first launch of the two-launch training forward):
+    -> {"sigma" [N], "sigma_raw" [N], "emb" [N,15]}."""
+    n, dev, L = sel.shape[0], sel.device, spec.layout
+    cfg = spec.cfg(False)
+    pp = L.c_struct(flat, _hip.FieldParams)
+    sn, sl = enc_strides(n, level_major)
+    new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    o = dict(sigma=new(n), sigma_raw=new(n), emb=new(n, GEO_FEAT_DIM))
+    if not pack_ready:
+        _require_free(dev, WS_FIELD_FWD, "field_base_fwd (pack image rebuild)")
+    ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
+    _hip.check(_hip.lib().umhs_field_base_fwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(sel), n, ptr(o["sigma"]), ptr(o["sigma_raw"]),
+                                              ptr(o["emb"]), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_base_fwd")
+    return o
+
+
+_heads_scratch: Dict[int, torch.Tensor] = {}
+
+
+def field_heads_fwd(spec: FieldSpec, flat, emb, wpos, dirs, weights, ray_indices, packed_info, want_spectral=True, want_logits=True,
+                    pack_ready=True, release=True):
+    """Second launch of the two-launch training forward: heads + band tiles from ``emb``, per-ray band sums formed in the kernel.
+    -> {"spectral" [N,B] | None, "abundances" [N,C], "feat_logits" [N,16] | None, "comp": [spectral, spectral2, specular] ([R,B])}.
+    ``pack_ready``: the images field_fwd_prepare / field_base_fwd left in the forward workspace are reused."""
+    n, dev, L = emb.shape[0], emb.device, spec.layout
+    R = packed_info.shape[0]
+    cfg = spec.cfg(False)
+    pp = L.c_struct(flat, _hip.FieldParams)
+    new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    B = L.wavelengths
+    o = dict(spectral=new(n, B) if want_spectral else None, abundances=new(n, L.num_classes),
+             feat_logits=new(n, 16) if want_logits else None)
+    comp = [new(R, B)] + ([new(R, B), new(R, B)] if L.pred_specular else [])
+    need = _hip.lib().umhs_field_heads_fwd_scratch_bytes(C.byref(cfg), max(n, 1))
+    sc = _heads_scratch.get(dev.index or 0)
+    if sc is None or sc.numel() < need:
+        sc = _heads_scratch[dev.index or 0] = torch.empty(need, device=dev, dtype=torch.uint8)
+    ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
+    _hip.check(_hip.lib().umhs_field_heads_fwd(C.byref(cfg), C.byref(pp), ptr(emb), ptr(wpos), ptr(dirs), n, ptr(weights), ptr(ray_indices),
+                                               ptr(packed_info), R, ptr(o["spectral"]), ptr(o["abundances"]), ptr(o["feat_logits"]),
+                                               ptr(comp[0]), ptr(comp[1]) if len(comp) > 1 else None, ptr(comp[2]) if len(comp) > 1 else None,
+                                               ptr(sc), sc.numel(), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_heads_fwd")
+    if pack_ready and release:
+        _release(dev, WS_FIELD_FWD)
+    o["comp"] = comp
+    return o
+
+
 def field_density(spec: FieldSpec, flat, pos01, sel, want_emb: bool = True):
     """density_fn in one launch (hash gather inside the MLP kernel): -> {"sigma" [N], "sigma_raw" [N], "emb" [N,15] | None}."""
     n = sel.shape[0]
@@ -753,6 +802,17 @@ class Spec2RgbFn(torch.autograd.Function):
     def backward(ctx, d_rgb):
         s, m = ctx.saved_tensors
         return spec2rgb_bwd(s, m, _hip.f32c(d_rgb)), None
+
+
+def accumulate_fwd(weights, values, packed_info):
+    """out[r] = sum over the samples n of ray r of weights[n] * values[n] (no autograd)."""
+    R = packed_info.shape[0]
+    out = torch.empty((R, values.shape[1]), device=values.device, dtype=torch.float32)
+    st = _hip.ValueStreams()
+    st.n_streams, st.k[0], st.values[0], st.out[0] = 1, values.shape[1], values.data_ptr(), out.data_ptr()
+    _hip.check(_hip.lib().umhs_accumulate_fwd(ptr(weights), ptr(packed_info), R, weights.shape[0], C.byref(st), _hip.stream()),
+               "umhs_accumulate_fwd")
+    return out
 
 
 class AccumulateFn(torch.autograd.Function):

@@ -423,8 +423,26 @@ class UMHSModel(ModelBase):
                     prepared = ops.hashgrid_bwd_prepare(pos01, spec.scalings, L.log2_hashmap_size)
                 ev_done.record(side)
             main.wait_event(ev_ready)
-        fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
-        values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
+        # Measured on one MI355X (A/B in one session): 128 bands + specular (C3) 2.107 -> 1.938 ms per step; at 31 bands (C2) the two extra
+        # launches cost more than the streams they remove (0.817 -> 0.850), and without the specular head there is one stream and
+        # nothing to remove (C5 1.775 -> 1.826).  UMHS_SPLIT_FWD=0 / 1 forces either path.
+        knob = os.environ.get("UMHS_SPLIT_FWD", "")
+        split_fwd = n > 0 and (knob == "1" or (knob != "0" and c.pred_specular and L.wavelengths > 32))
+        if split_fwd:
+            # Two launches with the rendering weights known in between: mlp_base -> weights (transmittance scan) -> heads, whose
+            # kernel forms the per-ray band sums itself.  spectral2 / specular (no loss, umhs_model.py:373-374) never exist per sample
+            # and the three-stream compositing pass over [N,B] disappears; per-sample spectral stays for the compositing backward.
+            fo = ops.field_base_fwd(spec, flat, enc, True, sel, pack_ready=side is not None)
+            weights, acc, depth, _ = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, [])
+            ri = ray_indices if ray_indices.dtype == torch.int64 else ray_indices.long()
+            ho = ops.field_heads_fwd(spec, flat, fo["emb"], wpos, d, weights, ri.contiguous(), packed_info, pack_ready=True,
+                                     release=side is not None)
+            fo.update(spectral=ho["spectral"], abundances=ho["abundances"], feat_logits=ho["feat_logits"])
+            comp = ho["comp"] + [ops.accumulate_fwd(weights, ho["abundances"], packed_info)]
+            values = [fo["spectral"]]
+        else:
+            fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
+            values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
         if side is None:
             mm = ops.tmid_minmax(t0, t1)
         M = _hip.f32c(self.converter.transform_matrix)
@@ -432,7 +450,7 @@ class UMHSModel(ModelBase):
         both = c.method == "rgb+spectral"
         bg = (background if background is not None else torch.rand_like(image)) if (both and self.background_color == "random") else None
         w = (5.0, float(c.rgb_loss_weight)) if both else (1.0, 0.0)
-        if os.environ.get("UMHS_FUSED_RAY", "0") == "1" and L.wavelengths <= 256:
+        if os.environ.get("UMHS_FUSED_RAY", "0") == "1" and L.wavelengths <= 256 and not split_fwd:
             # Everything that is local to a ray -- compositing forward, epilogue + losses + their backward, compositing backward -- in
             # one launch (umhs_ray_train_fused; equal to the three kernels below, tests/test_hip_trajectory.py).  Measured at C2 on one
             # MI355X, A/B/A/B in one session: 0.966 / 0.967 ms per step fused vs 0.934 / 0.936 with the three kernels.  Each of the three
@@ -442,7 +460,8 @@ class UMHSModel(ModelBase):
                 fo["sigma"], t0, t1, packed_info, values, M, f.endmembers.detach(), mm, _hip.f32c(self.class_colors), hs,
                 image if both else None, bg, 0.2, w[0], w[1], both, bool(c.use_gradient_scaling))
         else:
-            weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
+            if not split_fwd:
+                weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
             # ray epilogue + both losses + their backward down to d_spectral / d_accumulation: one launch
             rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(
                 comp[0], M, f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), hs, image if both else None, bg, 0.2,
