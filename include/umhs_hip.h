@@ -192,6 +192,21 @@ int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
                    const float* sigma_raw, const float* emb, const float* feat_logits, int64_t n, const float* d_sigma,
                    const float* d_spectral, const float* d_emb_ext, float* d_enc, const umhs_field_grads* grads,
                    void* workspace, size_t workspace_bytes, int packs_ready, umhs_stream_t stream);
+/* umhs_field_bwd with the value half of the compositing backward (nerfacc accumulate_along_rays backward through               */
+/* SpectralRenderer, umhs_renderer.py:28-30) folded in -- the training step after umhs_field_heads_fwd.  Takes d_comp_spectral       */
+/* [R,B] (gradient of the per-ray band sums) + d_accumulation [R] and the renderer's sigma / intervals / packed_info /              */
+/* ray_indices / weights instead of d_spectral [N,B]; returns d_sigma [N] as well.  Per sample d_spectral = scale_n weights[n]      */
+/* d_comp[ray(n)] is formed on the fly and spectral is recomputed for dw_n: neither exists as an [N,B] array.  feat_logits          */
+/* required.  umhs_field_bwd_composited_supported: 1 when this configuration can take the path (else UMHS_ERR_UNSUPPORTED).         */
+int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg);
+int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
+                              int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
+                              const float* sigma_raw, const float* emb, const float* feat_logits, int64_t n, const float* sigma,
+                              const float* t_starts, const float* t_ends, const int64_t* packed_info, int64_t n_rays,
+                              const int64_t* ray_indices, const float* weights, const float* d_comp_spectral,
+                              const float* d_accumulation, int grad_scaling, float* d_sigma, float* d_enc,
+                              const umhs_field_grads* grads, void* workspace, size_t workspace_bytes, int packs_ready,
+                              umhs_stream_t stream);
 /* builds the transposed packs + forward image ahead of time (parameters only): then pass packs_ready = 1, same workspace */
 int umhs_field_bwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
                            size_t workspace_bytes, umhs_stream_t stream);
@@ -232,6 +247,11 @@ typedef struct umhs_value_grads {
 int umhs_composite_bwd(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
                        int64_t n_rays, int64_t n, const float* weights, const umhs_value_grads* grads,
                        const float* d_accumulation, int grad_scaling, float* d_sigma, umhs_stream_t stream);
+/* The density half alone, for a caller that has already formed dots[n] = sum over streams and bands of d_out[ray(n)][k] *    */
+/* value[n][k] itself (umhs_field_bwd_composited does): d_sigma only, no [N,k] array read or written.                           */
+int umhs_composite_bwd_dots(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                            int64_t n_rays, int64_t n, const float* weights, const float* dots, const float* d_accumulation,
+                            int grad_scaling, float* d_sigma, umhs_stream_t stream);
 
 /* R12 stand-alone: accumulate with caller-provided weights [N] -- SpectralRenderer.forward(spectral, weights,  */
 /* ray_indices, num_rays) called on its own (umhs_renderer.py:15-30; dino / abundance renders,                  */

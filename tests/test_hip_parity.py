@@ -689,3 +689,42 @@ def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
     assert ho["spectral"] is None and ho["feat_logits"] is None
     for a, b in zip(ho["comp"], runs[0]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,B,spec,gs", [(6, 31, True, True), (4, 40, False, False), (9, 128, True, True), (4, 141, False, True)])
+def test_field_backward_with_the_compositing_backward_folded_in(C, B, spec, gs):
+    """umhs_field_bwd_composited (d_comp [R,B] in, d_sigma out, no [N,B] array) against umhs_composite_bwd + umhs_field_bwd on the
+    same inputs: d_sigma, d_enc and every parameter gradient.  Ragged rays incl. empty and sub-tile ones; with and without
+    scale_gradients_by_distance_squared."""
+    ops = _ops()
+    _, _, layout, flat, fs = make_case(C, B, spec, 8, 8, log2_T=12)
+    assert ops.field_bwd_composited_supported(fs)
+    g = torch.Generator().manual_seed(B + 1)
+    counts = torch.tensor([0, 3, 2, 0, 1, 40, 17, 16, 5, 4, 3, 200, 0, 7, 33, 1, 1, 1, 90, 0], dtype=torch.int64)
+    R, n = counts.numel(), int(counts.sum())
+    starts = torch.cumsum(counts, 0) - counts
+    packed_info = torch.stack([starts, counts], 1).contiguous().to(DEV)
+    ray_idx = torch.repeat_interleave(torch.arange(R), counts).to(DEV)
+    enc = ((torch.rand(16, n, 2, generator=g) - 0.5)).to(DEV)
+    wpos = (torch.rand(n, 3, generator=g) * 2 - 1).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    sel = (torch.rand(n, generator=g) > 0.1).float().to(DEV)
+    t0 = (torch.rand(n, generator=g) * 1.5).to(DEV)
+    t1 = t0 + 0.05
+    fo = ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True, want_logits=True)
+    w, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, [fo["spectral"]])
+    d_comp = torch.randn(R, B, generator=g).to(DEV)
+    d_acc = torch.randn(R, generator=g).to(DEV)
+    d_sigma_ref, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, w, [fo["spectral"]], [d_comp], [True], d_acc, gs)
+    g_ref = torch.zeros_like(flat)
+    d_enc_ref = ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, fo["sigma_raw"], fo["emb"], d_sigma_ref, d_values[0], None, g_ref,
+                              feat_logits=fo["feat_logits"])
+    cp = dict(sigma=fo["sigma"], t0=t0, t1=t1, packed_info=packed_info, ray_indices=ray_idx, weights=w, d_comp=d_comp, d_acc=d_acc,
+              grad_scaling=gs)
+    g_got = torch.zeros_like(flat)
+    d_enc = ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, fo["sigma_raw"], fo["emb"], None, None, None, g_got,
+                          feat_logits=fo["feat_logits"], comp=cp)
+    assert_close("d_sigma", cp["d_sigma"], d_sigma_ref, 2e-5)
+    assert_close("d_enc", d_enc, d_enc_ref, 2e-5)
+    tail = layout.tail_offset()
+    assert_close("parameter gradients", g_got[tail:], g_ref[tail:], 2e-5)

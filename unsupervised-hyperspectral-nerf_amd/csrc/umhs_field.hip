@@ -239,6 +239,12 @@ struct FieldIO {
   float* part;                         // per-16-sample-tile partial sums, see HeadsComp
   float* comp[3];                      // [R,B] band sums of spectral / spectral2 / specular (rays inside one tile are written here directly)
   int n_streams;                       // 1 without the specular head, else 3
+  // transpose-free backward, part 0 with the compositing backward's value half folded in (FUSED): d_spectral[n][b] =
+  // scale_n * weights[n] * d_comp[ray(n)][b] is formed on the fly, and dots[n] = sum_b d_comp[ray(n)][b] * spectral[n][b] (spectral
+  // recomputed) goes out for umhs_composite_bwd_dots
+  const float* d_comp;                 // [R,B] gradient w.r.t. the per-ray band sums of spectral
+  const float *t0, *t1;                // [N] sample intervals (gradient scaling by distance), or null
+  float* dots;                         // [N]
 };
 
 // NeRF positional encoding slots of quarter q (3 per lane) and SH slots (4 per lane)
@@ -1810,7 +1816,7 @@ extern "C" int umhs_debug_tf_stamps_clear() {
 
 // BF: the fp32 chain (forward recompute + dX) of every layer with >= 7 k-steps runs as three-piece bf16 products (gemm_bf); the
 // 4-step layers (the band tiles' products, the out-layer transposes) keep the fp32 MFMA.
-template <int PART, bool SPEC, int TBMAX, bool BF>
+template <int PART, bool SPEC, int TBMAX, bool BF, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDesc pd, TPackDesc td, const float* __restrict__ image,
                                                               const float* __restrict__ wT_image, ImgSegs seg_f, ImgSegs seg_t,
                                                               int wt_off, const float* __restrict__ bf_image, ImgSegs seg_b, int bf_off,
@@ -1856,6 +1862,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     float2 e[PART == 1 ? 4 : 1];
     v4f x0, x1;  // part 0: saved feature logits, -;  part 1: d_fl, d_bo (from part 0)
     float emb[4], dsig, sel, demb[4];
+    float ws;     // FUSED: scale_n * weights[n]
+    int64_t ray;  // FUSED: the sample's ray
   };
   auto fetch = [&](int64_t tile, TileIn& in) {
     int64_t n = tile * 64 + wave * 16 + j;
@@ -1874,6 +1882,15 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         in.emb[r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) meets a zero weight column
       }
       in.x0 = *reinterpret_cast<const v4f*>(io.feat_logits_in + n * 16 + 4 * q);
+      if (FUSED) {
+        float sc = 1.0f;
+        if (io.t0) {  // scale_gradients_by_distance_squared: clamp(t_mid^2, 0, 1)
+          const float m = (io.t0[n] + io.t1[n]) / 2.0f;
+          sc = fminf(fmaxf(m * m, 0.0f), 1.0f);
+        }
+        in.ws = ok ? io.weights[n] * sc : 0.0f;
+        in.ray = io.ray_of[n];
+      }
     } else {
 #pragma unroll
       for (int lv = 0; lv < 4; ++lv) in.e[lv] = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
@@ -1949,14 +1966,18 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     if constexpr (PART == 0) {
       // This tile's upstream gradients, all band tiles: requested here, consumed after the head MLP's forward recompute (with one
       // wave per SIMD a load issued next to its use costs its whole latency: one band tile ahead was 585 us at 128 bands)
-      float dall[TBMAX][4];
+      float dall[TBMAX][4];  // FUSED: the ray's d_comp row (unscaled; [R,B] stays in L2), else this sample's d_spectral row
 #pragma unroll
       for (int t = 0; t < TBMAX; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int b = 16 * t + 4 * q + r;
-          dall[t][r] = (t < TB && ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
+          if (FUSED)
+            dall[t][r] = (t < TB && ok && b < B) ? io.d_comp[cur.ray * B + b] : 0.0f;
+          else
+            dall[t][r] = (t < TB && ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
         }
+      float dotacc = 0.0f;
       // =================== forward recompute: head MLP, directional hidden layer (feature logits come from the forward) ===
 #pragma unroll
       for (int r = 0; r < 4; ++r) in27[0][3 + r] = cur.emb[r];
@@ -2009,7 +2030,13 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         if (t < TB) {
           float dsp[NT][4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dsp[0][r] = dall[t][r];
+          for (int r = 0; r < 4; ++r) dsp[0][r] = FUSED ? cur.ws * dall[t][r] : dall[t][r];
+          if (FUSED) {  // this band tile of the mixing product, for the dot with the ray's upstream gradient
+            v4f mx4[NT][1];
+            gemm_pack<1, 4, NT, 1>(mx4, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dotacc += dall[t][r] * mx4[0][0][r];
+          }
           gemm_pack<1, 4, NT, 0>((t & 1) ? dm4b : dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
           STile dspS[1];
           dspS[0] = to_swapped<false>(dsp[0], ident);
@@ -2021,6 +2048,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float sp = sigmoidf_(sc[0][0][r]);
+              if (FUSED) dotacc += dall[t][r] * (hs.s1[0] * sp);
               ds1 += dsp[0][r] * sp;
               dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
             }
@@ -2032,6 +2060,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         }
       }
       TF_STAMP(3);
+      if (FUSED) {
+        dotacc = xq_sum(dotacc);
+        if (ok && q == 0) io.dots[n] = dotacc;
+      }
       ds1 = xq_sum(ds1);
       dm4[0][0] += dm4b[0][0], dhd4[0][0] += dhd4b[0][0];
       // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
@@ -2972,11 +3004,12 @@ static int bf_image_dwords(const BwdPlan& pl) {
   return bp.total;
 }
 
-static bool tf_part(const BwdPlan& pl, int part, bool bf, TfPart* pp) {
-  const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
+static bool tf_part(const BwdPlan& pl, int part, bool bf, TfPart* pp, bool fused = false) {
+  // fused (part 0): also the forward mixing pack -- the kernel recomputes spectral for the compositing backward's dot products
+  const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1, L_MX}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
   const int fl1[] = {L_B0, L_B1, L_F0, L_F1}, tl1[] = {T_B1, T_B0, T_F2, T_F1, T_F0};
   const int* fl = part == 0 ? fl0 : fl1;
-  const int nfl = part == 0 ? 5 : 4;
+  const int nfl = part == 0 ? (fused ? 6 : 5) : 4;
   const int* tl = part == 0 ? tl0 : tl1;
   const int ntl = 5;
   pp->pd = pl.pd_all, pp->td = pl.td;
@@ -3009,6 +3042,7 @@ static bool tf_part(const BwdPlan& pl, int part, bool bf, TfPart* pp) {
   }
   for (int i = 0; i < nfl; ++i) {
     const LayerDesc& L = pl.pd_all.L[fl[i]];
+    if (fl[i] == L_MX) continue;  // no bias tile
     add(pp->seg_f, L.off_b, cur, 16 * L.OT);
     pp->pd.L[fl[i]].off_b = cur, cur += 16 * L.OT;
   }
@@ -3059,36 +3093,54 @@ static void fill_tf_map(TfMap* mp, bool spec, int TB) {
   if (spec) bias(SL::D_D0, L_D0, 1), bias(SL::D_D1, L_D1, TB);
 }
 
+// The compositing backward folded between the two parts (umhs_field_bwd_composited): part 0 forms d_spectral on the fly and emits the
+// dot products, umhs_composite_bwd_dots turns them into d_sigma, part 1 consumes it.
+struct BwdComp {
+  const float *sigma, *t0, *t1, *weights, *d_comp, *d_acc;
+  const int64_t *packed_info, *ray_of;
+  int64_t n_rays;
+  int grad_scaling;
+  float *d_sigma, *dots;
+};
+
 template <int TBMAX>
 static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, FieldIO io, bool spec, const float* img, const float* wT,
-                     const float* bfimg, float* slabs, const GradPtrs& gp, int64_t n, umhs_stream_t stream) {
+                     const float* bfimg, float* slabs, const GradPtrs& gp, int64_t n, umhs_stream_t stream, const BwdComp* bc) {
   typedef TfSlots<TBMAX> SL;
   const unsigned grid = tf_grid(n);
   int rc;
-#define LAUNCH_TF(P_, S_, BF_)                                                                                                    \
+#define LAUNCH_TF(P_, S_, BF_, FU_)                                                                                                \
   do {                                                                                                                            \
-    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX, BF_>, part[P_].lds);                                                          \
+    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX, BF_, FU_>, part[P_].lds);                                                     \
     if (rc) return rc;                                                                                                            \
-    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX, BF_>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io,        \
+    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX, BF_, FU_>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io,   \
                        part[P_].pd, part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, bfimg, part[P_].seg_b,  \
                        part[P_].bf_off, part[P_].bo, slabs);                                                                      \
   } while (0)
-#define LAUNCH_TF_P(P_)                \
-  do {                                 \
-    if (spec) {                        \
-      if (bf_mask >> P_ & 1)           \
-        LAUNCH_TF(P_, true, true);     \
-      else                             \
-        LAUNCH_TF(P_, true, false);    \
-    } else {                           \
-      if (bf_mask >> P_ & 1)           \
-        LAUNCH_TF(P_, false, true);    \
-      else                             \
-        LAUNCH_TF(P_, false, false);   \
-    }                                  \
+#define LAUNCH_TF_P(P_, FU_)                 \
+  do {                                       \
+    if (spec) {                              \
+      if (bf_mask >> P_ & 1)                 \
+        LAUNCH_TF(P_, true, true, FU_);      \
+      else                                   \
+        LAUNCH_TF(P_, true, false, FU_);     \
+    } else {                                 \
+      if (bf_mask >> P_ & 1)                 \
+        LAUNCH_TF(P_, false, true, FU_);     \
+      else                                   \
+        LAUNCH_TF(P_, false, false, FU_);    \
+    }                                        \
   } while (0)
-  LAUNCH_TF_P(0);
-  LAUNCH_TF_P(1);
+  if (bc) {
+    LAUNCH_TF_P(0, true);
+    UMHS_CHECK_LAUNCH();
+    rc = umhs_composite_bwd_dots(bc->sigma, bc->t0, bc->t1, bc->packed_info, bc->n_rays, n, bc->weights, bc->dots, bc->d_acc,
+                                 bc->grad_scaling, bc->d_sigma, stream);
+    if (rc) return rc;
+  } else {
+    LAUNCH_TF_P(0, false);
+  }
+  LAUNCH_TF_P(1, false);
 #undef LAUNCH_TF_P
 #undef LAUNCH_TF
   UMHS_CHECK_LAUNCH();
@@ -3143,16 +3195,19 @@ extern "C" size_t umhs_field_bwd_workspace_bytes(const umhs_field_cfg* cfg, int6
   return bwd_workspace_need(pl, n);
 }
 
-extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
-                              int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
-                              const float* selector, const float* sigma_raw, const float* emb, const float* feat_logits,
-                              int64_t n, const float* d_sigma, const float* d_spectral, const float* d_emb_ext, float* d_enc,
-                              const umhs_field_grads* grads, void* workspace, size_t workspace_bytes, int packs_ready,
-                              umhs_stream_t stream) {
+static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
+                         int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
+                         const float* selector, const float* sigma_raw, const float* emb, const float* feat_logits,
+                         int64_t n, const float* d_sigma, const float* d_spectral, const float* d_emb_ext, float* d_enc,
+                         const umhs_field_grads* grads, void* workspace, size_t workspace_bytes, int packs_ready,
+                         umhs_stream_t stream, BwdComp* bc) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
-  if (!params || !enc || !selector || !world_pos || !sigma_raw || !emb || !d_sigma || !d_spectral || !grads || n < 0)
+  if (!params || !enc || !selector || !world_pos || !sigma_raw || !emb || !d_sigma || (!bc && !d_spectral) || !grads || n < 0)
+    return UMHS_ERR_ARG;
+  if (bc && (!feat_logits || !bc->sigma || !bc->t0 || !bc->t1 || !bc->weights || !bc->d_comp || !bc->packed_info || !bc->ray_of ||
+             bc->n_rays < 0))
     return UMHS_ERR_ARG;
   const bool spec = cfg->pred_specular != 0;
   if (spec && !directions) return UMHS_ERR_ARG;
@@ -3209,20 +3264,27 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
     TfPart part[2];
     bool ok = true;
     for (int p = 0; p < 2; ++p) {
-      if ((bf_mask >> p & 1) && !tf_part(pl, p, true, &part[p])) bf_mask &= ~(1 << p);  // LDS: fall back to the fp32 chain
-      if (!(bf_mask >> p & 1)) ok = ok && tf_part(pl, p, false, &part[p]);
+      const bool fused = bc && p == 0;
+      if ((bf_mask >> p & 1) && !tf_part(pl, p, true, &part[p], fused)) bf_mask &= ~(1 << p);  // LDS: fall back to the fp32 chain
+      if (!(bf_mask >> p & 1)) ok = ok && tf_part(pl, p, false, &part[p], fused);
     }
     if (ok) {
       io.feat_logits_in = feat_logits, io.d_fl = d_fl;
+      if (bc) {
+        bc->dots = d_bo2;  // [N] of the (unused here) second hand-off buffer
+        io.weights = bc->weights, io.ray_of = bc->ray_of, io.d_comp = bc->d_comp, io.dots = bc->dots;
+        io.t0 = bc->grad_scaling ? bc->t0 : nullptr, io.t1 = bc->grad_scaling ? bc->t1 : nullptr;
+      }
       switch (tbmax) {
-        case 2: return launch_tf<2>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
-        case 4: return launch_tf<4>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
-        case 8: return launch_tf<8>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
-        case 12: return launch_tf<12>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
-        default: return launch_tf<16>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream);
+        case 2: return launch_tf<2>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream, bc);
+        case 4: return launch_tf<4>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream, bc);
+        case 8: return launch_tf<8>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream, bc);
+        case 12: return launch_tf<12>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream, bc);
+        default: return launch_tf<16>(pl, part, bf_mask, io, spec, img, wT, bfimg, slabs, gp, n, stream, bc);
       }
     }
   }
+  if (bc) return UMHS_ERR_UNSUPPORTED;  // only the transpose-free kernels carry the folded compositing backward
 #define LAUNCH_HEADS(S_, NA_, W_)                                                                                  \
   do {                                                                                                             \
     rc = set_lds(field_bwd_heads_kernel<S_, NA_, W_>, pl.lds_h);                                                   \
@@ -3287,4 +3349,50 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
                      (int)grid, pl.sl, pd_all, gp, pl.n_bias_items);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
+}
+
+extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
+                              int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
+                              const float* selector, const float* sigma_raw, const float* emb, const float* feat_logits,
+                              int64_t n, const float* d_sigma, const float* d_spectral, const float* d_emb_ext, float* d_enc,
+                              const umhs_field_grads* grads, void* workspace, size_t workspace_bytes, int packs_ready,
+                              umhs_stream_t stream) {
+  return run_field_bwd(cfg, params, enc, stride_n, stride_l, world_pos, directions, selector, sigma_raw, emb, feat_logits, n, d_sigma,
+                       d_spectral, d_emb_ext, d_enc, grads, workspace, workspace_bytes, packs_ready, stream, nullptr);
+}
+
+// 1 when umhs_field_bwd_composited can serve this configuration (the transpose-free kernels with every pack LDS-resident).
+extern "C" int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg) {
+  if (check_cfg(cfg) || cfg->density_only) return 0;
+  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : 3;
+  if (tf_mode == 0) return 0;
+  umhs_field_params dummy = {};
+  const float zero = 0.0f;
+  const float** pp = reinterpret_cast<const float**>(&dummy);
+  for (size_t i = 0; i < sizeof(dummy) / sizeof(float*); ++i) pp[i] = &zero;  // layout only, never dereferenced
+  BwdPlan pl;
+  if (build_bwd_plan(cfg, &dummy, &pl) || tf_tbmax(pl.TB) == 0) return 0;
+  TfPart part;
+  return tf_part(pl, 0, false, &part, true) && tf_part(pl, 1, false, &part, false) ? 1 : 0;
+}
+
+// umhs_field_bwd with the value half of the compositing backward folded in (training step after umhs_field_heads_fwd): instead of
+// d_spectral [N,B] it takes the gradient of the per-ray band sums d_comp_spectral [R,B] (+ d_accumulation [R]) and what the
+// renderer knows -- sigma, intervals, packed_info, ray_indices, weights -- and returns d_sigma [N] besides everything umhs_field_bwd
+// returns.  Per sample: d_spectral[n][b] = scale_n weights[n] d_comp[ray(n)][b] on the fly; spectral[n][b] recomputed for
+// dw_n = d_acc[r] + sum_b d_comp[r][b] spectral[n][b]; umhs_composite_bwd_dots; then the density half of the field backward.
+// Neither spectral nor d_spectral exists as an [N,B] array.  feat_logits is required.
+extern "C" int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
+                                         int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
+                                         const float* selector, const float* sigma_raw, const float* emb, const float* feat_logits,
+                                         int64_t n, const float* sigma, const float* t_starts, const float* t_ends,
+                                         const int64_t* packed_info, int64_t n_rays, const int64_t* ray_indices, const float* weights,
+                                         const float* d_comp_spectral, const float* d_accumulation, int grad_scaling, float* d_sigma,
+                                         float* d_enc, const umhs_field_grads* grads, void* workspace, size_t workspace_bytes,
+                                         int packs_ready, umhs_stream_t stream) {
+  BwdComp bc = {};
+  bc.sigma = sigma, bc.t0 = t_starts, bc.t1 = t_ends, bc.weights = weights, bc.d_comp = d_comp_spectral, bc.d_acc = d_accumulation;
+  bc.packed_info = packed_info, bc.ray_of = ray_indices, bc.n_rays = n_rays, bc.grad_scaling = grad_scaling, bc.d_sigma = d_sigma;
+  return run_field_bwd(cfg, params, enc, stride_n, stride_l, world_pos, directions, selector, sigma_raw, emb, feat_logits, n, d_sigma,
+                       nullptr, nullptr, d_enc, grads, workspace, workspace_bytes, packs_ready, stream, &bc);
 }

@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ pinfo, int64_t n_rays,
                                                             const float* __restrict__ weights, CompGrads gr,
                                                             const float* __restrict__ d_acc, int grad_scaling,
-                                                            float* __restrict__ d_sigma) {
+                                                            float* __restrict__ d_sigma, const float* __restrict__ dots) {
   const int lane = threadIdx.x & 63;
   __shared__ float lds_tile[4][64 * 33 + 64 + 32];  // per wave: [64][33] value tile, 64 weights, 32 upstream gradients
   float* const tile = lds_tile[threadIdx.x >> 6];
@@ -954,6 +954,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
       w = weights[nidx];
       tnext = d_sigma[nidx];
       dw = dacc;
+      if (dots) dw += dots[nidx];  // sum_k d_out[r][k] v[n][k], formed by the caller (umhs_composite_bwd_dots)
     }
     const int nvalid = min(64, cnt - c * 64);
     // The chunk's [nvalid x K] rows are one contiguous block.  K <= 32: read it with full 256-byte wave loads into an LDS tile
@@ -1042,7 +1043,22 @@ extern "C" int umhs_composite_bwd(const float* sigma, const float* t_starts, con
   }
   if (n_rays == 0 || n == 0) return UMHS_OK;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), sigma,
-                     t_starts, t_ends, packed_info, n_rays, weights, gr, d_accumulation, grad_scaling, d_sigma);
+                     t_starts, t_ends, packed_info, n_rays, weights, gr, d_accumulation, grad_scaling, d_sigma, (const float*)nullptr);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+// The density half of umhs_composite_bwd when the caller has already formed dots[n] = sum over streams and bands of
+// d_out[ray(n)][k] * value[n][k] (the field backward does, from values it recomputes): d_sigma only, no [N,k] array read or written.
+extern "C" int umhs_composite_bwd_dots(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                                       int64_t n_rays, int64_t n, const float* weights, const float* dots,
+                                       const float* d_accumulation, int grad_scaling, float* d_sigma, umhs_stream_t stream) {
+  if (n_rays < 0 || n < 0 || !packed_info || !d_sigma) return UMHS_ERR_ARG;
+  if (n > 0 && (!sigma || !t_starts || !t_ends || !weights || !dots)) return UMHS_ERR_ARG;
+  if (n_rays == 0 || n == 0) return UMHS_OK;
+  CompGrads gr = {};
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), sigma, t_starts, t_ends,
+                     packed_info, n_rays, weights, gr, d_accumulation, grad_scaling, d_sigma, dots);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }

@@ -77,6 +77,11 @@ SIGNATURES = {
     "umhs_field_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FieldCfg), _i64]),
     "umhs_field_bwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                  _vp, _vp, _vp, _vp, C.POINTER(FieldGrads), _vp, C.c_size_t, C.c_int, _vp]),
+    "umhs_field_bwd_composited_supported": (C.c_int, [C.POINTER(FieldCfg)]),
+    "umhs_field_bwd_composited": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                            _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.POINTER(FieldGrads), _vp,
+                                            C.c_size_t, C.c_int, _vp]),
+    "umhs_composite_bwd_dots": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "umhs_pack_info": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "umhs_composite_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.POINTER(ValueStreams), _vp, _vp, _vp, _vp]),
     "umhs_composite_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(ValueGrads), _vp, C.c_int, _vp, _vp]),

@@ -395,10 +395,17 @@ def _require_free(device, slot: int, who: str) -> None:
         raise RuntimeError(f"{who} would overwrite workspace slot {slot} while {held} holds data in it for a consumer that has not run")
 
 
+def field_bwd_composited_supported(spec: FieldSpec) -> bool:
+    cfg = spec.cfg(False)
+    return bool(_hip.lib().umhs_field_bwd_composited_supported(C.byref(cfg)))
+
+
 def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
-              packs_ready=False, feat_logits=None, d_tail=None):
+              packs_ready=False, feat_logits=None, d_tail=None, comp=None):
     """Writes d_enc (returned) and the MLP / endmember gradients straight into ``d_flat`` (flat layout) -- or, when ``d_tail`` is
-    given (a tensor of ``total - tail_offset()`` floats), into that instead (gradient accumulation adds it to the flat gradient)."""
+    given (a tensor of ``total - tail_offset()`` floats), into that instead (gradient accumulation adds it to the flat gradient).
+    ``comp``: dict(sigma, t0, t1, packed_info, ray_indices, weights, d_comp, d_acc, grad_scaling) -- the value half of the compositing
+    backward runs inside (umhs_field_bwd_composited); d_sigma / d_spectral are then ignored and comp["d_sigma"] receives d_sigma."""
     n = sel.shape[0]
     L = spec.layout
     cfg = spec.cfg(False)
@@ -408,6 +415,17 @@ def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_ra
     d_enc = torch.empty_like(enc)
     nbytes = _hip.lib().umhs_field_bwd_workspace_bytes(C.byref(cfg), n)
     ws = _workspace(nbytes, sel.device)
+    if comp is not None:
+        comp["d_sigma"] = torch.empty(n, device=sel.device, dtype=torch.float32)
+        pi = comp["packed_info"]
+        _hip.check(_hip.lib().umhs_field_bwd_composited(
+            C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), ptr(sigma_raw), ptr(emb), ptr(feat_logits), n,
+            ptr(comp["sigma"]), ptr(comp["t0"]), ptr(comp["t1"]), ptr(pi), pi.shape[0], ptr(comp["ray_indices"]), ptr(comp["weights"]),
+            ptr(comp["d_comp"]), ptr(comp["d_acc"]), int(bool(comp["grad_scaling"])), ptr(comp["d_sigma"]), ptr(d_enc), C.byref(gp), ptr(ws),
+            ws.numel(), int(packs_ready), _hip.stream()), "umhs_field_bwd_composited")
+        if packs_ready:
+            _release(sel.device, WS_FIELD_BWD)
+        return d_enc
     _hip.check(_hip.lib().umhs_field_bwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel),
                                          ptr(sigma_raw), ptr(emb), ptr(feat_logits), n,
                                          ptr(d_sigma), ptr(d_spectral), ptr(d_emb), ptr(d_enc), C.byref(gp), ptr(ws),
@@ -541,7 +559,7 @@ def ssim(a, b, data_range=None):
 
 
 def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_raw, emb, d_sigma, d_spectral, d_emb,
-                        prepared: bool = False, feat_logits=None, hash_ready=None):
+                        prepared: bool = False, feat_logits=None, hash_ready=None, comp=None):
     """``prepared``: field_bwd_prepare and hashgrid_bwd_prepare (all levels) already ran for this step's parameters/positions;
     ``hash_ready``: event of the stream hashgrid_bwd_prepare was issued on -- waited for only in front of the scatter pass, so the
     histogram may still be running under the field backward.
@@ -559,7 +577,7 @@ def field_backward_into(spec: FieldSpec, flat, pos01, sel, wpos, d, enc, sigma_r
         d_flat[tail:].zero_()  # never written -- the sink's persistent buffer has it zeroed once, a fresh tensor needs it now
     d_tail = torch.zeros(L.total - tail, device=flat.device, dtype=torch.float32) if acc else None
     d_enc = field_bwd(spec, flat.detach(), enc, True, wpos, d, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
-                      packs_ready=prepared, feat_logits=feat_logits, d_tail=d_tail)
+                      packs_ready=prepared, feat_logits=feat_logits, d_tail=d_tail, comp=comp)
     if acc:
         d_flat[tail:].add_(d_tail)
     if own:

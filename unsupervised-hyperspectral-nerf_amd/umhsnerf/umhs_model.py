@@ -428,6 +428,12 @@ class UMHSModel(ModelBase):
         # nothing to remove (C5 1.775 -> 1.826).  UMHS_SPLIT_FWD=0 / 1 forces either path.
         knob = os.environ.get("UMHS_SPLIT_FWD", "")
         split_fwd = n > 0 and (knob == "1" or (knob != "0" and c.pred_specular and L.wavelengths > 32))
+        # ... and with the value half of the compositing backward folded into the field backward (umhs_field_bwd_composited) no [N,B]
+        # array is left at all: spectral is recomputed there, d_spectral formed on the fly.  UMHS_FUSED_BWD=0 keeps the per-sample arrays.
+        knob_b = os.environ.get("UMHS_FUSED_BWD", "")
+        fused_bwd = n > 0 and knob_b != "0" and (knob_b == "1" or L.wavelengths > 32) and knob != "0" \
+            and ops.field_bwd_composited_supported(spec)
+        split_fwd = split_fwd or fused_bwd
         if split_fwd:
             # Two launches with the rendering weights known in between: mlp_base -> weights (transmittance scan) -> heads, whose
             # kernel forms the per-ray band sums itself.  spectral2 / specular (no loss, umhs_model.py:373-374) never exist per sample
@@ -435,7 +441,8 @@ class UMHSModel(ModelBase):
             fo = ops.field_base_fwd(spec, flat, enc, True, sel, pack_ready=side is not None)
             weights, acc, depth, _ = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, [])
             ri = ray_indices if ray_indices.dtype == torch.int64 else ray_indices.long()
-            ho = ops.field_heads_fwd(spec, flat, fo["emb"], wpos, d, weights, ri.contiguous(), packed_info, pack_ready=True,
+            ri = ri.contiguous()
+            ho = ops.field_heads_fwd(spec, flat, fo["emb"], wpos, d, weights, ri, packed_info, want_spectral=not fused_bwd, pack_ready=True,
                                      release=side is not None)
             fo.update(spectral=ho["spectral"], abundances=ho["abundances"], feat_logits=ho["feat_logits"])
             comp = ho["comp"] + [ops.accumulate_fwd(weights, ho["abundances"], packed_info)]
@@ -450,6 +457,7 @@ class UMHSModel(ModelBase):
         both = c.method == "rgb+spectral"
         bg = (background if background is not None else torch.rand_like(image)) if (both and self.background_color == "random") else None
         w = (5.0, float(c.rgb_loss_weight)) if both else (1.0, 0.0)
+        bwd_comp = None
         if os.environ.get("UMHS_FUSED_RAY", "0") == "1" and L.wavelengths <= 256 and not split_fwd:
             # Everything that is local to a ray -- compositing forward, epilogue + losses + their backward, compositing backward -- in
             # one launch (umhs_ray_train_fused; equal to the three kernels below, tests/test_hip_trajectory.py).  Measured at C2 on one
@@ -466,11 +474,17 @@ class UMHSModel(ModelBase):
             rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(
                 comp[0], M, f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), hs, image if both else None, bg, 0.2,
                 w[0], w[1], both)
-            d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
-                                                  bool(c.use_gradient_scaling))
-            d_spectral_samples = d_values[0]
+            if fused_bwd:
+                d_sigma = d_spectral_samples = None
+                bwd_comp = dict(sigma=fo["sigma"], t0=t0, t1=t1, packed_info=packed_info, ray_indices=ri, weights=weights, d_comp=d_spec,
+                                d_acc=d_acc, grad_scaling=bool(c.use_gradient_scaling))
+            else:
+                d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
+                                                      bool(c.use_gradient_scaling))
+                d_spectral_samples = d_values[0]
         left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_spectral_samples, None,
-                                       prepared=prepared, feat_logits=fo["feat_logits"], hash_ready=ev_done if side is not None else None)
+                                       prepared=prepared, feat_logits=fo["feat_logits"], hash_ready=ev_done if side is not None else None,
+                                       comp=bwd_comp)
         assert left is None  # direct_step_supported() guarantees the sink owned this backward
         outputs = self._assemble_outputs(acc.view(-1, 1), depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights.view(-1, 1),
                                          lazy_bands=True)
