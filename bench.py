@@ -209,7 +209,8 @@ def main():
     batch = {"image": gt_rgb, "hs_image": b["gt_spectral"]}
 
     timer = KernelTimer(ops)
-    OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "composite_fwd", "tmid_minmax", "ray_train_tail", "composite_bwd", "field_bwd",
+    OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "field_base_fwd", "field_heads_fwd", "accumulate_fwd", "composite_fwd", "tmid_minmax",
+           "ray_train_tail", "composite_bwd", "field_bwd",
            "hashgrid_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "field_fwd_prepare", "field_bwd_prepare", "adam_step",
            "adam_step_rows", "adam_step_rows_range")  # (one GPU: the dense hash levels' Adam step rides in hashgrid_bwd_apply)
     for name in OPS:
@@ -293,7 +294,10 @@ def main():
         alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12), "hashgrid_bwd_apply": N * (1024 + 128 + 12),
                      "composite_fwd": N * (nstream + 4) * 4, "composite_bwd": N * (2 * B + 5) * 4,
                      "adam_step": pipe.model.field.flat.numel() * 28}
-        alg_flops = {"field_fwd": 2.0 * mac * N, "field_bwd": 4.0 * mac * N}
+        # (wide-band models run the forward as mlp_base + heads with the per-ray band sums inside the heads kernel, and the backward
+        # with the compositing backward's value half inside field_bwd: ops.field_base_fwd / field_heads_fwd; field_bwd then includes it)
+        alg_flops = {"field_fwd": 2.0 * mac * N, "field_bwd": 4.0 * mac * N, "field_base_fwd": 2.0 * 3072 * N,
+                     "field_heads_fwd": 2.0 * (mac - 3072) * N}
         # HBM traffic / MFMA-busy from the committed rocprofv3 --pmc passes of this same command -- only when they were taken on
         # THIS build of the kernels (the summary records the source hash); counters cannot be read from inside the process
         pmc, pmc_src = {}, None
@@ -307,7 +311,8 @@ def main():
             except Exception:
                 pass
         op_kernels = {"field_bwd": ("field_bwd_part_kernel", "field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce", "field_bwd_tf_kernel"),
-                      "field_fwd": ("field_fwd_kernel", "field_pack_fwd"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
+                      "field_fwd": ("field_fwd_kernel", "field_pack_all"), "field_base_fwd": ("field_fwd_kernel<false, true",),
+                      "field_heads_fwd": ("field_fwd_kernel", "field_heads_finish"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
                       "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"),
                       "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel"), "adam_step": ("adam_kernel",),
                       "composite_fwd": ("composite_fwd_kernel",), "composite_bwd": ("composite_bwd_kernel",)}

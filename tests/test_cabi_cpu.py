@@ -118,6 +118,33 @@ def test_null_pointers_of_the_field_and_hashgrid_entries_are_argument_errors():
     for missing in ("params", "enc", "wpos", "dirs", "sel", "sigma_raw", "emb", "d_sigma", "d_spectral", "grads"):
         assert bwd(**{missing: None}) == ARG, missing
     assert bwd(ws=None) == -3 and bwd(wsb=16) == -3  # workspace missing / too small
+    # the two-launch forward and the backward with the compositing backward folded in (none of these has a fallback for a missing input)
+    base = lambda **kw: lib.umhs_field_base_fwd(*[kw.get(k, v) for k, v in dict(
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, sel=d, n=64, sigma=d, sigma_raw=d, emb=d, ws=d, wsb=1 << 30,
+        ready=1, stream=None).items()])
+    for missing in ("params", "enc", "sel", "sigma", "ws"):
+        assert base(**{missing: None}) == ARG, missing
+    assert base(wsb=16) == -3
+    heads = lambda **kw: lib.umhs_field_heads_fwd(*[kw.get(k, v) for k, v in dict(
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), emb=d, wpos=d, dirs=d, n=64, weights=d, ray=d, pinfo=d, R=4, spectral=None, abund=d,
+        logits=d, c0=d, c1=d, c2=d, scratch=d, sb=1 << 30, ws=d, wsb=1 << 30, ready=1, stream=None).items()])
+    for missing in ("params", "emb", "wpos", "dirs", "weights", "ray", "pinfo", "c0", "scratch", "ws"):
+        assert heads(**{missing: None}) == ARG, missing
+    assert heads(sb=16) == -3 and heads(wsb=16) == -3
+    assert lib.umhs_field_heads_fwd_scratch_bytes(ctypes.byref(cfg), 64) >= 4 * 2 * 3 * 32 * 4
+    assert lib.umhs_field_bwd_composited_supported(ctypes.byref(cfg)) == 1
+    bwdc = lambda **kw: lib.umhs_field_bwd_composited(*[kw.get(k, v) for k, v in dict(
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, wpos=d, dirs=d, sel=d, sigma_raw=d, emb=d, logits=d, n=64,
+        sigma=d, t0=d, t1=d, pinfo=d, R=4, ray=d, weights=d, d_comp=d, d_acc=None, gs=1, d_sigma=d, d_enc=d, grads=ctypes.byref(gp), ws=d,
+        wsb=1 << 30, ready=0, stream=None).items()])
+    for missing in ("params", "enc", "wpos", "dirs", "sel", "sigma_raw", "emb", "logits", "sigma", "t0", "t1", "pinfo", "ray", "weights", "d_comp",
+                    "d_sigma", "grads"):
+        assert bwdc(**{missing: None}) == ARG, missing
+    assert bwdc(ws=None) == -3
+    dots = lambda **kw: lib.umhs_composite_bwd_dots(*[kw.get(k, v) for k, v in dict(
+        sigma=d, t0=d, t1=d, pinfo=d, R=4, n=64, weights=d, dots=d, d_acc=None, gs=0, d_sigma=d, stream=None).items()])
+    for missing in ("sigma", "t0", "t1", "pinfo", "weights", "dots", "d_sigma"):
+        assert dots(**{missing: None}) == ARG, missing
     # hash-grid backward halves: positions, scalings, gradient and destination are all required before anything is launched
     prep = lambda pos=d, sc=d: lib.umhs_hashgrid_bwd_prepare(pos, sc, 512, 0, 16, 19, d, 1 << 30, None)
     assert prep(pos=None) == ARG and prep(sc=None) == ARG

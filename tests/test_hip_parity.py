@@ -497,9 +497,14 @@ def test_ray_epilogue_and_fused_loss():
     assert abs(float(l1) - float(torch.nn.functional.mse_loss(spec, gt_s))) < 1e-6
 
 
-def test_model_train_iteration_matches_oracle_step():
-    """Plugin-surface path (UMHSPipeline.train_iteration): outputs, losses and the parameters after one fused-Adam step."""
+@pytest.mark.parametrize("fused", ["0", "1"], ids=["per-sample arrays", "band sums in the field kernels"])
+def test_model_train_iteration_matches_oracle_step(fused, monkeypatch):
+    """Plugin-surface path (UMHSPipeline.train_iteration): outputs, losses and the parameters after one fused-Adam step -- for both
+    forms of the step (composite kernels over [N,B] arrays / two-launch forward + folded compositing backward)."""
     import numpy as np
+
+    monkeypatch.setenv("UMHS_SPLIT_FWD", fused)
+    monkeypatch.setenv("UMHS_FUSED_BWD", fused)
     from umhsnerf._ns_compat import packed_ray_samples
     from umhsnerf.umhs_model import UMHSConfig
     from umhsnerf.umhs_pipeline import UMHSPipeline

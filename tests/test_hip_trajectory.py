@@ -71,11 +71,17 @@ def hip_batch(b, M):
 
 
 # ------------------------------------------------------------------------------------------------------------------- #
-def test_fifty_step_training_trajectory_matches_the_oracle():
-    """Same init, same four batches cycled, 50 steps of Adam(lr 2e-2 exp-decayed, eps 1e-15) + clamp_endmembers
+@pytest.mark.parametrize("path", ["per-sample [N,B] arrays", "band sums inside the field kernels"])
+def test_fifty_step_training_trajectory_matches_the_oracle(path, monkeypatch):
+    """(Both forms of the training step: the field forward + compositing kernels over per-sample [N,B] arrays -- the default up to 32
+    bands -- and the two-launch forward / folded compositing backward that never materialises them -- the default above.)
+    Same init, same four batches cycled, 50 steps of Adam(lr 2e-2 exp-decayed, eps 1e-15) + clamp_endmembers
     (umhs_config.py:59-64, umhs_model.py:358-370,568-572).  Bounds: loss curve 1e-3 relative at every step, final spectral PSNR
     0.05 dB, endmembers 1e-3 absolute.  (The fp32 oracle drifts from its own fp64 run by 4e-5 / 2e-4 dB / 4e-5 over these 50
     steps, so the bounds are ~25x the arithmetic noise floor, not slack for a wrong update rule.)"""
+    fused = path.startswith("band sums")
+    monkeypatch.setenv("UMHS_SPLIT_FWD", "1" if fused else "0")
+    monkeypatch.setenv("UMHS_FUSED_BWD", "1" if fused else "0")
     R, S, B, C, temp, log2_T, steps = 64, 24, 31, 6, 0.4, 14, 50
     bands = list(np.linspace(400, 700, B))
     M = T.colour_matrix(bands)
