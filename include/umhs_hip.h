@@ -168,13 +168,17 @@ int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_params* param
 /*                         fixed order (per 16-sample tile, then tile by tile): same bits every run.                             */
 int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                         int64_t stride_l, const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
-                        void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
+                        float* base16, void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
 size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n);
-int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb, const float* world_pos,
-                         const float* directions, int64_t n, const float* weights, const int64_t* ray_indices,
-                         const int64_t* packed_info, int64_t n_rays, float* spectral, float* abundances, float* feat_logits,
-                         float* comp_spectral, float* comp_spectral2, float* comp_specular, void* scratch, size_t scratch_bytes,
-                         void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
+/* emb / base16: the base MLP's outputs either as the reference's [N,15] embedding (emb, emb_stride 15; any of emb / base16 may be    */
+/* NULL in umhs_field_base_fwd) or as aligned rows base16 [N,16] with sigma_raw in slot 0 (emb_stride 16: one 64-byte row per sample  */
+/* instead of 15 dword stores / loads).  comp_abundances [R,C] (optional): the per-ray abundance sums, fourth stream of the kernel.  */
+int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb, int emb_stride,
+                         const float* world_pos, const float* directions, int64_t n, const float* weights,
+                         const int64_t* ray_indices, const int64_t* packed_info, int64_t n_rays, float* spectral, float* abundances,
+                         float* feat_logits, float* comp_spectral, float* comp_spectral2, float* comp_specular,
+                         float* comp_abundances, void* scratch, size_t scratch_bytes, void* workspace, size_t workspace_bytes,
+                         int pack_ready, umhs_stream_t stream);
 /* feat_logits (optional, [N,16]): the feature_mlp logits, saved so that umhs_field_bwd can run its heads as two kernels   */
 /* (head MLP + directional + mixing / feature MLP) with every weight pack LDS-resident; NULL there = one fused kernel.       */
 /* builds the pack image ahead of time (parameters only): then pass pack_ready = 1 with the same workspace */
@@ -201,7 +205,8 @@ int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
 int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg);
 int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                               int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
-                              const float* sigma_raw, const float* emb, const float* feat_logits, int64_t n, const float* sigma,
+                              const float* sigma_raw, const float* emb, int emb_stride, const float* feat_logits, int64_t n,
+                              const float* sigma,
                               const float* t_starts, const float* t_ends, const int64_t* packed_info, int64_t n_rays,
                               const int64_t* ray_indices, const float* weights, const float* d_comp_spectral,
                               const float* d_accumulation, int grad_scaling, float* d_sigma, float* d_enc,

@@ -120,21 +120,22 @@ def test_null_pointers_of_the_field_and_hashgrid_entries_are_argument_errors():
     assert bwd(ws=None) == -3 and bwd(wsb=16) == -3  # workspace missing / too small
     # the two-launch forward and the backward with the compositing backward folded in (none of these has a fallback for a missing input)
     base = lambda **kw: lib.umhs_field_base_fwd(*[kw.get(k, v) for k, v in dict(
-        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, sel=d, n=64, sigma=d, sigma_raw=d, emb=d, ws=d, wsb=1 << 30,
-        ready=1, stream=None).items()])
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, sel=d, n=64, sigma=d, sigma_raw=d, emb=d, b16=None, ws=d,
+        wsb=1 << 30, ready=1, stream=None).items()])
     for missing in ("params", "enc", "sel", "sigma", "ws"):
         assert base(**{missing: None}) == ARG, missing
     assert base(wsb=16) == -3
     heads = lambda **kw: lib.umhs_field_heads_fwd(*[kw.get(k, v) for k, v in dict(
-        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), emb=d, wpos=d, dirs=d, n=64, weights=d, ray=d, pinfo=d, R=4, spectral=None, abund=d,
-        logits=d, c0=d, c1=d, c2=d, scratch=d, sb=1 << 30, ws=d, wsb=1 << 30, ready=1, stream=None).items()])
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), emb=d, es=15, wpos=d, dirs=d, n=64, weights=d, ray=d, pinfo=d, R=4, spectral=None, abund=d,
+        logits=d, c0=d, c1=d, c2=d, cab=d, scratch=d, sb=1 << 30, ws=d, wsb=1 << 30, ready=1, stream=None).items()])
+    assert heads(es=14) == ARG and heads(es=16, emb=ctypes.c_void_p(4100)) == ARG  # 15 or 16; the row form is 16-byte aligned
     for missing in ("params", "emb", "wpos", "dirs", "weights", "ray", "pinfo", "c0", "scratch", "ws"):
         assert heads(**{missing: None}) == ARG, missing
     assert heads(sb=16) == -3 and heads(wsb=16) == -3
-    assert lib.umhs_field_heads_fwd_scratch_bytes(ctypes.byref(cfg), 64) >= 4 * 2 * 3 * 32 * 4
+    assert lib.umhs_field_heads_fwd_scratch_bytes(ctypes.byref(cfg), 64) >= 4 * 2 * (3 * 32 + 16) * 4
     assert lib.umhs_field_bwd_composited_supported(ctypes.byref(cfg)) == 1
     bwdc = lambda **kw: lib.umhs_field_bwd_composited(*[kw.get(k, v) for k, v in dict(
-        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, wpos=d, dirs=d, sel=d, sigma_raw=d, emb=d, logits=d, n=64,
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, wpos=d, dirs=d, sel=d, sigma_raw=d, emb=d, es=15, logits=d, n=64,
         sigma=d, t0=d, t1=d, pinfo=d, R=4, ray=d, weights=d, d_comp=d, d_acc=None, gs=1, d_sigma=d, d_enc=d, grads=ctypes.byref(gp), ws=d,
         wsb=1 << 30, ready=0, stream=None).items()])
     for missing in ("params", "enc", "wpos", "dirs", "sel", "sigma_raw", "emb", "logits", "sigma", "t0", "t1", "pinfo", "ray", "weights", "d_comp",

@@ -689,10 +689,15 @@ def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
         runs.append([c.clone() for c in ho["comp"]])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
-    ho = ops.field_heads_fwd(fs, flat, base["emb"], wpos, dirs, w, ray_idx, packed_info, want_spectral=False, want_logits=False,
-                             pack_ready=True, release=False)
-    assert ho["spectral"] is None and ho["feat_logits"] is None
-    for a, b in zip(ho["comp"], runs[0]):
+    ab_ref = ops.accumulate_fwd(w, ref["abundances"], packed_info)
+    assert_close("per-ray abundances", ho["comp_abundances"], ab_ref, 2e-6)
+    # the aligned-row form of the base outputs ([N,16], sigma_raw in slot 0) feeds the same kernel: same bits everywhere
+    base16 = ops.field_base_fwd(fs, flat, enc, True, sel, pack_ready=True, rows16=True)
+    assert base16["emb"] is None and torch.equal(base16["base16"][:, 1:], ref["emb"]) and torch.equal(base16["base16"][:, 0], ref["sigma_raw"])
+    h2 = ops.field_heads_fwd(fs, flat, base16["base16"], wpos, dirs, w, ray_idx, packed_info, want_spectral=False, want_logits=False,
+                             pack_ready=True, release=False, want_abundances=False)
+    assert h2["spectral"] is None and h2["feat_logits"] is None and h2["abundances"] is None
+    for a, b in zip(h2["comp"] + [h2["comp_abundances"]], runs[0] + [ho["comp_abundances"]]):
         assert torch.equal(a, b)
 
 
@@ -733,3 +738,8 @@ def test_field_backward_with_the_compositing_backward_folded_in(C, B, spec, gs):
     assert_close("d_enc", d_enc, d_enc_ref, 2e-5)
     tail = layout.tail_offset()
     assert_close("parameter gradients", g_got[tail:], g_ref[tail:], 2e-5)
+    # the saved base outputs as aligned [N,16] rows: same bits
+    b16 = torch.cat([fo["sigma_raw"][:, None], fo["emb"]], 1).contiguous()
+    g2, cp2 = torch.zeros_like(flat), dict(cp)
+    d_enc2 = ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, fo["sigma_raw"], b16, None, None, None, g2, feat_logits=fo["feat_logits"], comp=cp2)
+    assert torch.equal(d_enc2, d_enc) and torch.equal(g2, g_got) and torch.equal(cp2["d_sigma"], cp["d_sigma"])

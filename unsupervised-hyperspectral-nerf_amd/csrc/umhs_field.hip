@@ -239,9 +239,14 @@ struct FieldIO {
   float* part;                         // per-16-sample-tile partial sums, see HeadsComp
   float* comp[3];                      // [R,B] band sums of spectral / spectral2 / specular (rays inside one tile are written here directly)
   int n_streams;                       // 1 without the specular head, else 3
+  float* part_ab;                      // abundances: per-tile partials [(g*2 + az)*16 + c]
+  float* comp_ab;                      // [R,C] per-ray abundance sums (or null)
+  float* bo16;                         // density half: the base MLP's 16 outputs as aligned rows [N,16] (slot 0 = sigma_raw), or null
+  const float* bo16_in;                // heads forward / backward part 0: read emb from such rows instead of [N,15]
   // transpose-free backward, part 0 with the compositing backward's value half folded in (FUSED): d_spectral[n][b] =
-  // scale_n * weights[n] * d_comp[ray(n)][b] is formed on the fly, and dots[n] = sum_b d_comp[ray(n)][b] * spectral[n][b] (spectral
-  // recomputed) goes out for umhs_composite_bwd_dots
+  // scale_n * weights[n] * d_comp[ray(n)][b] is formed on the fly, and dots[n] = sum_b d_comp[ray(n)][b] * spectral[n][b] goes out for
+  // umhs_composite_bwd_dots (mixing half: sum_c m[c] (d_comp E^T)[c], which the kernel's d m accumulator already is; specular half
+  // from the sigmoids it computes anyway)
   const float* d_comp;                 // [R,B] gradient w.r.t. the per-ray band sums of spectral
   const float *t0, *t1;                // [N] sample intervals (gradient scaling by distance), or null
   float* dots;                         // [N]
@@ -347,6 +352,7 @@ __device__ __forceinline__ void store_density(const FieldIO& io, const v4f (&bo4
           if (e >= 0) io.emb[nn[ct] * 15 + e] = bo4[ct][0][r];
         }
       }
+      if (io.bo16) *reinterpret_cast<v4f*>(io.bo16 + nn[ct] * 16 + 4 * q) = bo4[ct][0];  // one 64-byte row per sample
     }
   }
 }
@@ -577,8 +583,15 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int e = 4 * q + r - 1;
-          bo4[ct][0][r] = e >= 0 ? io.emb_in[nn[ct] * 15 + e] : 0.0f;  // slot 0 (sigma_raw) meets a zero weight column
+          bo4[ct][0][r] = (e >= 0 && !io.bo16_in) ? io.emb_in[nn[ct] * 15 + e] : 0.0f;  // slot 0 (sigma_raw) meets a zero weight column
         }
+      if (io.bo16_in) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          bo4[ct][0] = *reinterpret_cast<const v4f*>(io.bo16_in + nn[ct] * 16 + 4 * q);
+          if (q == 0) bo4[ct][0][0] = 0.0f;
+        }
+      }
     } else {
       v4f h4[NT][4];
       FWD_GEMM(4, 8, h4, encf, L_B0);
@@ -723,6 +736,45 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (ok[ct] && 4 * q + r < io.C) io.abund[nn[ct] * io.C + 4 * q + r] = hs.ab[ct][r];
+    }
+    if constexpr (HEADS) {
+      // abundances: the fourth stream of the per-ray sums.  Layout here is samples on lanes (lane = (sample j, q), reg r <-> class
+      // 4q+r): the sum over a tile's samples is a reduction over the 16 lanes of a row, masked by the sample's ray.
+      if (io.part_ab) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          if (rfirst[ct] < 0) continue;
+          const int64_t nb0 = tile * TILE + wave * (16 * NT) + ct * 16;
+          const int64_t g = nb0 >> 4;
+          const bool vj = nb0 + j < io.n;
+          const float wj = vj ? io.weights[nb0 + j] : 0.0f;
+          const int rj = vj ? (int)io.ray_of[nb0 + j] : -2;
+          auto row_sum = [&](int ray, float (&out)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = (rj == ray) ? wj * hs.ab[ct][r] : 0.0f;
+#pragma unroll
+              for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d, 64);
+              out[r] = v;
+            }
+          };
+          float a[4];
+          row_sum(rfirst[ct], a);
+          if (j == 0) *reinterpret_cast<v4f*>(io.part_ab + (g * 2 + 0) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
+          if (rlast[ct] != rfirst[ct]) {
+            row_sum(rlast[ct], a);
+            if (j == 0) *reinterpret_cast<v4f*>(io.part_ab + (g * 2 + 1) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
+            for (int m = rfirst[ct] + 1; m < rlast[ct]; ++m) {
+              row_sum(m, a);
+              if (j == 0 && io.comp_ab) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (4 * q + r < io.C) io.comp_ab[(int64_t)m * io.C + 4 * q + r] = a[r];
+              }
+            }
+          }
+        }
+      }
     }
   }
 }
@@ -1879,7 +1931,12 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int e = 4 * q + r - 1;
-        in.emb[r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) meets a zero weight column
+        in.emb[r] = (e >= 0 && !io.bo16_in) ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) meets a zero weight column
+      }
+      if (io.bo16_in) {  // the aligned-row form of the saved base outputs (one 16-byte load)
+        const v4f b4 = *reinterpret_cast<const v4f*>(io.bo16_in + n * 16 + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in.emb[r] = (q == 0 && r == 0) ? 0.0f : b4[r];
       }
       in.x0 = *reinterpret_cast<const v4f*>(io.feat_logits_in + n * 16 + 4 * q);
       if (FUSED) {
@@ -2031,13 +2088,17 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
           float dsp[NT][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) dsp[0][r] = FUSED ? cur.ws * dall[t][r] : dall[t][r];
-          if (FUSED) {  // this band tile of the mixing product, for the dot with the ray's upstream gradient
-            v4f mx4[NT][1];
-            gemm_pack<1, 4, NT, 1>(mx4, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
+          if (FUSED) {
+            // d m accumulates from the UNSCALED ray gradient and is scaled by ws_n after the loop (the product is linear in it):
+            // sum_b d_comp[b] (m E)[b] = sum_c m[c] (d_comp E^T)[c], so the mixing half of the dot product falls out of this
+            // accumulator and spectral's mixing term never has to be recomputed
+            float dcv[NT][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dotacc += dall[t][r] * mx4[0][0][r];
+            for (int r = 0; r < 4; ++r) dcv[0][r] = dall[t][r];
+            gemm_pack<1, 4, NT, 0>((t & 1) ? dm4b : dm4, dcv, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+          } else {
+            gemm_pack<1, 4, NT, 0>((t & 1) ? dm4b : dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
           }
-          gemm_pack<1, 4, NT, 0>((t & 1) ? dm4b : dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
           STile dspS[1];
           dspS[0] = to_swapped<false>(dsp[0], ident);
           dw_pairs<1, 1>(&acc_[SL::A_MX - A0 + t], dspS, mS);  // dE^T[b][c] += sum_n d_spectral[n][b] m[n][c]
@@ -2060,12 +2121,16 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         }
       }
       TF_STAMP(3);
+      dm4[0][0] += dm4b[0][0], dhd4[0][0] += dhd4b[0][0];
       if (FUSED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dotacc += hs.m[0][r] * dm4[0][0][r];  // classes 4q+r (m is zero from class C on)
         dotacc = xq_sum(dotacc);
         if (ok && q == 0) io.dots[n] = dotacc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dm4[0][0][r] *= cur.ws;
       }
       ds1 = xq_sum(ds1);
-      dm4[0][0] += dm4b[0][0], dhd4[0][0] += dhd4b[0][0];
       // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
       float dhs[NT][4], dfl[NT][4];
       {
@@ -2662,7 +2727,7 @@ extern "C" int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_pa
 // images umhs_field_heads_fwd uses, built once by umhs_field_fwd_prepare).
 extern "C" int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                                    int64_t stride_l, const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
-                                   void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
+                                   float* base16, void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
@@ -2684,7 +2749,8 @@ extern "C" int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_p
   fp.args.bf_image = img + ((pd.total + 63) & ~63);
   FieldIO io = {};
   io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.sel = selector, io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = 0;
-  io.temperature = cfg->temperature, io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb;
+  io.temperature = cfg->temperature, io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.bo16 = base16;
+  if (base16 && ((uintptr_t)base16 & 15)) return UMHS_ERR_ARG;
   const int64_t ntiles = (n + 127) / 128;
   const unsigned grid = (unsigned)(ntiles < 256 * 8 ? ntiles : 256 * 8);
   rc = set_lds(field_fwd_kernel<false, true, 2, 4, false, true>, fp.lds);
@@ -2697,10 +2763,11 @@ extern "C" int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_p
 
 // Adds the tile partials of umhs_field_heads_fwd ray by ray (see field_fwd_kernel, HEADS): one workgroup per ray, threads over
 // (stream, band), tiles in order.
-__global__ __launch_bounds__(128) void field_heads_finish_kernel(const float* __restrict__ part, const int64_t* __restrict__ ray_of,
+__global__ __launch_bounds__(256) void field_heads_finish_kernel(const float* __restrict__ part, const int64_t* __restrict__ ray_of,
                                                                 const int64_t* __restrict__ pinfo, int64_t n, int B, int BP, int NS,
                                                                 float* __restrict__ c0, float* __restrict__ c1,
-                                                                float* __restrict__ c2) {
+                                                                float* __restrict__ c2, const float* __restrict__ part_ab, int C,
+                                                                float* __restrict__ cab) {
   const int64_t ray = blockIdx.x;
   const int64_t s0 = pinfo[2 * ray], cnt = pinfo[2 * ray + 1];
   const int64_t ts = s0 >> 4, te = cnt > 0 ? (s0 + cnt - 1) >> 4 : ts - 1;
@@ -2708,39 +2775,44 @@ __global__ __launch_bounds__(128) void field_heads_finish_kernel(const float* __
     const int64_t l = 16 * ts + 15 < n ? 16 * ts + 15 : n - 1;
     if (ray_of[16 * ts] != ray && ray_of[l] != ray) return;
   }
-  for (int i = threadIdx.x; i < NS * B; i += 128) {
+  // only the ray's first tile can hold it as its LAST ray (Z); every later tile starts with it (A)
+  const int az0 = (cnt > 0 && ray_of[16 * ts] != ray) ? 1 : 0;
+  for (int i = threadIdx.x; i < NS * B; i += 256) {
     const int sidx = i / B, b = i - sidx * B;
     float acc = 0.0f;
-    for (int64_t t = ts; t <= te; ++t) {
-      const int az = ray_of[16 * t] == ray ? 0 : 1;
-      acc += part[((t * 2 + az) * NS + sidx) * BP + b];
-    }
+    for (int64_t t = ts; t <= te; ++t) acc += part[((t * 2 + (t == ts ? az0 : 0)) * NS + sidx) * BP + b];
     float* const c = sidx == 0 ? c0 : (sidx == 1 ? c1 : c2);
     if (c) c[ray * B + b] = acc;
+  }
+  if (cab && threadIdx.x < C) {
+    float acc = 0.0f;
+    for (int64_t t = ts; t <= te; ++t) acc += part_ab[(t * 2 + (t == ts ? az0 : 0)) * 16 + threadIdx.x];
+    cab[ray * C + threadIdx.x] = acc;
   }
 }
 
 extern "C" size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n) {
   if (check_cfg(cfg) || cfg->density_only || n <= 0) return 0;
   const int TB = (cfg->n_bands + 15) / 16, NS = cfg->pred_specular ? 3 : 1;
-  return (size_t)((n + 15) / 16) * 2 * NS * 16 * TB * sizeof(float) + 256;
+  return (size_t)((n + 15) / 16) * 2 * (NS * 16 * TB + 16) * sizeof(float) + 256;  // band streams, then the abundance partials
 }
 
 // umhs_field_heads_fwd: everything after mlp_base from its saved outputs emb [N,15], with the per-ray band sums
 // comp_*[r][b] = sum over the samples n of ray r of weights[n] * stream[n][b] formed inside the kernel; spectral [N,B] (per sample) is
 // written only when given.  ray_indices [N] non-decreasing, packed_info [R,2] = (first sample, count) as umhs_pack_info makes them.
-extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb,
+extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb, int emb_stride,
                                     const float* world_pos, const float* directions, int64_t n, const float* weights,
                                     const int64_t* ray_indices, const int64_t* packed_info, int64_t n_rays, float* spectral,
                                     float* abundances, float* feat_logits, float* comp_spectral, float* comp_spectral2,
-                                    float* comp_specular, void* scratch, size_t scratch_bytes, void* workspace, size_t workspace_bytes,
-                                    int pack_ready, umhs_stream_t stream) {
+                                    float* comp_specular, float* comp_abundances, void* scratch, size_t scratch_bytes, void* workspace,
+                                    size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
   const bool spec = cfg->pred_specular != 0;
   if (!params || !workspace || n < 0 || n_rays < 0 || !packed_info || !comp_spectral) return UMHS_ERR_ARG;
   if (n > 0 && (!emb || !world_pos || !weights || !ray_indices || !scratch || (spec && !directions))) return UMHS_ERR_ARG;
+  if ((emb_stride != 15 && emb_stride != 16) || (emb_stride == 16 && ((uintptr_t)emb & 15))) return UMHS_ERR_ARG;
   if (n_rays == 0) return UMHS_OK;
   PackDesc pd;
   int TB;
@@ -2761,7 +2833,9 @@ extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_
     FieldIO io = {};
     io.wpos = world_pos, io.dirs = directions, io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB;
     io.temperature = cfg->temperature, io.emb_in = emb, io.spectral = spectral, io.abund = abundances, io.feat_logits = feat_logits;
+    if (emb_stride == 16) io.bo16_in = emb;
     io.weights = weights, io.ray_of = ray_indices, io.part = reinterpret_cast<float*>(scratch);
+    io.part_ab = comp_abundances ? io.part + (size_t)((n + 15) / 16) * 2 * NS * 16 * TB : nullptr, io.comp_ab = comp_abundances;
     io.comp[0] = comp_spectral, io.comp[1] = comp_spectral2, io.comp[2] = comp_specular, io.n_streams = NS;
     const int64_t ntiles = (n + 255) / 256;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
@@ -2778,9 +2852,10 @@ extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_
     }
     UMHS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(field_heads_finish_kernel, dim3((unsigned)n_rays), dim3(128), 0, umhs_s(stream),
+  hipLaunchKernelGGL(field_heads_finish_kernel, dim3((unsigned)n_rays), dim3(256), 0, umhs_s(stream),
                      reinterpret_cast<const float*>(scratch), ray_indices, packed_info, n, cfg->n_bands, 16 * TB, NS, comp_spectral,
-                     spec ? comp_spectral2 : nullptr, spec ? comp_specular : nullptr);
+                     spec ? comp_spectral2 : nullptr, spec ? comp_specular : nullptr,
+                     reinterpret_cast<const float*>(scratch) + (size_t)((n + 15) / 16) * 2 * NS * 16 * TB, cfg->n_classes, comp_abundances);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
@@ -3004,12 +3079,11 @@ static int bf_image_dwords(const BwdPlan& pl) {
   return bp.total;
 }
 
-static bool tf_part(const BwdPlan& pl, int part, bool bf, TfPart* pp, bool fused = false) {
-  // fused (part 0): also the forward mixing pack -- the kernel recomputes spectral for the compositing backward's dot products
-  const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1, L_MX}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
+static bool tf_part(const BwdPlan& pl, int part, bool bf, TfPart* pp) {
+  const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
   const int fl1[] = {L_B0, L_B1, L_F0, L_F1}, tl1[] = {T_B1, T_B0, T_F2, T_F1, T_F0};
   const int* fl = part == 0 ? fl0 : fl1;
-  const int nfl = part == 0 ? (fused ? 6 : 5) : 4;
+  const int nfl = part == 0 ? 5 : 4;
   const int* tl = part == 0 ? tl0 : tl1;
   const int ntl = 5;
   pp->pd = pl.pd_all, pp->td = pl.td;
@@ -3042,7 +3116,6 @@ static bool tf_part(const BwdPlan& pl, int part, bool bf, TfPart* pp, bool fused
   }
   for (int i = 0; i < nfl; ++i) {
     const LayerDesc& L = pl.pd_all.L[fl[i]];
-    if (fl[i] == L_MX) continue;  // no bias tile
     add(pp->seg_f, L.off_b, cur, 16 * L.OT);
     pp->pd.L[fl[i]].off_b = cur, cur += 16 * L.OT;
   }
@@ -3101,6 +3174,7 @@ struct BwdComp {
   int64_t n_rays;
   int grad_scaling;
   float *d_sigma, *dots;
+  bool emb16;  // emb is the aligned [N,16] form umhs_field_base_fwd writes (slot 0 = sigma_raw)
 };
 
 template <int TBMAX>
@@ -3264,15 +3338,15 @@ static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* par
     TfPart part[2];
     bool ok = true;
     for (int p = 0; p < 2; ++p) {
-      const bool fused = bc && p == 0;
-      if ((bf_mask >> p & 1) && !tf_part(pl, p, true, &part[p], fused)) bf_mask &= ~(1 << p);  // LDS: fall back to the fp32 chain
-      if (!(bf_mask >> p & 1)) ok = ok && tf_part(pl, p, false, &part[p], fused);
+      if ((bf_mask >> p & 1) && !tf_part(pl, p, true, &part[p])) bf_mask &= ~(1 << p);  // LDS: fall back to the fp32 chain
+      if (!(bf_mask >> p & 1)) ok = ok && tf_part(pl, p, false, &part[p]);
     }
     if (ok) {
       io.feat_logits_in = feat_logits, io.d_fl = d_fl;
       if (bc) {
         bc->dots = d_bo2;  // [N] of the (unused here) second hand-off buffer
         io.weights = bc->weights, io.ray_of = bc->ray_of, io.d_comp = bc->d_comp, io.dots = bc->dots;
+        if (bc->emb16) io.bo16_in = emb;
         io.t0 = bc->grad_scaling ? bc->t0 : nullptr, io.t1 = bc->grad_scaling ? bc->t1 : nullptr;
       }
       switch (tbmax) {
@@ -3373,7 +3447,7 @@ extern "C" int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg) {
   BwdPlan pl;
   if (build_bwd_plan(cfg, &dummy, &pl) || tf_tbmax(pl.TB) == 0) return 0;
   TfPart part;
-  return tf_part(pl, 0, false, &part, true) && tf_part(pl, 1, false, &part, false) ? 1 : 0;
+  return tf_part(pl, 0, false, &part) && tf_part(pl, 1, false, &part) ? 1 : 0;
 }
 
 // umhs_field_bwd with the value half of the compositing backward folded in (training step after umhs_field_heads_fwd): instead of
@@ -3384,8 +3458,8 @@ extern "C" int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg) {
 // Neither spectral nor d_spectral exists as an [N,B] array.  feat_logits is required.
 extern "C" int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
                                          int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
-                                         const float* selector, const float* sigma_raw, const float* emb, const float* feat_logits,
-                                         int64_t n, const float* sigma, const float* t_starts, const float* t_ends,
+                                         const float* selector, const float* sigma_raw, const float* emb, int emb_stride,
+                                         const float* feat_logits, int64_t n, const float* sigma, const float* t_starts, const float* t_ends,
                                          const int64_t* packed_info, int64_t n_rays, const int64_t* ray_indices, const float* weights,
                                          const float* d_comp_spectral, const float* d_accumulation, int grad_scaling, float* d_sigma,
                                          float* d_enc, const umhs_field_grads* grads, void* workspace, size_t workspace_bytes,
@@ -3393,6 +3467,8 @@ extern "C" int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_f
   BwdComp bc = {};
   bc.sigma = sigma, bc.t0 = t_starts, bc.t1 = t_ends, bc.weights = weights, bc.d_comp = d_comp_spectral, bc.d_acc = d_accumulation;
   bc.packed_info = packed_info, bc.ray_of = ray_indices, bc.n_rays = n_rays, bc.grad_scaling = grad_scaling, bc.d_sigma = d_sigma;
+  if ((emb_stride != 15 && emb_stride != 16) || (emb_stride == 16 && ((uintptr_t)emb & 15))) return UMHS_ERR_ARG;
+  bc.emb16 = emb_stride == 16;
   return run_field_bwd(cfg, params, enc, stride_n, stride_l, world_pos, directions, selector, sigma_raw, emb, feat_logits, n, d_sigma,
                        nullptr, nullptr, d_enc, grads, workspace, workspace_bytes, packs_ready, stream, &bc);
 }

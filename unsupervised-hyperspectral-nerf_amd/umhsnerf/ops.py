@@ -294,20 +294,21 @@ def field_fwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, density_
     return o
 
 
-def field_base_fwd(spec: FieldSpec, flat, enc, level_major, sel, pack_ready=False):
+def field_base_fwd(spec: FieldSpec, flat, enc, level_major, sel, pack_ready=False, rows16=False):
     """mlp_base only, from the full configuration's pack images (first launch of the two-launch training forward):
-    -> {"sigma" [N], "sigma_raw" [N], "emb" [N,15]}."""
+    -> {"sigma" [N], "sigma_raw" [N], "emb" [N,15]}; ``rows16``: instead of emb, "base16" [N,16] = aligned rows (sigma_raw, emb)."""
     n, dev, L = sel.shape[0], sel.device, spec.layout
     cfg = spec.cfg(False)
     pp = L.c_struct(flat, _hip.FieldParams)
     sn, sl = enc_strides(n, level_major)
     new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-    o = dict(sigma=new(n), sigma_raw=new(n), emb=new(n, GEO_FEAT_DIM))
+    o = dict(sigma=new(n), sigma_raw=new(n), emb=None if rows16 else new(n, GEO_FEAT_DIM), base16=new(n, 16) if rows16 else None)
     if not pack_ready:
         _require_free(dev, WS_FIELD_FWD, "field_base_fwd (pack image rebuild)")
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_base_fwd(C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(sel), n, ptr(o["sigma"]), ptr(o["sigma_raw"]),
-                                              ptr(o["emb"]), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_base_fwd")
+                                              ptr(o["emb"]), ptr(o["base16"]), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()),
+               "umhs_field_base_fwd")
     return o
 
 
@@ -315,9 +316,11 @@ _heads_scratch: Dict[int, torch.Tensor] = {}
 
 
 def field_heads_fwd(spec: FieldSpec, flat, emb, wpos, dirs, weights, ray_indices, packed_info, want_spectral=True, want_logits=True,
-                    pack_ready=True, release=True):
-    """Second launch of the two-launch training forward: heads + band tiles from ``emb``, per-ray band sums formed in the kernel.
-    -> {"spectral" [N,B] | None, "abundances" [N,C], "feat_logits" [N,16] | None, "comp": [spectral, spectral2, specular] ([R,B])}.
+                    pack_ready=True, release=True, want_abundances=True):
+    """Second launch of the two-launch training forward: heads + band tiles from ``emb`` ([N,15], or the [N,16] aligned rows of
+    field_base_fwd(rows16=True)), per-ray sums formed in the kernel.
+    -> {"spectral" [N,B] | None, "abundances" [N,C] | None, "feat_logits" [N,16] | None, "comp": [spectral, spectral2, specular] ([R,B]),
+        "comp_abundances" [R,C]}.
     ``pack_ready``: the images field_fwd_prepare / field_base_fwd left in the forward workspace are reused."""
     n, dev, L = emb.shape[0], emb.device, spec.layout
     R = packed_info.shape[0]
@@ -325,18 +328,19 @@ def field_heads_fwd(spec: FieldSpec, flat, emb, wpos, dirs, weights, ray_indices
     pp = L.c_struct(flat, _hip.FieldParams)
     new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
     B = L.wavelengths
-    o = dict(spectral=new(n, B) if want_spectral else None, abundances=new(n, L.num_classes),
-             feat_logits=new(n, 16) if want_logits else None)
+    o = dict(spectral=new(n, B) if want_spectral else None, abundances=new(n, L.num_classes) if want_abundances else None,
+             feat_logits=new(n, 16) if want_logits else None, comp_abundances=new(R, L.num_classes))
     comp = [new(R, B)] + ([new(R, B), new(R, B)] if L.pred_specular else [])
     need = _hip.lib().umhs_field_heads_fwd_scratch_bytes(C.byref(cfg), max(n, 1))
     sc = _heads_scratch.get(dev.index or 0)
     if sc is None or sc.numel() < need:
         sc = _heads_scratch[dev.index or 0] = torch.empty(need, device=dev, dtype=torch.uint8)
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
-    _hip.check(_hip.lib().umhs_field_heads_fwd(C.byref(cfg), C.byref(pp), ptr(emb), ptr(wpos), ptr(dirs), n, ptr(weights), ptr(ray_indices),
-                                               ptr(packed_info), R, ptr(o["spectral"]), ptr(o["abundances"]), ptr(o["feat_logits"]),
-                                               ptr(comp[0]), ptr(comp[1]) if len(comp) > 1 else None, ptr(comp[2]) if len(comp) > 1 else None,
-                                               ptr(sc), sc.numel(), ptr(ws), ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_heads_fwd")
+    _hip.check(_hip.lib().umhs_field_heads_fwd(C.byref(cfg), C.byref(pp), ptr(emb), emb.shape[1], ptr(wpos), ptr(dirs), n, ptr(weights),
+                                               ptr(ray_indices), ptr(packed_info), R, ptr(o["spectral"]), ptr(o["abundances"]),
+                                               ptr(o["feat_logits"]), ptr(comp[0]), ptr(comp[1]) if len(comp) > 1 else None,
+                                               ptr(comp[2]) if len(comp) > 1 else None, ptr(o["comp_abundances"]), ptr(sc), sc.numel(), ptr(ws),
+                                               ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_heads_fwd")
     if pack_ready and release:
         _release(dev, WS_FIELD_FWD)
     o["comp"] = comp
@@ -419,7 +423,7 @@ def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_ra
         comp["d_sigma"] = torch.empty(n, device=sel.device, dtype=torch.float32)
         pi = comp["packed_info"]
         _hip.check(_hip.lib().umhs_field_bwd_composited(
-            C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), ptr(sigma_raw), ptr(emb), ptr(feat_logits), n,
+            C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), ptr(sigma_raw), ptr(emb), emb.shape[1], ptr(feat_logits), n,
             ptr(comp["sigma"]), ptr(comp["t0"]), ptr(comp["t1"]), ptr(pi), pi.shape[0], ptr(comp["ray_indices"]), ptr(comp["weights"]),
             ptr(comp["d_comp"]), ptr(comp["d_acc"]), int(bool(comp["grad_scaling"])), ptr(comp["d_sigma"]), ptr(d_enc), C.byref(gp), ptr(ws),
             ws.numel(), int(packs_ready), _hip.stream()), "umhs_field_bwd_composited")

@@ -438,14 +438,16 @@ class UMHSModel(ModelBase):
             # Two launches with the rendering weights known in between: mlp_base -> weights (transmittance scan) -> heads, whose
             # kernel forms the per-ray band sums itself.  spectral2 / specular (no loss, umhs_model.py:373-374) never exist per sample
             # and the three-stream compositing pass over [N,B] disappears; per-sample spectral stays for the compositing backward.
-            fo = ops.field_base_fwd(spec, flat, enc, True, sel, pack_ready=side is not None)
+            fo = ops.field_base_fwd(spec, flat, enc, True, sel, pack_ready=side is not None, rows16=fused_bwd)
+            if fused_bwd:
+                fo["emb"] = fo["base16"]  # the aligned-row form feeds the heads kernel and the composited backward
             weights, acc, depth, _ = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, [])
             ri = ray_indices if ray_indices.dtype == torch.int64 else ray_indices.long()
             ri = ri.contiguous()
             ho = ops.field_heads_fwd(spec, flat, fo["emb"], wpos, d, weights, ri, packed_info, want_spectral=not fused_bwd, pack_ready=True,
-                                     release=side is not None)
-            fo.update(spectral=ho["spectral"], abundances=ho["abundances"], feat_logits=ho["feat_logits"])
-            comp = ho["comp"] + [ops.accumulate_fwd(weights, ho["abundances"], packed_info)]
+                                     release=side is not None, want_abundances=False)
+            fo.update(spectral=ho["spectral"], feat_logits=ho["feat_logits"])
+            comp = ho["comp"] + [ho["comp_abundances"]]
             values = [fo["spectral"]]
         else:
             fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
