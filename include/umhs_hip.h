@@ -163,19 +163,22 @@ int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_params* param
 /*   umhs_composite_fwd with no value streams: weights, accumulation, depth.                                                     */
 /*   umhs_field_heads_fwd: everything after mlp_base from emb [N,15]; comp_*[r][b] = sum_{n in ray r} weights[n] stream[n][b]    */
 /*                         (SpectralRenderer, renderers.py:18-53) for spectral / spectral2 / specular ([R,B]; the last two NULL   */
-/*                         without the specular head), abundances [N,C], feat_logits [N,16]; spectral [N,B] per sample only when  */
-/*                         given.  ray_indices [N] non-decreasing; packed_info [R,2] as umhs_pack_info.  The sums are taken in a  */
+/*                         without the specular head), abundances, feat_logits [N,16]; no [N,B] array is ever written.            */
+/*                         ray_indices [N] non-decreasing; packed_info [R,2] as umhs_pack_info.  The sums are taken in a          */
 /*                         fixed order (per 16-sample tile, then tile by tile): same bits every run.                             */
 int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                         int64_t stride_l, const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
                         float* base16, void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
-size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n);
+size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n, int64_t n_rays);
 /* emb / base16: the base MLP's outputs either as the reference's [N,15] embedding (emb, emb_stride 15; any of emb / base16 may be    */
 /* NULL in umhs_field_base_fwd) or as aligned rows base16 [N,16] with sigma_raw in slot 0 (emb_stride 16: one 64-byte row per sample  */
-/* instead of 15 dword stores / loads).  comp_abundances [R,C] (optional): the per-ray abundance sums, fourth stream of the kernel.  */
+/* instead of 15 dword stores / loads).  The mixing term is linear in the mixing input m: the kernel sums w_n m_n (16 classes) per   */
+/* ray and the finish pass multiplies by the endmembers once per RAY; only the specular term is formed per sample and band.          */
+/* comp_spectral2 / comp_specular: required with the specular head, ignored without.  comp_abundances [R,C], abundances [N,C],      */
+/* feat_logits [N,16]: optional.  scratch: umhs_field_heads_fwd_scratch_bytes, 16-byte aligned.                                      */
 int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb, int emb_stride,
                          const float* world_pos, const float* directions, int64_t n, const float* weights,
-                         const int64_t* ray_indices, const int64_t* packed_info, int64_t n_rays, float* spectral, float* abundances,
+                         const int64_t* ray_indices, const int64_t* packed_info, int64_t n_rays, float* abundances,
                          float* feat_logits, float* comp_spectral, float* comp_spectral2, float* comp_specular,
                          float* comp_abundances, void* scratch, size_t scratch_bytes, void* workspace, size_t workspace_bytes,
                          int pack_ready, umhs_stream_t stream);
@@ -203,6 +206,7 @@ int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
 /* d_comp[ray(n)] is formed on the fly and spectral is recomputed for dw_n: neither exists as an [N,B] array.  feat_logits          */
 /* required.  umhs_field_bwd_composited_supported: 1 when this configuration can take the path (else UMHS_ERR_UNSUPPORTED).         */
 int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg);
+size_t umhs_field_bwd_composited_scratch_bytes(const umhs_field_cfg* cfg, int64_t n, int64_t n_rays);
 int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, int64_t stride_n,
                               int64_t stride_l, const float* world_pos, const float* directions, const float* selector,
                               const float* sigma_raw, const float* emb, int emb_stride, const float* feat_logits, int64_t n,
@@ -210,8 +214,8 @@ int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_field_params
                               const float* t_starts, const float* t_ends, const int64_t* packed_info, int64_t n_rays,
                               const int64_t* ray_indices, const float* weights, const float* d_comp_spectral,
                               const float* d_accumulation, int grad_scaling, float* d_sigma, float* d_enc,
-                              const umhs_field_grads* grads, void* workspace, size_t workspace_bytes, int packs_ready,
-                              umhs_stream_t stream);
+                              const umhs_field_grads* grads, void* scratch, size_t scratch_bytes, void* workspace,
+                              size_t workspace_bytes, int packs_ready, umhs_stream_t stream);
 /* builds the transposed packs + forward image ahead of time (parameters only): then pass packs_ready = 1, same workspace */
 int umhs_field_bwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
                            size_t workspace_bytes, umhs_stream_t stream);

@@ -126,20 +126,22 @@ def test_null_pointers_of_the_field_and_hashgrid_entries_are_argument_errors():
         assert base(**{missing: None}) == ARG, missing
     assert base(wsb=16) == -3
     heads = lambda **kw: lib.umhs_field_heads_fwd(*[kw.get(k, v) for k, v in dict(
-        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), emb=d, es=15, wpos=d, dirs=d, n=64, weights=d, ray=d, pinfo=d, R=4, spectral=None, abund=d,
+        cfg=ctypes.byref(cfg), params=ctypes.byref(pp), emb=d, es=15, wpos=d, dirs=d, n=64, weights=d, ray=d, pinfo=d, R=4, abund=d,
         logits=d, c0=d, c1=d, c2=d, cab=d, scratch=d, sb=1 << 30, ws=d, wsb=1 << 30, ready=1, stream=None).items()])
     assert heads(es=14) == ARG and heads(es=16, emb=ctypes.c_void_p(4100)) == ARG  # 15 or 16; the row form is 16-byte aligned
-    for missing in ("params", "emb", "wpos", "dirs", "weights", "ray", "pinfo", "c0", "scratch", "ws"):
+    for missing in ("params", "emb", "wpos", "dirs", "weights", "ray", "pinfo", "c0", "c1", "c2", "scratch", "ws"):
         assert heads(**{missing: None}) == ARG, missing
     assert heads(sb=16) == -3 and heads(wsb=16) == -3
-    assert lib.umhs_field_heads_fwd_scratch_bytes(ctypes.byref(cfg), 64) >= 4 * 2 * (3 * 32 + 16) * 4
+    assert lib.umhs_field_heads_fwd_scratch_bytes(ctypes.byref(cfg), 64, 4) >= (4 * 2 * (32 + 16 + 16) + 4 * 16) * 4
+    assert lib.umhs_field_bwd_composited_scratch_bytes(ctypes.byref(cfg), 64, 4) >= (4 * 32 + 4 * 32 + 6 * 31) * 4
     assert lib.umhs_field_bwd_composited_supported(ctypes.byref(cfg)) == 1
     bwdc = lambda **kw: lib.umhs_field_bwd_composited(*[kw.get(k, v) for k, v in dict(
         cfg=ctypes.byref(cfg), params=ctypes.byref(pp), enc=d, sn=2, sl=2 * 64, wpos=d, dirs=d, sel=d, sigma_raw=d, emb=d, es=15, logits=d, n=64,
-        sigma=d, t0=d, t1=d, pinfo=d, R=4, ray=d, weights=d, d_comp=d, d_acc=None, gs=1, d_sigma=d, d_enc=d, grads=ctypes.byref(gp), ws=d,
-        wsb=1 << 30, ready=0, stream=None).items()])
+        sigma=d, t0=d, t1=d, pinfo=d, R=4, ray=d, weights=d, d_comp=d, d_acc=None, gs=1, d_sigma=d, d_enc=d, grads=ctypes.byref(gp), sc=d,
+        scb=1 << 30, ws=d, wsb=1 << 30, ready=0, stream=None).items()])
+    assert bwdc(scb=16) == -3
     for missing in ("params", "enc", "wpos", "dirs", "sel", "sigma_raw", "emb", "logits", "sigma", "t0", "t1", "pinfo", "ray", "weights", "d_comp",
-                    "d_sigma", "grads"):
+                    "d_sigma", "grads", "sc"):
         assert bwdc(**{missing: None}) == ARG, missing
     assert bwdc(ws=None) == -3
     dots = lambda **kw: lib.umhs_composite_bwd_dots(*[kw.get(k, v) for k, v in dict(

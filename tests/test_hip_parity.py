@@ -497,13 +497,12 @@ def test_ray_epilogue_and_fused_loss():
     assert abs(float(l1) - float(torch.nn.functional.mse_loss(spec, gt_s))) < 1e-6
 
 
-@pytest.mark.parametrize("fused", ["0", "1"], ids=["per-sample arrays", "band sums in the field kernels"])
+@pytest.mark.parametrize("fused", ["0", "1"], ids=["per-sample arrays", "per-ray sums in the field kernels"])
 def test_model_train_iteration_matches_oracle_step(fused, monkeypatch):
     """Plugin-surface path (UMHSPipeline.train_iteration): outputs, losses and the parameters after one fused-Adam step -- for both
     forms of the step (composite kernels over [N,B] arrays / two-launch forward + folded compositing backward)."""
     import numpy as np
 
-    monkeypatch.setenv("UMHS_SPLIT_FWD", fused)
     monkeypatch.setenv("UMHS_FUSED_BWD", fused)
     from umhsnerf._ns_compat import packed_ray_samples
     from umhsnerf.umhs_model import UMHSConfig
@@ -650,11 +649,12 @@ def test_field_bwd_overwrites_every_parameter_gradient(C, B, spec):
         assert all(n.startswith("mlp_directional") for n in untouched) and (not spec or not untouched), untouched
 
 
-@pytest.mark.parametrize("C,B,spec", [(6, 31, True), (4, 40, False), (9, 128, True)])
+@pytest.mark.parametrize("C,B,spec", [(6, 31, True), (4, 40, False), (9, 128, True), (4, 141, False)])
 def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
     """umhs_field_base_fwd -> weights -> umhs_field_heads_fwd against umhs_field_fwd + umhs_composite_fwd: per-sample outputs bit for
-    bit (same kernels' arithmetic), per-ray band sums to rounding (another, fixed, summation order), run-to-run identical.  Rays with
-    no samples, rays shorter than a 16-sample tile (several inside one tile), rays across many tiles, N not a multiple of 16."""
+    bit (same kernels' arithmetic), per-ray sums to rounding (another, fixed, summation order; the mixing term summed per ray as w m
+    and multiplied by the endmembers once per ray), run-to-run identical.  Rays with no samples, rays shorter than a 16-sample tile
+    (several inside one tile), rays across many tiles, N not a multiple of 16."""
     ops = _ops()
     _, _, layout, flat, fs = make_case(C, B, spec, 8, 8, log2_T=12)
     g = torch.Generator().manual_seed(B)
@@ -671,7 +671,7 @@ def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
     t0 = torch.rand(n, generator=g).to(DEV)
     t1 = t0 + 0.05
     ref = ops.field_fwd(fs, flat, enc, True, wpos, dirs, sel, want_emb=True, want_logits=True)
-    vals = [ref["spectral"]] + ([ref["spectral2"], ref["specular"]] if spec else [])
+    vals = [ref["spectral"]] + ([ref["spectral2"], ref["specular"]] if spec else []) + [ref["abundances"]]
     w_ref, acc_ref, depth_ref, comp_ref = ops.composite_fwd(ref["sigma"], t0, t1, packed_info, vals)
     base = ops.field_base_fwd(fs, flat, enc, True, sel)
     for k in ("sigma", "sigma_raw", "emb"):
@@ -680,24 +680,22 @@ def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
     assert none == [] and torch.equal(w, w_ref) and torch.equal(acc, acc_ref) and torch.equal(depth, depth_ref)
     runs = []
     for rep in range(2):
-        ho = ops.field_heads_fwd(fs, flat, base["emb"], wpos, dirs, w, ray_idx, packed_info, pack_ready=True, release=False)
-        for k in ("spectral", "abundances", "feat_logits"):
+        ho = ops.field_heads_fwd(fs, flat, base["emb"], wpos, dirs, w, ray_idx, packed_info, pack_ready=True, release=False, want_abundances=True)
+        for k in ("abundances", "feat_logits"):
             assert torch.equal(ho[k], ref[k]), k
-        assert len(ho["comp"]) == len(comp_ref)
-        for i, (a, b) in enumerate(zip(ho["comp"], comp_ref)):
-            assert_close(f"comp[{i}]", a, b, 2e-6)
-        runs.append([c.clone() for c in ho["comp"]])
+        got = ho["comp"] + [ho["comp_abundances"]]
+        assert len(got) == len(comp_ref)
+        for i, (a, b) in enumerate(zip(got, comp_ref)):
+            assert_close(f"comp[{i}]", a, b, 3e-6)
+        runs.append([c.clone() for c in got])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
-    ab_ref = ops.accumulate_fwd(w, ref["abundances"], packed_info)
-    assert_close("per-ray abundances", ho["comp_abundances"], ab_ref, 2e-6)
     # the aligned-row form of the base outputs ([N,16], sigma_raw in slot 0) feeds the same kernel: same bits everywhere
     base16 = ops.field_base_fwd(fs, flat, enc, True, sel, pack_ready=True, rows16=True)
     assert base16["emb"] is None and torch.equal(base16["base16"][:, 1:], ref["emb"]) and torch.equal(base16["base16"][:, 0], ref["sigma_raw"])
-    h2 = ops.field_heads_fwd(fs, flat, base16["base16"], wpos, dirs, w, ray_idx, packed_info, want_spectral=False, want_logits=False,
-                             pack_ready=True, release=False, want_abundances=False)
-    assert h2["spectral"] is None and h2["feat_logits"] is None and h2["abundances"] is None
-    for a, b in zip(h2["comp"] + [h2["comp_abundances"]], runs[0] + [ho["comp_abundances"]]):
+    h2 = ops.field_heads_fwd(fs, flat, base16["base16"], wpos, dirs, w, ray_idx, packed_info, want_logits=False, pack_ready=True, release=False)
+    assert h2["feat_logits"] is None and h2["abundances"] is None
+    for a, b in zip(h2["comp"] + [h2["comp_abundances"]], runs[0]):
         assert torch.equal(a, b)
 
 

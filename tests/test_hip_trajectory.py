@@ -80,7 +80,6 @@ def test_fifty_step_training_trajectory_matches_the_oracle(path, monkeypatch):
     0.05 dB, endmembers 1e-3 absolute.  (The fp32 oracle drifts from its own fp64 run by 4e-5 / 2e-4 dB / 4e-5 over these 50
     steps, so the bounds are ~25x the arithmetic noise floor, not slack for a wrong update rule.)"""
     fused = path.startswith("band sums")
-    monkeypatch.setenv("UMHS_SPLIT_FWD", "1" if fused else "0")
     monkeypatch.setenv("UMHS_FUSED_BWD", "1" if fused else "0")
     R, S, B, C, temp, log2_T, steps = 64, 24, 31, 6, 0.4, 14, 50
     bands = list(np.linspace(400, 700, B))

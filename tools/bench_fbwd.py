@@ -24,6 +24,16 @@ for name in os.environ.get("CASES", "C2,C3,C5").split(","):
     dsig, dspec = torch.rand(N, device=dev), torch.rand(N, B, device=dev)
     dflat = torch.zeros_like(flat)
     fn = lambda: ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, out["sigma_raw"], out["emb"], dsig, dspec, None, dflat, feat_logits=out["feat_logits"])
+    if os.environ.get("FUSED", "0") == "1":  # the folded compositing backward (64-sample rays)
+        R = N // 64
+        pinfo = torch.stack([torch.arange(R, device=dev) * 64, torch.full((R,), 64, device=dev)], 1).contiguous()
+        ray = torch.arange(R, device=dev).repeat_interleave(64).contiguous()
+        t0 = torch.rand(N, device=dev)
+        comp = dict(sigma=out["sigma"], t0=t0, t1=t0 + 0.01, packed_info=pinfo, ray_indices=ray, weights=torch.rand(N, device=dev) * 0.05,
+                    d_comp=torch.randn(R, B, device=dev), d_acc=torch.randn(R, device=dev), grad_scaling=True)
+        b16 = torch.cat([out["sigma_raw"][:, None], out["emb"]], 1).contiguous()
+        fn = lambda: ops.field_bwd(fs, flat, enc, True, wpos, dirs, sel, out["sigma_raw"], b16, None, None, None, dflat, feat_logits=out["feat_logits"],
+                                   comp=dict(comp))
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -34,4 +44,4 @@ for name in os.environ.get("CASES", "C2,C3,C5").split(","):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"{name}: N={N} B={B} C={C} spec={spec} TF={os.environ.get('UMHS_BWD_TF', '1')}: field_bwd {us:8.1f} us = {us * 1e3 / N:.2f} ns/sample", flush=True)
+    print(f"{name}: N={N} B={B} C={C} spec={spec} TF={os.environ.get('UMHS_BWD_TF', '3')} FUSED={os.environ.get('FUSED', '0')}: field_bwd {us:8.1f} us = {us * 1e3 / N:.2f} ns/sample", flush=True)

@@ -208,6 +208,16 @@ __device__ __forceinline__ float xq_sum(float v) {
   a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
+// sum over the 16 lanes of a DPP row (the lanes that share a quarter q), result in every lane: four rotate-and-add steps on the
+// VALU (row_ror 8 / 4 / 2 / 1) -- __shfl_xor compiles to ds_bpermute here, ~100 cycles of LDS latency per step that a kernel at one
+// wave per SIMD cannot hide (part 0 of the backward: +14 us at C2 with four of those per value)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
 __device__ __forceinline__ float sel4(const v4f& v, int r) { return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3])); }
 
 struct FieldIO {
@@ -239,6 +249,8 @@ struct FieldIO {
   float* part;                         // per-16-sample-tile partial sums, see HeadsComp
   float* comp[3];                      // [R,B] band sums of spectral / spectral2 / specular (rays inside one tile are written here directly)
   int n_streams;                       // 1 without the specular head, else 3
+  float* part_m;                       // w m (mixing input): per-tile partials [(g*2 + az)*16 + c]
+  float* mix16;                        // [R,16] per-ray sums of w m (written here for rays strictly inside a tile, else by the finish pass)
   float* part_ab;                      // abundances: per-tile partials [(g*2 + az)*16 + c]
   float* comp_ab;                      // [R,C] per-ray abundance sums (or null)
   float* bo16;                         // density half: the base MLP's 16 outputs as aligned rows [N,16] (slot 0 = sigma_raw), or null
@@ -248,6 +260,9 @@ struct FieldIO {
   // umhs_composite_bwd_dots (mixing half: sum_c m[c] (d_comp E^T)[c], which the kernel's d m accumulator already is; specular half
   // from the sigmoids it computes anyway)
   const float* d_comp;                 // [R,B] gradient w.r.t. the per-ray band sums of spectral
+  const float* mix_g;                  // [R,16] G[r][c] = sum_b d_comp[r][b] E[c][b] (field_mix_grad_kernel): d m_n = ws_n G[ray(n)]
+  float* part_ms;                      // per-tile partials of ws_n m_n [(g*2 + az)*16 + c] (-> dE = (sum_n ws_n m_n)^T d_comp per ray)
+  float* mws16;                        // [R,16] the same sums for rays strictly inside one tile
   const float *t0, *t1;                // [N] sample intervals (gradient scaling by distance), or null
   float* dots;                         // [N]
 };
@@ -645,91 +660,38 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
       relu_to<1, NT>(hdir, d4);
     }
     // ---- per 16-band tile: mixing (K = classes) and specular (K = 16 hidden) -------------------------
-    // HEADS: this lane's four rows (samples 4q..4q+3 of each tile): weight, ray; the tile's first / last ray (wave-uniform)
-    float w4[NT][4];
-    int r4[NT][4], rfirst[NT], rlast[NT];
-    if constexpr (HEADS) {
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) {
-        const int64_t nb0 = tile * TILE + wave * (16 * NT) + ct * 16;  // first sample of the tile
-        const int64_t last = nb0 + 15 < io.n ? nb0 + 15 : io.n - 1;
-        rfirst[ct] = nb0 < io.n ? __builtin_amdgcn_readfirstlane((int)io.ray_of[nb0]) : -1;
-        rlast[ct] = nb0 < io.n ? __builtin_amdgcn_readfirstlane((int)io.ray_of[last]) : -1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t sidx = nb0 + 4 * q + r;
-          const bool v = sidx < io.n;
-          w4[ct][r] = v ? io.weights[sidx] : 0.0f;
-          r4[ct][r] = v ? (int)io.ray_of[sidx] : -2;
-        }
-      }
-    }
+    if constexpr (!HEADS) {
 #pragma unroll 1  // a runtime loop: left alone hipcc unrolls the (small) no-specular body 8x and spills 200+ registers
-    for (int t = 0; t < io.TB; ++t) {
-      // transposed tiles: rows = samples 4q+r of the column tile, lanes&15 = bands 16t..16t+15 -> 64-byte row segments
-      v4f sp[NT][1], sc[NT][1];
-      gemm_pack<1, 4, NT, 1, true>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
-      if (SPEC) gemm_pack<1, 4, NT, 2, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
-      const int b = 16 * t + j;
+      for (int t = 0; t < io.TB; ++t) {
+        // transposed tiles: rows = samples 4q+r of the column tile, lanes&15 = bands 16t..16t+15 -> 64-byte row segments
+        v4f sp[NT][1], sc[NT][1];
+        gemm_pack<1, 4, NT, 1, true>(sp, hs.m, lds + pd.L[L_MX].off_w + t * 256, nullptr, lane);
+        if (SPEC) gemm_pack<1, 4, NT, 2, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+        const int b = 16 * t + j;
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) {
-        const int64_t nb = tile * TILE + wave * (16 * NT) + ct * 16 + 4 * q;  // first sample of this lane's 4 rows
-        float val[3][4];  // spectral, spectral2 (mixing only), specular
+        for (int ct = 0; ct < NT; ++ct) {
+          const int64_t nb = tile * TILE + wave * (16 * NT) + ct * 16 + 4 * q;  // first sample of this lane's 4 rows
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float s1r = SPEC ? __shfl(hs.s1[ct], 4 * q + r, 64) : 0.0f;  // s1 lives on lane&15 = sample
-          const float spec = sp[ct][0][r];
-          const float spl = SPEC ? s1r * sigmoidf_(sc[ct][0][r]) : 0.0f;
-          val[0][r] = SPEC ? spec + spl : spec, val[1][r] = spec, val[2][r] = spl;
+          for (int r = 0; r < 4; ++r) {
+            const float s1r = SPEC ? __shfl(hs.s1[ct], 4 * q + r, 64) : 0.0f;  // s1 lives on lane&15 = sample
 #ifdef UMHS_ABL_NO_STORE
-          if (nb + r < io.n && b < io.B && sp[ct][0][r] == 1.2345e30f) {
+            if (nb + r < io.n && b < io.B && sp[ct][0][r] == 1.2345e30f) {
 #else
-          if (nb + r < io.n && b < io.B) {
+            if (nb + r < io.n && b < io.B) {
 #endif
-            const int64_t o = (nb + r) * io.B + b;
-            if (!HEADS || io.spectral) io.spectral[o] = val[0][r];
-            if (!HEADS && SPEC && io.spectral2) io.spectral2[o] = spec;
-            if (!HEADS && SPEC && io.specular) io.specular[o] = spl;
-          }
-        }
-        if constexpr (HEADS) {
-          const int64_t g = (tile * TILE + wave * (16 * NT) + ct * 16) >> 4;
-          const int NS = SPEC ? 3 : 1, BP = 16 * io.TB;
-          if (rfirst[ct] >= 0) {
-#pragma unroll
-            for (int sidx = 0; sidx < NS; ++sidx) {
-              float a = 0.0f;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) a += (r4[ct][r] == rfirst[ct]) ? w4[ct][r] * val[sidx][r] : 0.0f;
-              a = xq_sum(a);
-              if (q == 0) io.part[((g * 2 + 0) * NS + sidx) * BP + b] = a;
-            }
-            if (rlast[ct] != rfirst[ct]) {  // wave-uniform
-#pragma unroll
-              for (int sidx = 0; sidx < NS; ++sidx) {
-                float z = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z += (r4[ct][r] == rlast[ct]) ? w4[ct][r] * val[sidx][r] : 0.0f;
-                z = xq_sum(z);
-                if (q == 0) io.part[((g * 2 + 1) * NS + sidx) * BP + b] = z;
-              }
-              for (int m = rfirst[ct] + 1; m < rlast[ct]; ++m) {  // rays strictly inside this tile (short rays; rare)
-#pragma unroll
-                for (int sidx = 0; sidx < NS; ++sidx) {
-                  float v = 0.0f;
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v += (r4[ct][r] == m) ? w4[ct][r] * val[sidx][r] : 0.0f;
-                  v = xq_sum(v);
-                  if (q == 0 && b < io.B && io.comp[sidx]) io.comp[sidx][(int64_t)m * io.B + b] = v;
-                }
-              }
+              const float spec = sp[ct][0][r];
+              const float spl = SPEC ? s1r * sigmoidf_(sc[ct][0][r]) : 0.0f;
+              const int64_t o = (nb + r) * io.B + b;
+              io.spectral[o] = SPEC ? spec + spl : spec;
+              if (SPEC && io.spectral2) io.spectral2[o] = spec;
+              if (SPEC && io.specular) io.specular[o] = spl;
             }
           }
         }
       }
+      // ---- per-sample scalars last (conditional stores = branches) -----------------------------------
+      store_density<NT>(io, bo4, nn, ok, q);
     }
-    // ---- per-sample scalars last (conditional stores = branches) -----------------------------------
-    if (!HEADS) store_density<NT>(io, bo4, nn, ok, q);
     if (io.abund) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
@@ -738,42 +700,89 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
           if (ok[ct] && 4 * q + r < io.C) io.abund[nn[ct] * io.C + 4 * q + r] = hs.ab[ct][r];
     }
     if constexpr (HEADS) {
-      // abundances: the fourth stream of the per-ray sums.  Layout here is samples on lanes (lane = (sample j, q), reg r <-> class
-      // 4q+r): the sum over a tile's samples is a reduction over the 16 lanes of a row, masked by the sample's ray.
-      if (io.part_ab) {
+      // Per-ray sums inside the kernel.  The mixing term is linear in m: sum_n w_n (m_n E) = (sum_n w_n m_n) E, so the kernel sums
+      // w_n m_n (16 classes) per ray and the finish pass multiplies by E once per RAY -- no mixing product per sample and band tile at
+      // all; only the specular term (a sigmoid per sample and band) is formed per band tile.  Abundances are a third 16-wide stream.
+      float w4[NT][4], wj[NT];
+      int r4[NT][4], rj[NT], rfirst[NT], rlast[NT];
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-          if (rfirst[ct] < 0) continue;
-          const int64_t nb0 = tile * TILE + wave * (16 * NT) + ct * 16;
-          const int64_t g = nb0 >> 4;
-          const bool vj = nb0 + j < io.n;
-          const float wj = vj ? io.weights[nb0 + j] : 0.0f;
-          const int rj = vj ? (int)io.ray_of[nb0 + j] : -2;
-          auto row_sum = [&](int ray, float (&out)[4]) __attribute__((always_inline)) {
+      for (int ct = 0; ct < NT; ++ct) {
+        const int64_t nb0 = tile * TILE + wave * (16 * NT) + ct * 16;  // first sample of the tile
+        const int64_t last = nb0 + 15 < io.n ? nb0 + 15 : io.n - 1;
+        rfirst[ct] = nb0 < io.n ? __builtin_amdgcn_readfirstlane((int)io.ray_of[nb0]) : -1;
+        rlast[ct] = nb0 < io.n ? __builtin_amdgcn_readfirstlane((int)io.ray_of[last]) : -1;
+        const bool vj = nb0 + j < io.n;
+        wj[ct] = vj ? io.weights[nb0 + j] : 0.0f;  // this lane's sample (samples-on-lanes tiles) ...
+        rj[ct] = vj ? (int)io.ray_of[nb0 + j] : -2;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v = (rj == ray) ? wj * hs.ab[ct][r] : 0.0f;
+        for (int r = 0; r < 4; ++r) {  // ... and the four rows 4q..4q+3 it holds of a transposed band tile
+          w4[ct][r] = __shfl(wj[ct], 4 * q + r, 64);
+          r4[ct][r] = __shfl(rj[ct], 4 * q + r, 64);
+        }
+      }
+      if (SPEC) {
+#pragma unroll 1
+        for (int t = 0; t < io.TB; ++t) {
+          v4f sc[NT][1];
+          gemm_pack<1, 4, NT, 2, true>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
+          const int b = 16 * t + j, BP = 16 * io.TB;
 #pragma unroll
-              for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d, 64);
-              out[r] = v;
-            }
-          };
-          float a[4];
-          row_sum(rfirst[ct], a);
-          if (j == 0) *reinterpret_cast<v4f*>(io.part_ab + (g * 2 + 0) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
-          if (rlast[ct] != rfirst[ct]) {
-            row_sum(rlast[ct], a);
-            if (j == 0) *reinterpret_cast<v4f*>(io.part_ab + (g * 2 + 1) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
-            for (int m = rfirst[ct] + 1; m < rlast[ct]; ++m) {
-              row_sum(m, a);
-              if (j == 0 && io.comp_ab) {
+          for (int ct = 0; ct < NT; ++ct) {
+            if (rfirst[ct] < 0) continue;
+            const int64_t g = (tile * TILE + wave * (16 * NT) + ct * 16) >> 4;
+            float val[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  if (4 * q + r < io.C) io.comp_ab[(int64_t)m * io.C + 4 * q + r] = a[r];
+            for (int r = 0; r < 4; ++r) val[r] = w4[ct][r] * (__shfl(hs.s1[ct], 4 * q + r, 64) * sigmoidf_(sc[ct][0][r]));
+            auto col_sum = [&](int ray) __attribute__((always_inline)) {
+              float a = 0.0f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) a += (r4[ct][r] == ray) ? val[r] : 0.0f;
+              return xq_sum(a);
+            };
+            const float a = col_sum(rfirst[ct]);
+            if (q == 0) io.part[(g * 2 + 0) * BP + b] = a;
+            if (rlast[ct] != rfirst[ct]) {  // wave-uniform
+              const float z = col_sum(rlast[ct]);
+              if (q == 0) io.part[(g * 2 + 1) * BP + b] = z;
+              for (int m = rfirst[ct] + 1; m < rlast[ct]; ++m) {  // rays strictly inside this tile (short rays; rare)
+                const float v = col_sum(m);
+                if (q == 0 && b < io.B) io.comp[2][(int64_t)m * io.B + b] = v;
               }
             }
           }
         }
+      }
+      // the two 16-wide streams (w m and w abundances): samples on lanes (lane = (sample j, q), reg r <-> class 4q+r) -- the sum
+      // over a tile's samples is a reduction over the 16 lanes of a row, masked by the sample's ray
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        if (rfirst[ct] < 0) continue;
+        const int64_t g = (tile * TILE + wave * (16 * NT) + ct * 16) >> 4;
+        auto row_sum = [&](const float(&x)[4], int ray, float(&out)[4]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            out[r] = row_sum16((rj[ct] == ray) ? wj[ct] * x[r] : 0.0f);
+          }
+        };
+        auto stream16 = [&](const float(&x)[4], float* __restrict__ part16, float* __restrict__ direct, int width) __attribute__((always_inline)) {
+          float a[4];
+          row_sum(x, rfirst[ct], a);
+          if (j == 0) *reinterpret_cast<v4f*>(part16 + (g * 2 + 0) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
+          if (rlast[ct] != rfirst[ct]) {
+            row_sum(x, rlast[ct], a);
+            if (j == 0) *reinterpret_cast<v4f*>(part16 + (g * 2 + 1) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
+            for (int m = rfirst[ct] + 1; m < rlast[ct]; ++m) {
+              row_sum(x, m, a);
+              if (j == 0 && direct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (4 * q + r < width) direct[(int64_t)m * width + 4 * q + r] = a[r];
+              }
+            }
+          }
+        };
+        stream16(hs.m[ct], io.part_m, io.mix16, 16);
+        if (io.part_ab) stream16(hs.ab[ct], io.part_ab, io.comp_ab, io.C);
       }
     }
   }
@@ -1914,8 +1923,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     float2 e[PART == 1 ? 4 : 1];
     v4f x0, x1;  // part 0: saved feature logits, -;  part 1: d_fl, d_bo (from part 0)
     float emb[4], dsig, sel, demb[4];
-    float ws;     // FUSED: scale_n * weights[n]
-    int64_t ray;  // FUSED: the sample's ray
+    float ws, tm0, tm1;  // FUSED: weights[n] (scaled by scale_n once the tile is current), the sample's interval
+    int64_t ray;         // FUSED: the sample's ray
   };
   auto fetch = [&](int64_t tile, TileIn& in) {
     int64_t n = tile * 64 + wave * 16 + j;
@@ -1939,13 +1948,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         for (int r = 0; r < 4; ++r) in.emb[r] = (q == 0 && r == 0) ? 0.0f : b4[r];
       }
       in.x0 = *reinterpret_cast<const v4f*>(io.feat_logits_in + n * 16 + 4 * q);
-      if (FUSED) {
-        float sc = 1.0f;
-        if (io.t0) {  // scale_gradients_by_distance_squared: clamp(t_mid^2, 0, 1)
-          const float m = (io.t0[n] + io.t1[n]) / 2.0f;
-          sc = fminf(fmaxf(m * m, 0.0f), 1.0f);
-        }
-        in.ws = ok ? io.weights[n] * sc : 0.0f;
+      if (FUSED) {  // raw loads only: arithmetic on a prefetched value would make the wave wait for it here, a tile too early
+        in.ws = io.weights[n];
+        in.tm0 = io.t0 ? io.t0[n] : 1.0f, in.tm1 = io.t0 ? io.t1[n] : 1.0f;  // (t_mid = 1: scale 1)
         in.ray = io.ray_of[n];
       }
     } else {
@@ -2030,10 +2035,18 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
         for (int r = 0; r < 4; ++r) {
           const int b = 16 * t + 4 * q + r;
           if (FUSED)
-            dall[t][r] = (t < TB && ok && b < B) ? io.d_comp[cur.ray * B + b] : 0.0f;
+            dall[t][r] = (SPEC && t < TB && ok && b < B) ? io.d_comp[cur.ray * B + b] : 0.0f;  // only the specular tail needs the row
           else
             dall[t][r] = (t < TB && ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
         }
+      // FUSED: G[ray][4q .. 4q+3], requested here with the ray index the previous tile's prefetch brought (a load that depends on
+      // another load inside the prefetch stalls the wave for a whole memory latency per tile: +14 us at C2) and consumed after the band loop
+      v4f g4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (FUSED) {
+        g4 = *reinterpret_cast<const v4f*>(io.mix_g + cur.ray * 16 + 4 * q);
+        const float tm = (cur.tm0 + cur.tm1) / 2.0f;  // scale_gradients_by_distance_squared: clamp(t_mid^2, 0, 1)
+        cur.ws = ok ? cur.ws * fminf(fmaxf(tm * tm, 0.0f), 1.0f) : 0.0f;
+      }
       float dotacc = 0.0f;
       // =================== forward recompute: head MLP, directional hidden layer (feature logits come from the forward) ===
 #pragma unroll
@@ -2088,20 +2101,15 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
           float dsp[NT][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) dsp[0][r] = FUSED ? cur.ws * dall[t][r] : dall[t][r];
-          if (FUSED) {
-            // d m accumulates from the UNSCALED ray gradient and is scaled by ws_n after the loop (the product is linear in it):
-            // sum_b d_comp[b] (m E)[b] = sum_c m[c] (d_comp E^T)[c], so the mixing half of the dot product falls out of this
-            // accumulator and spectral's mixing term never has to be recomputed
-            float dcv[NT][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dcv[0][r] = dall[t][r];
-            gemm_pack<1, 4, NT, 0>((t & 1) ? dm4b : dm4, dcv, wT + td.L[T_MX].off + t * 256, nullptr, lane);
-          } else {
+          if (!FUSED) {
+            // (FUSED: d_spectral[n] = ws_n d_comp[ray(n)] is one vector per RAY times a scalar per sample, and the mixing term is
+            // linear -- d m_n = ws_n (d_comp E^T)[ray] and dE = sum_rays (sum_n ws_n m_n)^T d_comp[ray] are formed per ray by
+            // field_mix_grad_kernel / field_mix_dE_kernel, nothing of the mixing term is left per sample and band tile)
             gemm_pack<1, 4, NT, 0>((t & 1) ? dm4b : dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
+            STile dspS[1];
+            dspS[0] = to_swapped<false>(dsp[0], ident);
+            dw_pairs<1, 1>(&acc_[SL::A_MX - A0 + t], dspS, mS);  // dE^T[b][c] += sum_n d_spectral[n][b] m[n][c]
           }
-          STile dspS[1];
-          dspS[0] = to_swapped<false>(dsp[0], ident);
-          dw_pairs<1, 1>(&acc_[SL::A_MX - A0 + t], dspS, mS);  // dE^T[b][c] += sum_n d_spectral[n][b] m[n][c]
           if (SPEC) {
             v4f sc[NT][1];
             gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
@@ -2124,11 +2132,36 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       dm4[0][0] += dm4b[0][0], dhd4[0][0] += dhd4b[0][0];
       if (FUSED) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dotacc += hs.m[0][r] * dm4[0][0][r];  // classes 4q+r (m is zero from class C on)
+        for (int r = 0; r < 4; ++r) dotacc += hs.m[0][r] * g4[r];  // classes 4q+r (m is zero from class C on)
         dotacc = xq_sum(dotacc);
         if (ok && q == 0) io.dots[n] = dotacc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dm4[0][0][r] *= cur.ws;
+        for (int r = 0; r < 4; ++r) dm4[0][0][r] = cur.ws * g4[r];
+        // per-ray sums of ws_n m_n for dE: this 16-sample tile's share of its first / last ray, rays strictly inside written directly
+        const int rayj = (int)cur.ray;
+        const int rf = __builtin_amdgcn_readlane(rayj, 0), rl = __builtin_amdgcn_readlane(rayj, 15);
+        const int64_t g = tile * 4 + wave;
+        auto row_sum = [&](int ray, float(&out)[4]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            out[r] = row_sum16((rayj == ray) ? cur.ws * hs.m[0][r] : 0.0f);
+          }
+        };
+#ifndef UMHS_ABL_NO_MS
+        if (tile * 64 + wave * 16 < io.n) {
+          float a[4];
+          row_sum(rf, a);
+          if (j == 0) *reinterpret_cast<v4f*>(io.part_ms + (g * 2 + 0) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
+          if (rl != rf) {
+            row_sum(rl, a);
+            if (j == 0) *reinterpret_cast<v4f*>(io.part_ms + (g * 2 + 1) * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
+            for (int m = rf + 1; m < rl; ++m) {
+              row_sum(m, a);
+              if (j == 0) *reinterpret_cast<v4f*>(io.mws16 + (int64_t)m * 16 + 4 * q) = v4f{a[0], a[1], a[2], a[3]};
+            }
+          }
+        }
+#endif
       }
       ds1 = xq_sum(ds1);
       // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
@@ -2282,6 +2315,105 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
 }
 #undef TF_GEMM_F
 #undef TF_GEMM_T
+
+// ---- the mixing term of the folded compositing backward, per RAY (umhs_field_bwd_composited) ---------------------------------
+// G[r][c] = sum_b d_comp[r][b] E[c][b]   (c < C, zero above): d m_n = ws_n G[ray(n)]
+__global__ __launch_bounds__(256) void field_mix_grad_kernel(const float* __restrict__ d_comp, const float* __restrict__ E, int64_t R,
+                                                            int B, int C, float* __restrict__ G) {
+  // 16 rays per workgroup: the rays' gradient rows and the endmembers staged in LDS (odd row stride: the 16 class rows a wave reads
+  // sit in 16 banks), thread = (ray, class)
+  extern __shared__ float sm[];
+  const int BS = B | 1;
+  float* sE = sm;             // [16][BS]
+  float* sD = sm + 16 * BS;   // [16][BS]
+  const int tid = threadIdx.x;
+  const int64_t ray0 = (int64_t)blockIdx.x * 16;
+  for (int i = tid; i < 16 * B; i += 256) {
+    const int r = i / B, b = i - r * B;
+    sE[r * BS + b] = r < C ? E[(int64_t)r * B + b] : 0.0f;
+    sD[r * BS + b] = ray0 + r < R ? d_comp[(ray0 + r) * B + b] : 0.0f;
+  }
+  __syncthreads();
+  const int rr = tid >> 4, c = tid & 15;
+  float a0 = 0.0f, a1 = 0.0f;
+  int b = 0;
+  for (; b + 1 < B; b += 2) a0 += sD[rr * BS + b] * sE[c * BS + b], a1 += sD[rr * BS + b + 1] * sE[c * BS + b + 1];
+  if (b < B) a0 += sD[rr * BS + b] * sE[c * BS + b];
+  if (ray0 + rr < R) G[(ray0 + rr) * 16 + c] = a0 + a1;
+}
+// dE[c][b] = sum_r M[r][c] d_comp[r][b] with M[r][c] = sum over the samples of ray r of ws_n m_n[c] (finished here from part 0's tile
+// partials, as field_heads_finish_kernel does).  Stage 1: one workgroup per 32 rays -> partial[chunk][c][b]; stage 2 adds the chunks.
+constexpr int MIX_CHUNK = 32;
+__global__ __launch_bounds__(256) void field_mix_dE_kernel(const float* __restrict__ part_ms, const float* __restrict__ mws16,
+                                                          const int64_t* __restrict__ ray_of, const int64_t* __restrict__ pinfo,
+                                                          int64_t n, int64_t R, const float* __restrict__ d_comp, int B, int C,
+                                                          float* __restrict__ partial) {
+  __shared__ float sM[MIX_CHUNK][16];
+  const int tid = threadIdx.x;
+  const int64_t ray0 = (int64_t)blockIdx.x * MIX_CHUNK;
+  {
+    const int64_t ray = ray0 + (tid >> 3);
+    const int c0 = 2 * (tid & 7);
+    float acc[2] = {0.0f, 0.0f};
+    if (ray < R) {
+      const int64_t s0 = pinfo[2 * ray], cnt = pinfo[2 * ray + 1];
+      if (cnt > 0) {
+        const int64_t ts = s0 >> 4, te = (s0 + cnt - 1) >> 4;
+        const bool first = ray_of[16 * ts] == ray;
+        bool inside = false;
+        if (ts == te) {
+          const int64_t l = 16 * ts + 15 < n ? 16 * ts + 15 : n - 1;
+          inside = !first && ray_of[l] != ray;
+        }
+        if (inside) {
+          acc[0] = mws16[ray * 16 + c0], acc[1] = mws16[ray * 16 + c0 + 1];
+        } else {
+          for (int64_t t = ts; t <= te; ++t) {
+            const float2 v = *reinterpret_cast<const float2*>(part_ms + (t * 2 + ((t == ts && !first) ? 1 : 0)) * 16 + c0);
+            acc[0] += v.x, acc[1] += v.y;
+          }
+        }
+      }
+    }
+    sM[tid >> 3][c0] = acc[0], sM[tid >> 3][c0 + 1] = acc[1];
+  }
+  __syncthreads();
+  const int nr = (int)(R - ray0 < MIX_CHUNK ? R - ray0 : MIX_CHUNK);
+  for (int i = tid; i < C * B; i += 256) {
+    const int c = i / B, b = i - c * B;
+    float a0 = 0.0f, a1 = 0.0f;
+    int rr = 0;
+    for (; rr + 1 < nr; rr += 2) {
+      a0 += sM[rr][c] * d_comp[(ray0 + rr) * B + b];
+      a1 += sM[rr + 1][c] * d_comp[(ray0 + rr + 1) * B + b];
+    }
+    if (rr < nr) a0 += sM[rr][c] * d_comp[(ray0 + rr) * B + b];
+    partial[(size_t)blockIdx.x * C * B + i] = a0 + a1;
+  }
+}
+__global__ __launch_bounds__(1024) void field_mix_dE_sum_kernel(const float* __restrict__ partial, int nchunks, int CB,
+                                                               float* __restrict__ dE) {
+  // 64 outputs per workgroup, 16 waves each adding a sixteenth of the chunks (in chunk order), then one fixed-order sum
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
+  const int per = (nchunks + 15) / 16, k0 = pw * per, k1 = min(nchunks, k0 + per);
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  if (i < CB) {
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      a0 += partial[(size_t)k * CB + i], a1 += partial[(size_t)(k + 1) * CB + i];
+      a2 += partial[(size_t)(k + 2) * CB + i], a3 += partial[(size_t)(k + 3) * CB + i];
+    }
+    for (; k < k1; ++k) a0 += partial[(size_t)k * CB + i];
+  }
+  part[pw][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (pw != 0 || i >= CB) return;
+  float sacc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) sacc += (part[k][lane] + part[k + 1][lane]) + (part[k + 2][lane] + part[k + 3][lane]);
+  dE[i] = sacc;
+}
 
 struct GradPtrs {
   float* W[NLAYERS];
@@ -2765,57 +2897,104 @@ extern "C" int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_p
   return UMHS_OK;
 }
 
-// Adds the tile partials of umhs_field_heads_fwd ray by ray (see field_fwd_kernel, HEADS): one workgroup per ray, threads over
-// (stream, band), tiles in order.
-__global__ __launch_bounds__(256) void field_heads_finish_kernel(const float* __restrict__ part, const int64_t* __restrict__ ray_of,
-                                                                const int64_t* __restrict__ pinfo, int64_t n, int B, int BP, int NS,
-                                                                float* __restrict__ c0, float* __restrict__ c1,
-                                                                float* __restrict__ c2, const float* __restrict__ part_ab, int C,
-                                                                float* __restrict__ cab) {
-  const int64_t ray = blockIdx.x;
-  const int64_t s0 = pinfo[2 * ray], cnt = pinfo[2 * ray + 1];
-  const int64_t ts = s0 >> 4, te = cnt > 0 ? (s0 + cnt - 1) >> 4 : ts - 1;
-  if (cnt > 0 && ts == te) {  // inside one tile: its first or last ray (-> A / Z), or strictly inside (-> the heads kernel wrote it)
-    const int64_t l = 16 * ts + 15 < n ? 16 * ts + 15 : n - 1;
-    if (ray_of[16 * ts] != ray && ray_of[l] != ray) return;
+// Finishes the per-ray sums of umhs_field_heads_fwd (see field_fwd_kernel, HEADS): one workgroup per ray.  Adds the ray's tile
+// partials in tile order (only its first tile can hold it as that tile's LAST ray, every later tile starts with it; a ray strictly
+// inside one tile was written by the heads kernel), then mixes once per ray: spectral2[b] = sum_c (sum_n w_n m_n[c]) E[c][b].
+__global__ __launch_bounds__(256) void field_heads_finish_kernel(const float* __restrict__ part_spec, const float* __restrict__ part_m,
+                                                                const float* __restrict__ part_ab, const int64_t* __restrict__ ray_of,
+                                                                const int64_t* __restrict__ pinfo, int64_t n, int64_t R, int B, int BP,
+                                                                int C, const float* __restrict__ E, float* __restrict__ mix16,
+                                                                float* __restrict__ c_spectral, float* __restrict__ c_mix,
+                                                                float* __restrict__ c_specular, float* __restrict__ cab) {
+  // four rays per workgroup (one wave each): four independent chains of dependent loads in flight instead of one
+  __shared__ float sM[4][16];
+  const int tid = threadIdx.x, sub = tid >> 6, lane = tid & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + sub;
+  const bool live = ray < R;
+  int64_t ts = 0, te = -1;
+  bool inside = false;  // strictly inside one tile: the heads kernel wrote this ray's sums itself
+  int az0 = 0;
+  if (live) {
+    const int64_t s0 = pinfo[2 * ray], cnt = pinfo[2 * ray + 1];
+    ts = s0 >> 4, te = cnt > 0 ? (s0 + cnt - 1) >> 4 : ts - 1;
+    if (cnt > 0) {
+      const bool first = ray_of[16 * ts] == ray;
+      if (ts == te) {
+        const int64_t l = 16 * ts + 15 < n ? 16 * ts + 15 : n - 1;
+        inside = !first && ray_of[l] != ray;
+      }
+      az0 = first ? 0 : 1;
+    }
   }
-  // only the ray's first tile can hold it as its LAST ray (Z); every later tile starts with it (A)
-  const int az0 = (cnt > 0 && ray_of[16 * ts] != ray) ? 1 : 0;
-  for (int i = threadIdx.x; i < NS * B; i += 256) {
-    const int sidx = i / B, b = i - sidx * B;
+  if (live && lane < 16) {
     float acc = 0.0f;
-    for (int64_t t = ts; t <= te; ++t) acc += part[((t * 2 + (t == ts ? az0 : 0)) * NS + sidx) * BP + b];
-    float* const c = sidx == 0 ? c0 : (sidx == 1 ? c1 : c2);
-    if (c) c[ray * B + b] = acc;
+    if (inside) {
+      acc = mix16[ray * 16 + lane];
+    } else {
+      for (int64_t t = ts; t <= te; ++t) acc += part_m[(t * 2 + (t == ts ? az0 : 0)) * 16 + lane];
+      mix16[ray * 16 + lane] = acc;
+    }
+    sM[sub][lane] = lane < C ? acc : 0.0f;
+  } else if (live && lane < 32 && cab && !inside && lane - 16 < C) {
+    float acc = 0.0f;
+    for (int64_t t = ts; t <= te; ++t) acc += part_ab[(t * 2 + (t == ts ? az0 : 0)) * 16 + (lane - 16)];
+    cab[ray * C + (lane - 16)] = acc;
   }
-  if (cab && threadIdx.x < C) {
-    float acc = 0.0f;
-    for (int64_t t = ts; t <= te; ++t) acc += part_ab[(t * 2 + (t == ts ? az0 : 0)) * 16 + threadIdx.x];
-    cab[ray * C + threadIdx.x] = acc;
+  __syncthreads();
+  if (!live) return;
+  for (int b = lane; b < B; b += 64) {
+    float mix = 0.0f;
+    for (int c = 0; c < C; ++c) mix += sM[sub][c] * E[(int64_t)c * B + b];
+    if (part_spec) {  // specular head: spectral = mixing + specular
+      float sp = 0.0f;
+      if (inside) {
+        sp = c_specular[ray * B + b];
+      } else {
+        for (int64_t t = ts; t <= te; ++t) sp += part_spec[(t * 2 + (t == ts ? az0 : 0)) * BP + b];
+        c_specular[ray * B + b] = sp;
+      }
+      c_mix[ray * B + b] = mix;
+      c_spectral[ray * B + b] = mix + sp;
+    } else {
+      c_spectral[ray * B + b] = mix;
+    }
   }
 }
 
-extern "C" size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n) {
-  if (check_cfg(cfg) || cfg->density_only || n <= 0) return 0;
-  const int TB = (cfg->n_bands + 15) / 16, NS = cfg->pred_specular ? 3 : 1;
-  return (size_t)((n + 15) / 16) * 2 * (NS * 16 * TB + 16) * sizeof(float) + 256;  // band streams, then the abundance partials
+// scratch of umhs_field_heads_fwd: [specular partials G*2*BP (specular head only)][w m partials G*2*16][abundance partials G*2*16]
+// [mix16 R*16], G = ceil(n / 16) tiles
+static size_t heads_scratch_floats(const umhs_field_cfg* cfg, int64_t n, int64_t n_rays, size_t (&off)[4]) {
+  const size_t G = (size_t)((n + 15) / 16), BP = 16 * (size_t)((cfg->n_bands + 15) / 16);
+  off[0] = 0;
+  off[1] = off[0] + (cfg->pred_specular ? G * 2 * BP : 0);
+  off[2] = off[1] + G * 2 * 16;
+  off[3] = off[2] + G * 2 * 16;
+  return off[3] + (size_t)n_rays * 16;
+}
+extern "C" size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n, int64_t n_rays) {
+  if (check_cfg(cfg) || cfg->density_only || n < 0 || n_rays < 0) return 0;
+  size_t off[4];
+  return heads_scratch_floats(cfg, n, n_rays, off) * sizeof(float) + 256;
 }
 
-// umhs_field_heads_fwd: everything after mlp_base from its saved outputs emb [N,15], with the per-ray band sums
-// comp_*[r][b] = sum over the samples n of ray r of weights[n] * stream[n][b] formed inside the kernel; spectral [N,B] (per sample) is
-// written only when given.  ray_indices [N] non-decreasing, packed_info [R,2] = (first sample, count) as umhs_pack_info makes them.
+// umhs_field_heads_fwd: everything after mlp_base from its saved outputs (emb [N,15] or the aligned [N,16] rows), with the per-ray
+// sums comp_*[r] = sum over the samples n of ray r of weights[n] * stream[n] formed inside the kernel + the finish pass.  No [N,B]
+// array exists: the mixing term is summed per ray as w m (16 classes) and multiplied by the endmembers once per ray, the specular
+// term per band tile.  ray_indices [N] non-decreasing, packed_info [R,2] = (first sample, count) as umhs_pack_info makes them.
 extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* emb, int emb_stride,
                                     const float* world_pos, const float* directions, int64_t n, const float* weights,
-                                    const int64_t* ray_indices, const int64_t* packed_info, int64_t n_rays, float* spectral,
-                                    float* abundances, float* feat_logits, float* comp_spectral, float* comp_spectral2,
-                                    float* comp_specular, float* comp_abundances, void* scratch, size_t scratch_bytes, void* workspace,
+                                    const int64_t* ray_indices, const int64_t* packed_info, int64_t n_rays, float* abundances,
+                                    float* feat_logits, float* comp_spectral, float* comp_spectral2, float* comp_specular,
+                                    float* comp_abundances, void* scratch, size_t scratch_bytes, void* workspace,
                                     size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
   const bool spec = cfg->pred_specular != 0;
-  if (!params || !workspace || n < 0 || n_rays < 0 || !packed_info || !comp_spectral) return UMHS_ERR_ARG;
-  if (n > 0 && (!emb || !world_pos || !weights || !ray_indices || !scratch || (spec && !directions))) return UMHS_ERR_ARG;
+  if (!params || !params->endmembers || !workspace || n < 0 || n_rays < 0 || !packed_info || !comp_spectral || !scratch)
+    return UMHS_ERR_ARG;
+  if (spec && (!comp_spectral2 || !comp_specular)) return UMHS_ERR_ARG;
+  if (n > 0 && (!emb || !world_pos || !weights || !ray_indices || (spec && !directions))) return UMHS_ERR_ARG;
   if ((emb_stride != 15 && emb_stride != 16) || (emb_stride == 16 && ((uintptr_t)emb & 15))) return UMHS_ERR_ARG;
   if (n_rays == 0) return UMHS_OK;
   PackDesc pd;
@@ -2823,24 +3002,27 @@ extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_
   rc = build_pack_desc(cfg, params, &pd, &TB);
   if (rc) return rc;
   if (workspace_bytes < fwd_ws_need(pd, false)) return UMHS_ERR_WORKSPACE;
-  if (n > 0 && (scratch_bytes < umhs_field_heads_fwd_scratch_bytes(cfg, n) || ((uintptr_t)scratch & 15))) return UMHS_ERR_WORKSPACE;
+  if (scratch_bytes < umhs_field_heads_fwd_scratch_bytes(cfg, n, n_rays) || ((uintptr_t)scratch & 15)) return UMHS_ERR_WORKSPACE;
   float* img = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   if (!pack_ready) {
     launch_fwd_packs(pd, false, img, stream);
     UMHS_CHECK_LAUNCH();
   }
-  const int NS = spec ? 3 : 1;
+  size_t off[4];
+  heads_scratch_floats(cfg, n, n_rays, off);
+  float* const sc = reinterpret_cast<float*>(scratch);
+  float *part_spec = spec ? sc + off[0] : nullptr, *part_m = sc + off[1], *part_ab = sc + off[2], *mix16 = sc + off[3];
   if (n > 0) {
     FwdBfPlan fp;
     if (!fwd_bf_plan(pd, &fp)) return UMHS_ERR_UNSUPPORTED;
     fp.args.bf_image = img + ((pd.total + 63) & ~63);
     FieldIO io = {};
     io.wpos = world_pos, io.dirs = directions, io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB;
-    io.temperature = cfg->temperature, io.emb_in = emb, io.spectral = spectral, io.abund = abundances, io.feat_logits = feat_logits;
+    io.temperature = cfg->temperature, io.emb_in = emb, io.abund = abundances, io.feat_logits = feat_logits;
     if (emb_stride == 16) io.bo16_in = emb;
-    io.weights = weights, io.ray_of = ray_indices, io.part = reinterpret_cast<float*>(scratch);
-    io.part_ab = comp_abundances ? io.part + (size_t)((n + 15) / 16) * 2 * NS * 16 * TB : nullptr, io.comp_ab = comp_abundances;
-    io.comp[0] = comp_spectral, io.comp[1] = comp_spectral2, io.comp[2] = comp_specular, io.n_streams = NS;
+    io.weights = weights, io.ray_of = ray_indices, io.part = part_spec, io.part_m = part_m, io.mix16 = mix16;
+    io.part_ab = comp_abundances ? part_ab : nullptr, io.comp_ab = comp_abundances;
+    io.comp[0] = comp_spectral, io.comp[1] = comp_spectral2, io.comp[2] = comp_specular, io.n_streams = spec ? 3 : 1;
     const int64_t ntiles = (n + 255) / 256;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     if (spec) {
@@ -2856,10 +3038,9 @@ extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_
     }
     UMHS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(field_heads_finish_kernel, dim3((unsigned)n_rays), dim3(256), 0, umhs_s(stream),
-                     reinterpret_cast<const float*>(scratch), ray_indices, packed_info, n, cfg->n_bands, 16 * TB, NS, comp_spectral,
-                     spec ? comp_spectral2 : nullptr, spec ? comp_specular : nullptr,
-                     reinterpret_cast<const float*>(scratch) + (size_t)((n + 15) / 16) * 2 * NS * 16 * TB, cfg->n_classes, comp_abundances);
+  hipLaunchKernelGGL(field_heads_finish_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, umhs_s(stream), (const float*)part_spec,
+                     (const float*)part_m, (const float*)part_ab, ray_indices, packed_info, n, n_rays, cfg->n_bands, 16 * TB, cfg->n_classes,
+                     params->endmembers, mix16, comp_spectral, comp_spectral2, comp_specular, comp_abundances);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
@@ -3179,6 +3360,11 @@ struct BwdComp {
   int grad_scaling;
   float *d_sigma, *dots;
   bool emb16;  // emb is the aligned [N,16] form umhs_field_base_fwd writes (slot 0 = sigma_raw)
+  // per-ray mixing term: scratch [G R*16][part_ms tiles*2*16][mws16 R*16][dE partials chunks*C*B]
+  float *mix_g, *part_ms, *mws16, *dE_part;
+  const float* E;  // endmembers [C][B]
+  float* dE;       // their gradient
+  int B, C;
 };
 
 template <int TBMAX>
@@ -3195,13 +3381,19 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
                        part[P_].pd, part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, bfimg, part[P_].seg_b,  \
                        part[P_].bf_off, part[P_].bo, slabs);                                                                      \
   } while (0)
-#define LAUNCH_TF_P(P_, FU_)                 \
-  do {                                       \
-    if (spec) {                              \
-      if (bf_mask >> P_ & 1)                 \
-        LAUNCH_TF(P_, true, true, FU_);      \
-      else                                   \
-        LAUNCH_TF(P_, true, false, FU_);     \
+  // (part 0 with the specular head above 128 bands: its bf16x3 variants spill into scratch -- never selected by default -- and the
+  // 256-band one crashes this hipcc's "Rewrite AGPR-Copy-MFMA" pass outright: not instantiated, the fp32 chain serves)
+#define LAUNCH_TF_P(P_, FU_)                                          \
+  do {                                                                \
+    if (spec) {                                                       \
+      if constexpr (P_ == 0 && TBMAX > 8) {                           \
+        LAUNCH_TF(P_, true, false, FU_);                              \
+      } else {                                                        \
+        if (bf_mask >> P_ & 1)                                        \
+          LAUNCH_TF(P_, true, true, FU_);                             \
+        else                                                          \
+          LAUNCH_TF(P_, true, false, FU_);                            \
+      }                                                               \
     } else {                                 \
       if (bf_mask >> P_ & 1)                 \
         LAUNCH_TF(P_, false, true, FU_);     \
@@ -3210,6 +3402,8 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
     }                                        \
   } while (0)
   if (bc) {
+    hipLaunchKernelGGL(field_mix_grad_kernel, dim3((unsigned)((bc->n_rays + 15) / 16)), dim3(256), (size_t)32 * (bc->B | 1) * 4,
+                       umhs_s(stream), bc->d_comp, bc->E, bc->n_rays, bc->B, bc->C, bc->mix_g);
     LAUNCH_TF_P(0, true);
     UMHS_CHECK_LAUNCH();
     rc = umhs_composite_bwd_dots(bc->sigma, bc->t0, bc->t1, bc->packed_info, bc->n_rays, n, bc->weights, bc->dots, bc->d_acc,
@@ -3225,9 +3419,19 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
   TfMap mp;
   fill_tf_map<TBMAX>(&mp, spec, pl.TB);
   const int items = SL::NACC * 256 + SL::NDB * 16;
+  if (bc)  // the endmember gradient comes from the per-ray pass below, not from the slabs
+    for (int t = 0; t < TBMAX; ++t) mp.layer[SL::A_MX + t] = -1;
   hipLaunchKernelGGL(field_reduce_tf_kernel, dim3((items + 63) / 64), dim3(1024), 0, umhs_s(stream), (const float*)slabs, (int)grid, mp,
                      pl.pd_all, gp);
   UMHS_CHECK_LAUNCH();
+  if (bc && bc->dE) {
+    const int nchunks = (int)((bc->n_rays + MIX_CHUNK - 1) / MIX_CHUNK), CB = bc->C * bc->B;
+    hipLaunchKernelGGL(field_mix_dE_kernel, dim3((unsigned)nchunks), dim3(256), 0, umhs_s(stream), (const float*)bc->part_ms,
+                       (const float*)bc->mws16, bc->ray_of, bc->packed_info, n, bc->n_rays, bc->d_comp, bc->B, bc->C, bc->dE_part);
+    hipLaunchKernelGGL(field_mix_dE_sum_kernel, dim3((unsigned)((CB + 63) / 64)), dim3(1024), 0, umhs_s(stream),
+                       (const float*)bc->dE_part, nchunks, CB, bc->dE);
+    UMHS_CHECK_LAUNCH();
+  }
   return UMHS_OK;
 }
 
@@ -3350,6 +3554,8 @@ static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* par
       if (bc) {
         bc->dots = d_bo2;  // [N] of the (unused here) second hand-off buffer
         io.weights = bc->weights, io.ray_of = bc->ray_of, io.d_comp = bc->d_comp, io.dots = bc->dots;
+        io.mix_g = bc->mix_g, io.part_ms = bc->part_ms, io.mws16 = bc->mws16;
+        bc->E = params->endmembers, bc->dE = grads->endmembers, bc->B = cfg->n_bands, bc->C = cfg->n_classes;
         if (bc->emb16) io.bo16_in = emb;
         io.t0 = bc->grad_scaling ? bc->t0 : nullptr, io.t1 = bc->grad_scaling ? bc->t1 : nullptr;
       }
@@ -3454,6 +3660,12 @@ extern "C" int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg) {
   return tf_part(pl, 0, false, &part) && tf_part(pl, 1, false, &part) ? 1 : 0;
 }
 
+extern "C" size_t umhs_field_bwd_composited_scratch_bytes(const umhs_field_cfg* cfg, int64_t n, int64_t n_rays) {
+  if (check_cfg(cfg) || cfg->density_only || n < 0 || n_rays < 0) return 0;
+  const size_t G = (size_t)((n + 15) / 16), chunks = (size_t)((n_rays + 31) / 32);
+  return ((size_t)n_rays * 32 + G * 32 + chunks * cfg->n_classes * cfg->n_bands) * sizeof(float) + 256;
+}
+
 // umhs_field_bwd with the value half of the compositing backward folded in (training step after umhs_field_heads_fwd): instead of
 // d_spectral [N,B] it takes the gradient of the per-ray band sums d_comp_spectral [R,B] (+ d_accumulation [R]) and what the
 // renderer knows -- sigma, intervals, packed_info, ray_indices, weights -- and returns d_sigma [N] besides everything umhs_field_bwd
@@ -3466,9 +3678,17 @@ extern "C" int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_f
                                          const float* feat_logits, int64_t n, const float* sigma, const float* t_starts, const float* t_ends,
                                          const int64_t* packed_info, int64_t n_rays, const int64_t* ray_indices, const float* weights,
                                          const float* d_comp_spectral, const float* d_accumulation, int grad_scaling, float* d_sigma,
-                                         float* d_enc, const umhs_field_grads* grads, void* workspace, size_t workspace_bytes,
-                                         int packs_ready, umhs_stream_t stream) {
+                                         float* d_enc, const umhs_field_grads* grads, void* scratch, size_t scratch_bytes,
+                                         void* workspace, size_t workspace_bytes, int packs_ready, umhs_stream_t stream) {
+  if (!cfg || n < 0 || n_rays < 0 || !scratch || ((uintptr_t)scratch & 15)) return UMHS_ERR_ARG;
+  if (scratch_bytes < umhs_field_bwd_composited_scratch_bytes(cfg, n, n_rays)) return UMHS_ERR_WORKSPACE;
   BwdComp bc = {};
+  {
+    float* sc = reinterpret_cast<float*>(scratch);
+    const size_t G = (size_t)((n + 15) / 16);
+    bc.mix_g = sc, bc.part_ms = bc.mix_g + (size_t)n_rays * 16, bc.mws16 = bc.part_ms + G * 2 * 16;
+    bc.dE_part = bc.mws16 + (size_t)n_rays * 16;
+  }
   bc.sigma = sigma, bc.t0 = t_starts, bc.t1 = t_ends, bc.weights = weights, bc.d_comp = d_comp_spectral, bc.d_acc = d_accumulation;
   bc.packed_info = packed_info, bc.ray_of = ray_indices, bc.n_rays = n_rays, bc.grad_scaling = grad_scaling, bc.d_sigma = d_sigma;
   if ((emb_stride != 15 && emb_stride != 16) || (emb_stride == 16 && ((uintptr_t)emb & 15))) return UMHS_ERR_ARG;

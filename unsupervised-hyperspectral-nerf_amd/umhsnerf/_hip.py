@@ -65,8 +65,8 @@ SIGNATURES = {
     "umhs_field_fwd_prepare": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, C.c_size_t, _vp]),
     "umhs_field_base_fwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                      C.c_size_t, C.c_int, _vp]),
-    "umhs_field_heads_fwd_scratch_bytes": (C.c_size_t, [C.POINTER(FieldCfg), _i64]),
-    "umhs_field_heads_fwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _i64] + [_vp] * 7
+    "umhs_field_heads_fwd_scratch_bytes": (C.c_size_t, [C.POINTER(FieldCfg), _i64, _i64]),
+    "umhs_field_heads_fwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _i64] + [_vp] * 6
                              + [_vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp]),
     "umhs_field_bwd_prepare": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, C.c_size_t, _vp]),
     "umhs_hashgrid_bwd_prepare": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
@@ -78,9 +78,10 @@ SIGNATURES = {
     "umhs_field_bwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                  _vp, _vp, _vp, _vp, C.POINTER(FieldGrads), _vp, C.c_size_t, C.c_int, _vp]),
     "umhs_field_bwd_composited_supported": (C.c_int, [C.POINTER(FieldCfg)]),
+    "umhs_field_bwd_composited_scratch_bytes": (C.c_size_t, [C.POINTER(FieldCfg), _i64, _i64]),
     "umhs_field_bwd_composited": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64,
                                             _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.POINTER(FieldGrads), _vp,
-                                            C.c_size_t, C.c_int, _vp]),
+                                            C.c_size_t, _vp, C.c_size_t, C.c_int, _vp]),
     "umhs_composite_bwd_dots": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "umhs_pack_info": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "umhs_composite_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.POINTER(ValueStreams), _vp, _vp, _vp, _vp]),

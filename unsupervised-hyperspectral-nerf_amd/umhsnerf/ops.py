@@ -312,15 +312,25 @@ def field_base_fwd(spec: FieldSpec, flat, enc, level_major, sel, pack_ready=Fals
     return o
 
 
-_heads_scratch: Dict[int, torch.Tensor] = {}
+_step_scratch: Dict[Tuple[int, str], torch.Tensor] = {}
 
 
-def field_heads_fwd(spec: FieldSpec, flat, emb, wpos, dirs, weights, ray_indices, packed_info, want_spectral=True, want_logits=True,
-                    pack_ready=True, release=True, want_abundances=True):
-    """Second launch of the two-launch training forward: heads + band tiles from ``emb`` ([N,15], or the [N,16] aligned rows of
-    field_base_fwd(rows16=True)), per-ray sums formed in the kernel.
-    -> {"spectral" [N,B] | None, "abundances" [N,C] | None, "feat_logits" [N,16] | None, "comp": [spectral, spectral2, specular] ([R,B]),
-        "comp_abundances" [R,C]}.
+def _scratch(dev, key: str, nbytes: int) -> torch.Tensor:
+    """Grow-only per-device scratch of the two-launch step (tile partials, per-ray sums); contents are dead after each call."""
+    k = (dev.index or 0, key)
+    sc = _step_scratch.get(k)
+    if sc is None or sc.numel() < nbytes:
+        sc = _step_scratch[k] = torch.empty(max(nbytes, 1 << 16), device=dev, dtype=torch.uint8)
+    return sc
+
+
+def field_heads_fwd(spec: FieldSpec, flat, emb, wpos, dirs, weights, ray_indices, packed_info, want_logits=True, pack_ready=True,
+                    release=True, want_abundances=False):
+    """Second launch of the two-launch training forward: heads from ``emb`` ([N,15], or the [N,16] aligned rows of
+    field_base_fwd(rows16=True)) with the per-ray sums formed in the kernel; no [N,B] array is written (the mixing term is summed
+    per ray as w m and multiplied by the endmembers once per ray).
+    -> {"abundances" [N,C] | None, "feat_logits" [N,16] | None, "comp": [spectral, spectral2, specular] ([R,B]; one entry without the
+        specular head), "comp_abundances" [R,C]}.
     ``pack_ready``: the images field_fwd_prepare / field_base_fwd left in the forward workspace are reused."""
     n, dev, L = emb.shape[0], emb.device, spec.layout
     R = packed_info.shape[0]
@@ -328,17 +338,14 @@ def field_heads_fwd(spec: FieldSpec, flat, emb, wpos, dirs, weights, ray_indices
     pp = L.c_struct(flat, _hip.FieldParams)
     new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
     B = L.wavelengths
-    o = dict(spectral=new(n, B) if want_spectral else None, abundances=new(n, L.num_classes) if want_abundances else None,
-             feat_logits=new(n, 16) if want_logits else None, comp_abundances=new(R, L.num_classes))
+    o = dict(abundances=new(n, L.num_classes) if want_abundances else None, feat_logits=new(n, 16) if want_logits else None,
+             comp_abundances=new(R, L.num_classes))
     comp = [new(R, B)] + ([new(R, B), new(R, B)] if L.pred_specular else [])
-    need = _hip.lib().umhs_field_heads_fwd_scratch_bytes(C.byref(cfg), max(n, 1))
-    sc = _heads_scratch.get(dev.index or 0)
-    if sc is None or sc.numel() < need:
-        sc = _heads_scratch[dev.index or 0] = torch.empty(need, device=dev, dtype=torch.uint8)
+    sc = _scratch(dev, "heads_fwd", _hip.lib().umhs_field_heads_fwd_scratch_bytes(C.byref(cfg), n, R))
     ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
     _hip.check(_hip.lib().umhs_field_heads_fwd(C.byref(cfg), C.byref(pp), ptr(emb), emb.shape[1], ptr(wpos), ptr(dirs), n, ptr(weights),
-                                               ptr(ray_indices), ptr(packed_info), R, ptr(o["spectral"]), ptr(o["abundances"]),
-                                               ptr(o["feat_logits"]), ptr(comp[0]), ptr(comp[1]) if len(comp) > 1 else None,
+                                               ptr(ray_indices), ptr(packed_info), R, ptr(o["abundances"]), ptr(o["feat_logits"]),
+                                               ptr(comp[0]), ptr(comp[1]) if len(comp) > 1 else None,
                                                ptr(comp[2]) if len(comp) > 1 else None, ptr(o["comp_abundances"]), ptr(sc), sc.numel(), ptr(ws),
                                                ws.numel(), int(pack_ready), _hip.stream()), "umhs_field_heads_fwd")
     if pack_ready and release:
@@ -422,11 +429,12 @@ def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_ra
     if comp is not None:
         comp["d_sigma"] = torch.empty(n, device=sel.device, dtype=torch.float32)
         pi = comp["packed_info"]
+        sc = _scratch(sel.device, "bwd_comp", _hip.lib().umhs_field_bwd_composited_scratch_bytes(C.byref(cfg), n, pi.shape[0]))
         _hip.check(_hip.lib().umhs_field_bwd_composited(
             C.byref(cfg), C.byref(pp), ptr(enc), sn, sl, ptr(wpos), ptr(dirs), ptr(sel), ptr(sigma_raw), ptr(emb), emb.shape[1], ptr(feat_logits), n,
             ptr(comp["sigma"]), ptr(comp["t0"]), ptr(comp["t1"]), ptr(pi), pi.shape[0], ptr(comp["ray_indices"]), ptr(comp["weights"]),
-            ptr(comp["d_comp"]), ptr(comp["d_acc"]), int(bool(comp["grad_scaling"])), ptr(comp["d_sigma"]), ptr(d_enc), C.byref(gp), ptr(ws),
-            ws.numel(), int(packs_ready), _hip.stream()), "umhs_field_bwd_composited")
+            ptr(comp["d_comp"]), ptr(comp["d_acc"]), int(bool(comp["grad_scaling"])), ptr(comp["d_sigma"]), ptr(d_enc), C.byref(gp), ptr(sc),
+            sc.numel(), ptr(ws), ws.numel(), int(packs_ready), _hip.stream()), "umhs_field_bwd_composited")
         if packs_ready:
             _release(sel.device, WS_FIELD_BWD)
         return d_enc

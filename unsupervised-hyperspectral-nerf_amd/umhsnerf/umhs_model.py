@@ -423,32 +423,24 @@ class UMHSModel(ModelBase):
                     prepared = ops.hashgrid_bwd_prepare(pos01, spec.scalings, L.log2_hashmap_size)
                 ev_done.record(side)
             main.wait_event(ev_ready)
-        # Measured on one MI355X (A/B in one session): 128 bands + specular (C3) 2.107 -> 1.938 ms per step; at 31 bands (C2) the two extra
-        # launches cost more than the streams they remove (0.817 -> 0.850), and without the specular head there is one stream and
-        # nothing to remove (C5 1.775 -> 1.826).  UMHS_SPLIT_FWD=0 / 1 forces either path.
-        knob = os.environ.get("UMHS_SPLIT_FWD", "")
-        split_fwd = n > 0 and (knob == "1" or (knob != "0" and c.pred_specular and L.wavelengths > 32))
-        # ... and with the value half of the compositing backward folded into the field backward (umhs_field_bwd_composited) no [N,B]
-        # array is left at all: spectral is recomputed there, d_spectral formed on the fly.  UMHS_FUSED_BWD=0 keeps the per-sample arrays.
+        # Above 32 bands the step runs without any per-sample [N,B] array: forward as two launches with the rendering
+        # weights known in between, per-ray sums inside the heads kernel, the mixing product once per RAY; the value half of the
+        # compositing backward folded into the field backward.  At 31 bands both forms take the same time (C2 0.82 ms), so the
+        # per-sample form stays the default there.  UMHS_FUSED_BWD=0 / 1 forces either.
         knob_b = os.environ.get("UMHS_FUSED_BWD", "")
-        fused_bwd = n > 0 and knob_b != "0" and (knob_b == "1" or L.wavelengths > 32) and knob != "0" \
-            and ops.field_bwd_composited_supported(spec)
-        split_fwd = split_fwd or fused_bwd
+        fused_bwd = n > 0 and knob_b != "0" and (knob_b == "1" or L.wavelengths > 32) and ops.field_bwd_composited_supported(spec)
+        split_fwd = fused_bwd
         if split_fwd:
-            # Two launches with the rendering weights known in between: mlp_base -> weights (transmittance scan) -> heads, whose
-            # kernel forms the per-ray band sums itself.  spectral2 / specular (no loss, umhs_model.py:373-374) never exist per sample
-            # and the three-stream compositing pass over [N,B] disappears; per-sample spectral stays for the compositing backward.
-            fo = ops.field_base_fwd(spec, flat, enc, True, sel, pack_ready=side is not None, rows16=fused_bwd)
-            if fused_bwd:
-                fo["emb"] = fo["base16"]  # the aligned-row form feeds the heads kernel and the composited backward
+            # mlp_base -> weights (transmittance scan) -> heads, whose kernel forms the per-ray sums itself
+            fo = ops.field_base_fwd(spec, flat, enc, True, sel, pack_ready=side is not None, rows16=True)
+            fo["emb"] = fo["base16"]  # the aligned-row form feeds the heads kernel and the composited backward
             weights, acc, depth, _ = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, [])
             ri = ray_indices if ray_indices.dtype == torch.int64 else ray_indices.long()
             ri = ri.contiguous()
-            ho = ops.field_heads_fwd(spec, flat, fo["emb"], wpos, d, weights, ri, packed_info, want_spectral=not fused_bwd, pack_ready=True,
-                                     release=side is not None, want_abundances=False)
-            fo.update(spectral=ho["spectral"], feat_logits=ho["feat_logits"])
+            ho = ops.field_heads_fwd(spec, flat, fo["emb"], wpos, d, weights, ri, packed_info, pack_ready=True, release=side is not None)
+            fo.update(feat_logits=ho["feat_logits"])
             comp = ho["comp"] + [ho["comp_abundances"]]
-            values = [fo["spectral"]]
+            values = None
         else:
             fo = ops.field_fwd(spec, flat, enc, True, wpos, d, sel, want_emb=True, pack_ready=side is not None, want_logits=True)
             values = [fo["spectral"]] + ([fo["spectral2"], fo["specular"]] if c.pred_specular else []) + [fo["abundances"]]
