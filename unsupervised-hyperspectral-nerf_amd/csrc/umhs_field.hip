@@ -1877,6 +1877,8 @@ extern "C" int umhs_debug_tf_stamps_clear() {
 
 // BF: the fp32 chain (forward recompute + dX) of every layer with >= 7 k-steps runs as three-piece bf16 products (gemm_bf); the
 // 4-step layers (the band tiles' products, the out-layer transposes) keep the fp32 MFMA.
+// (Two waves per SIMD for the part-0 kernel without specular head and with the per-ray mixing -- its accumulators alone would fit --
+// was tried: 128 + 128 registers, 103 spilled, 654 vs 485 us at 141 bands.)
 template <int PART, bool SPEC, int TBMAX, bool BF, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDesc pd, TPackDesc td, const float* __restrict__ image,
                                                               const float* __restrict__ wT_image, ImgSegs seg_f, ImgSegs seg_t,

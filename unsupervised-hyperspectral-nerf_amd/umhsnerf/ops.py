@@ -407,8 +407,15 @@ def _require_free(device, slot: int, who: str) -> None:
 
 
 def field_bwd_composited_supported(spec: FieldSpec) -> bool:
-    cfg = spec.cfg(False)
-    return bool(_hip.lib().umhs_field_bwd_composited_supported(C.byref(cfg)))
+    ok = getattr(spec, "_composited_ok", None)
+    if ok is None:  # depends on the configuration only: asked once
+        cfg = spec.cfg(False)
+        ok = bool(_hip.lib().umhs_field_bwd_composited_supported(C.byref(cfg)))
+        try:
+            spec._composited_ok = ok
+        except AttributeError:
+            pass
+    return ok
 
 
 def field_bwd(spec: FieldSpec, flat, enc, level_major, wpos, dirs, sel, sigma_raw, emb, d_sigma, d_spectral, d_emb, d_flat,
