@@ -114,6 +114,23 @@ def test_model_kwargs_follow_the_reference_pipeline_call():
     assert float(m.field.endmembers.min()) == 0.0 and float(m.field.endmembers.max()) == 1.0
 
 
+def test_background_color_last_sample_of_the_spectral_script_is_black_in_the_loss_blend():
+    """scripts/spectral.sh:6 passes ``--pipeline.model.background-color last_sample``; RGBRenderer.blend_background_for_loss_computation
+    (umhs_renderer.py:108-109) blends the ground truth over black in that case and leaves the prediction alone."""
+    from umhsnerf.umhs_model import UMHSConfig
+
+    cfg = UMHSConfig(log2_hashmap_size=12, background_color="last_sample", method="spectral")
+    m = cfg.setup(scene_box=None, num_train_data=1, metadata={"wavelengths": [400.0 + i for i in range(8)], "num_classes": 3}, num_classes=3)
+    g = torch.Generator().manual_seed(0)
+    pred, acc, gt = torch.rand(5, 3, generator=g), torch.rand(5, 1, generator=g), torch.rand(5, 4, generator=g)
+    p2, g2 = m.blend_background_for_loss_computation(pred, acc, gt)
+    assert torch.equal(p2, pred) and torch.equal(g2, gt[:, :3] * gt[:, 3:])
+    # the reference's inverted appearance flag (umhs_model.py:181): False would switch its 32-d embedding on -- refused, not ignored
+    with pytest.raises(NotImplementedError, match="appearance"):
+        UMHSConfig(log2_hashmap_size=12, use_appearance_embedding=False).setup(
+            scene_box=None, num_train_data=1, metadata={"wavelengths": [400.0 + i for i in range(8)], "num_classes": 3}, num_classes=3)
+
+
 def test_checkpoints_speak_the_reference_key_names_at_every_level():
     """model.load_state_dict(model.state_dict()) must round-trip; keys are the reference's."""
     a, b = _model(1), _model(2)

@@ -54,7 +54,9 @@ class UMHSConfig(ModelConfigBase):
     far_plane: float = 1e3
     use_gradient_scaling: bool = True
     use_appearance_embedding: bool = True
-    background_color: Literal["random", "black", "white"] = "random"
+    # "last_sample" is what scripts/spectral.sh:6 passes; for the loss blend it is black (RGBRenderer.blend_background_for_loss_computation,
+    # umhs_renderer.py:108-109), and this model's rgb is converter(spectral), never a renderer's last-sample composite
+    background_color: Literal["random", "last_sample", "black", "white"] = "random"
     disable_scene_contraction: bool = False
     implementation: Literal["hip", "tcnn", "torch"] = "hip"
     method: Literal["rgb", "spectral", "rgb+spectral"] = "rgb+spectral"
@@ -187,6 +189,10 @@ class UMHSModel(ModelBase):
         if "spectral" in c.method:
             self.renderer_spectral = SpectralRenderer()
         self.converter = ColourSystem(bands=wl, cs="sRGB")
+        if not c.use_appearance_embedding:
+            # umhs_model.py:181: the reference's flag is inverted -- False is what switches its 32-d per-image embedding ON (no script
+            # does); that input of the rgb / specular heads is not built here, and ignoring the flag would silently train another model
+            raise NotImplementedError("use_appearance_embedding=False (= the reference's 32-d appearance embedding, umhs_model.py:181) is not supported")
         self.field = UMHSField(
             aabb=self.scene_aabb_t, num_images=self.num_train_data, implementation=c.implementation,
             log2_hashmap_size=c.log2_hashmap_size, max_res=c.max_res,
