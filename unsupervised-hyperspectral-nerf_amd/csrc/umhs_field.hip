@@ -2443,24 +2443,57 @@ __device__ __forceinline__ int tf_col(int kind, int ti, int c) {
 // walking all 256 slabs was 82 us at 128 bands: 90 workgroups of serial loads)
 __global__ __launch_bounds__(1024) void field_reduce_tf_kernel(const float* __restrict__ slabs, int nslabs, TfMap mp, PackDesc pd,
                                                               GradPtrs gp) {
-  __shared__ float part[16][64];
+  // Workgroups [0, nacc): one accumulator item (64 lanes x 4 floats = 1 KiB per slab) each -- a wave reads the whole item of a slab
+  // with one 16-byte load per lane, 16 waves take a sixteenth of the slabs each (8 loads in flight), LDS combines in a fixed order.
+  // Workgroups from nacc on: 64 bias columns each (sum over the slabs and the 4 lane quarters).
+  __shared__ v4f part4[16][64];
   const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
-  const int nw = mp.nacc * 256, nb = mp.ndb * 16;
   const size_t stride = (size_t)mp.nitems * 256;
   const int per = (nslabs + 15) / 16, w0 = pw * per, w1 = min(nslabs, w0 + per);
-  float a[8];
+  if ((int)blockIdx.x < mp.nacc) {
+    const int item = blockIdx.x, l = mp.layer[item];
+    if (l < 0) return;  // an unused slot (workgroup-uniform)
+    const size_t off = (size_t)item * 256 + lane * 4;
+    v4f a[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = 0.0f;
-  if (e < nw) {
+    for (int k = 0; k < 4; ++k) a[k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     int w = w0;
     for (; w + 7 < w1; w += 8) {
+      v4f x[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] += slabs[(size_t)(w + k) * stride + e];
+      for (int k = 0; k < 8; ++k) x[k] = *reinterpret_cast<const v4f*>(slabs + (size_t)(w + k) * stride + off);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k & 3] += x[k];
     }
-    for (; w < w1; ++w) a[0] += slabs[(size_t)w * stride + e];
-  } else if (e < nw + nb) {
-    const int k = e - nw, T = k >> 4, c = k & 15;  // bias tile T (slot in db[]), column c: sum over slabs and the 4 lane quarters
+    for (; w < w1; ++w) a[0] += *reinterpret_cast<const v4f*>(slabs + (size_t)w * stride + off);
+    part4[pw][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (pw != 0) return;
+    v4f s4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) s4 += (part4[k][lane] + part4[k + 1][lane]) + (part4[k + 2][lane] + part4[k + 3][lane]);
+    const LayerDesc& L = pd.L[l];
+    if (!gp.W[l]) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int out = 16 * mp.to[item] + 4 * (lane >> 4) + r;
+      if (l == L_MX) {  // dE^T[b][c]
+        const int cls = lane & 15;
+        if (out < L.OUT && cls < L.IN) gp.W[l][(size_t)cls * L.OUT + out] = s4[r];
+      } else {
+        const int in = tf_col(L.kind, mp.ti[item], lane & 15);
+        if (out < L.OUT && in >= 0 && in < L.IN) gp.W[l][(size_t)out * L.IN + in] = s4[r];
+      }
+    }
+    return;
+  }
+  float(*part)[64] = reinterpret_cast<float(*)[64]>(&part4[0][0]);
+  const int k = ((int)blockIdx.x - mp.nacc) * 64 + lane, nb = mp.ndb * 16;
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = 0.0f;
+  const int T = k >> 4, c = k & 15;  // bias tile T (slot in db[]), column c
+  if (k < nb) {
     const size_t off = (size_t)(mp.nacc + (T >> 2)) * 256 + (T & 3);
     for (int w = w0; w < w1; ++w) {
       const float* p = slabs + (size_t)w * stride + off;
@@ -2469,30 +2502,14 @@ __global__ __launch_bounds__(1024) void field_reduce_tf_kernel(const float* __re
   }
   part[pw][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
-  if (pw != 0 || e >= nw + nb) return;
+  if (pw != 0 || k >= nb) return;
   float s = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 16; k += 4) s += (part[k][lane] + part[k + 1][lane]) + (part[k + 2][lane] + part[k + 3][lane]);
-  if (e < nw) {
-    const int item = e >> 8, rel = e & 255, r = rel & 3, ln = rel >> 2;
-    const int l = mp.layer[item];
-    if (l < 0) return;
-    const LayerDesc& L = pd.L[l];
-    const int out = 16 * mp.to[item] + 4 * (ln >> 4) + r;
-    if (l == L_MX) {  // dE^T[b][c]
-      const int cls = ln & 15;
-      if (out < L.OUT && cls < L.IN && gp.W[l]) gp.W[l][(size_t)cls * L.OUT + out] = s;
-      return;
-    }
-    const int in = tf_col(L.kind, mp.ti[item], ln & 15);
-    if (out < L.OUT && in >= 0 && in < L.IN && gp.W[l]) gp.W[l][(size_t)out * L.IN + in] = s;
-  } else {
-    const int k = e - nw, T = k >> 4, c = k & 15;
-    const int l = mp.db_layer[T];
-    if (l < 0) return;
-    const int o = 16 * mp.db_tile[T] + c;
-    if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
-  }
+  for (int i = 0; i < 16; i += 4) s += (part[i][lane] + part[i + 1][lane]) + (part[i + 2][lane] + part[i + 3][lane]);
+  const int l = mp.db_layer[T];
+  if (l < 0) return;
+  const int o = 16 * mp.db_tile[T] + c;
+  if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
 }
 
 // ---- sum the per-workgroup slabs and scatter into the reference-layout gradient tensors ------------
@@ -3420,11 +3437,10 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
   UMHS_CHECK_LAUNCH();
   TfMap mp;
   fill_tf_map<TBMAX>(&mp, spec, pl.TB);
-  const int items = SL::NACC * 256 + SL::NDB * 16;
   if (bc)  // the endmember gradient comes from the per-ray pass below, not from the slabs
     for (int t = 0; t < TBMAX; ++t) mp.layer[SL::A_MX + t] = -1;
-  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3((items + 63) / 64), dim3(1024), 0, umhs_s(stream), (const float*)slabs, (int)grid, mp,
-                     pl.pd_all, gp);
+  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3(SL::NACC + (SL::NDB * 16 + 63) / 64), dim3(1024), 0, umhs_s(stream),
+                     (const float*)slabs, (int)grid, mp, pl.pd_all, gp);
   UMHS_CHECK_LAUNCH();
   if (bc && bc->dE) {
     const int nchunks = (int)((bc->n_rays + MIX_CHUNK - 1) / MIX_CHUNK), CB = bc->C * bc->B;
