@@ -1467,9 +1467,14 @@ extern "C" int umhs_loss_bwd(const float* spectral, const float* gt_spectral, co
 // Loss sums: per-block partials, added in block order by the last block to finish (reproducible); the arrival counter
 // in `scratch` is left at zero again.
 // =============================================================================================
-__device__ __forceinline__ float red16(float v) {  // sum over the 16 lanes of a ray group
-  v += __shfl_xor(v, 1, 64), v += __shfl_xor(v, 2, 64), v += __shfl_xor(v, 4, 64);
-  return v + __shfl_xor(v, 8, 64);
+__device__ __forceinline__ float red16(float v) {  // sum over the 16 lanes of a ray group (= a DPP row), result in every lane
+  // four rotate-and-add steps on the VALU (v_add_f32_dpp row_ror:8/4/2/1); __shfl_xor compiles to ds_bpermute here, an LDS round
+  // trip per step in kernels that are nothing but chains of such reductions
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+  return v;
 }
 
 struct TailArgs {
@@ -1581,7 +1586,8 @@ __global__ __launch_bounds__(256) void ray_train_tail_kernel(TailArgs a) {
   __syncthreads();
   if (last) {  // block-wide tree over the (<= 256) partials: fixed order, no serial chain of L2 round trips
     __threadfence();
-    float s0 = tid < gridDim.x ? a.partial[2 * tid] : 0.0f, s1 = tid < gridDim.x ? a.partial[2 * tid + 1] : 0.0f;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (unsigned i = tid; i < gridDim.x; i += 256) s0 += a.partial[2 * i], s1 += a.partial[2 * i + 1];  // (<= 1024 partials)
     s0 = red16(s0), s1 = red16(s1);
     __syncthreads();
     if (l == 0) part[0][grp] = s0, part[1][grp] = s1;
@@ -1596,7 +1602,8 @@ __global__ __launch_bounds__(256) void ray_train_tail_kernel(TailArgs a) {
   }
 }
 
-extern "C" size_t umhs_ray_train_tail_scratch_bytes(void) { return 256 * 2 * sizeof(float) + 64; }
+constexpr int TAIL_MAX_BLOCKS = 1024;  // 16 rays per workgroup iteration: up to 16 k rays get a workgroup each (4 resident per CU)
+extern "C" size_t umhs_ray_train_tail_scratch_bytes(void) { return TAIL_MAX_BLOCKS * 2 * sizeof(float) + 64; }
 
 extern "C" int umhs_ray_train_tail(const float* spectral, const float* M, const float* endmembers, const float* accumulation,
                                    const float* depth, const float* tmid_minmax2, const float* class_colors,
@@ -1622,7 +1629,8 @@ extern "C" int umhs_ray_train_tail(const float* spectral, const float* M, const 
   a.seg_raw = seg_raw, a.seg_pred = seg_pred, a.losses = losses2, a.d_spec = d_spectral, a.d_acc = d_accumulation;
   a.counter = reinterpret_cast<uint32_t*>(scratch), a.partial = reinterpret_cast<float*>(scratch) + 16;
   const int64_t blocks = (n_rays + 15) / 16;
-  hipLaunchKernelGGL(ray_train_tail_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, umhs_s(stream), a);
+  hipLaunchKernelGGL(ray_train_tail_kernel, dim3((unsigned)(blocks < TAIL_MAX_BLOCKS ? blocks : TAIL_MAX_BLOCKS)), dim3(256), 0,
+                     umhs_s(stream), a);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
