@@ -75,3 +75,4 @@ for name in os.environ.get("CASES", "C2").split(","):
         for k in range(1, 19):
             if v[k]:
                 print(f"    {NAMES[part].get(k, str(k)):34s} {v[k] / tiles:8.0f}  {100.0 * v[k] / tot:5.1f} %")
+        print(f"    whole kernel (workgroup 0): LDS image {v[20]} + tile loop {v[21]} + accumulator reduce / slab {v[22]} cycles")

@@ -379,11 +379,24 @@ struct ImgSegs {
   int n, src[6], dst[6], len[6];  // float offsets / lengths, multiples of 4
 };
 __device__ __forceinline__ void copy_segs(float* dst, const float* __restrict__ src, const ImgSegs& sg) {
-  for (int k = 0; k < sg.n; ++k)
-    for (int i = threadIdx.x; i < (sg.len[k] >> 2); i += blockDim.x)
-      reinterpret_cast<float4*>(dst + sg.dst[k])[i] = reinterpret_cast<const float4*>(src + sg.src[k])[i];
+  // Every workgroup of a launch copies the SAME image at the same moment: walking it in the same order queues all CUs of an XCD on
+  // one L2 channel at a time (stamps: 21 k cycles from kernel start to the barrier behind the copy of ~100 KB, 6 % of the backward
+  // kernels; 15-19 k with each workgroup starting at its own rotation of the chunk sequence; 8 unconditional loads in flight per
+  // thread: 21 k again, 4-8 conditional ones 26-31 k).
+  for (int k = 0; k < sg.n; ++k) {
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + sg.src[k]);
+    float4* d4 = reinterpret_cast<float4*>(dst + sg.dst[k]);
+    const int n4 = sg.len[k] >> 2, bd = blockDim.x;
+    const int nchunks = (n4 + bd - 1) / bd;
+    const int c0 = (int)((blockIdx.x * 7u) % (unsigned)nchunks);
+    for (int c = 0; c < nchunks; ++c) {
+      int cc = c0 + c;
+      if (cc >= nchunks) cc -= nchunks;
+      const int i = cc * bd + threadIdx.x;
+      if (i < n4) d4[i] = s4[i];
+    }
+  }
 }
-
 
 enum TLayerId { T_B1 = 0, T_B0, T_H2, T_H1, T_H0, T_F2, T_F1, T_F0, T_D1, T_MX, NTLAYERS };
 
@@ -1363,6 +1376,9 @@ __global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, Pack
     in.x = *reinterpret_cast<const v4f*>((PART == 0 ? io.feat_logits_in : io.d_fl) + n * 16 + 4 * q);
   };
   TileIn cur, nxt;
+#ifdef UMHS_TF_STAMP
+  const unsigned long long k_t1 = __builtin_readcyclecounter();
+#endif
   if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t n0 = tile * S;
@@ -1628,6 +1644,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(F
     in.raw = io.sigma_raw_in[n], in.dsig = io.d_sigma[n], in.sel = io.sel[n];
   };
   TileIn cur, nxt;
+#ifdef UMHS_TF_STAMP
+  const unsigned long long k_t1 = __builtin_readcyclecounter();
+#endif
   if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t n = tile * S + row;
@@ -1886,6 +1905,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
                                                               BfOffs bo, float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef TfSlots<TBMAX> SL;
+#ifdef UMHS_TF_STAMP
+  const unsigned long long k_t0 = __builtin_readcyclecounter();
+#endif
   copy_segs(lds, image, seg_f);  // pd / td carry offsets local to this part's LDS image
   copy_segs(lds + wt_off, wT_image, seg_t);
   if (BF) copy_segs(lds + bf_off, bf_image, seg_b);
@@ -1972,6 +1994,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     }
   };
   TileIn cur, nxt;
+#ifdef UMHS_TF_STAMP
+  const unsigned long long k_t1 = __builtin_readcyclecounter();
+#endif
   if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t n = tile * 64 + wave * 16 + j;
@@ -2284,6 +2309,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     cur = nxt;
   }
   // =================== sum the four waves' accumulators through LDS (the pack images are dead), one slab per workgroup ======
+#ifdef UMHS_TF_STAMP
+  const unsigned long long k_t2 = __builtin_readcyclecounter();
+#endif
   float* const slab = slabs + (size_t)blockIdx.x * (SL::NITEMS * 256);
   constexpr int NMINE = NA + NDBP / 4;  // this part's items: its accumulators, then its bias-sum quadruples
 #pragma unroll
@@ -2314,6 +2342,12 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       *reinterpret_cast<v4f*>(slab + (abs_item * 64 + (e & 63)) * 4) = s;
     }
   }
+#ifdef UMHS_TF_STAMP
+  if (blockIdx.x == 0 && tid == 0) {
+    const unsigned long long k_t3 = __builtin_readcyclecounter();
+    g_tf_stamp[PART][20] += k_t1 - k_t0, g_tf_stamp[PART][21] += k_t2 - k_t1, g_tf_stamp[PART][22] += k_t3 - k_t2;
+  }
+#endif
 }
 #undef TF_GEMM_F
 #undef TF_GEMM_T
