@@ -93,6 +93,10 @@ def trained_like_init(field, seed):
         field.flat.data.copy_(flat.to(field.flat.device))
 
 
+# operators that have a roofline entry (the dominant one of them is timed live inside the timed region)
+ROOFLINE_OPS = ("field_bwd", "hashgrid_bwd_apply", "hashgrid_bwd", "field_fwd", "field_heads_fwd", "hashgrid_fwd", "composite_fwd", "composite_bwd")
+
+
 class KernelTimer:
     """HIP events around each C-ABI call on the launch stream (torch's current stream is the stream every op uses)."""
 
@@ -218,13 +222,25 @@ def main():
     # Inside the timed region only the dominant operator carries HIP events (2 per step) plus one event per step boundary (for the
     # median): an event is a barrier packet on the queue, and a pair around every one of the ~12 operators costs ~12 % of the
     # step.  The full per-operator table comes from a separate, untimed pass over the same step.
-    timer.only = {"field_bwd"}
-
     def step():
         return pipe.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
 
     for _ in range(args.warmup):
         step()
+    # Which operator is the dominant one is measured, not assumed: three steps with every operator timed (still warm-up), and the
+    # largest carries the events of the timed region.  field_bwd and hashgrid_bwd_apply are within a few percent of each other at
+    # C2 -- a ranking taken AFTER the timed region (from the untimed pass) would quote an operator that was not timed live.
+    timer.only, timer.enabled = None, True
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    timer.enabled = False
+    pre = timer.summary()
+    pick = torch.tensor([float(pre.get(k, (0.0, 0))[0]) for k in ROOFLINE_OPS], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(pick, op=dist.ReduceOp.MAX)  # every rank times the same operator
+    timer.only = {ROOFLINE_OPS[int(torch.argmax(pick).item())]}
+    timer.records.clear()
     timer.enabled = True
     parallel.STATS.update(bytes=0, messages=0)
     if world > 1:
@@ -284,14 +300,19 @@ def main():
         loss_dict = {k: v.detach() for k, v in loss_dict.items()}
         print(f"[bench] gpu: {ms_step:.3f} ms/step (median {median_ms:.3f}), {R * world * args.steps / dt:.0f} rays/s", file=sys.stderr, flush=True)
         kern = {k: round(v[0], 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][0])}
-        dom = next(iter(kern))
+        dom = next(iter(dom_live)) if dom_live else next(iter(kern))  # the operator that carried the events of the timed region
         # algorithmic work per launch: hash gather / scatter 1024 B per sample + the level-major feature rows (128 B) and
         # positions (12 B); field MLPs 2 x MAC per sample (forward), backward = dX + dW = 2 x forward; compositing and the optimizer
         # by the bytes they must move once
         spec = cfg["pred_specular"]
         mac = 3072 + 2 * (1728 + 4096) + 64 * Cn + 64 * (Cn + (1 if spec else 0)) + ((448 + 16 * B) if spec else 0) + Cn * B + 256
         nstream = (3 * B if spec else B) + Cn
-        alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12), "hashgrid_bwd_apply": N * (1024 + 128 + 12),
+        # (one GPU: the Adam step of the dense hash levels rides in the bucket reduce of hashgrid_bwd_apply -- 28 B per parameter of
+        # levels 5..15, the same bytes the separate adam_step would move -- so that operator's algorithmic bytes include them)
+        sink = getattr(pipe.model.field, "_grad_sink", None)
+        fused_adam_bytes = 28 * (16 - int(getattr(sink, "sparse_levels", 0) or 0)) * (1 << 19) * 2 if world == 1 else 0
+        alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12),
+                     "hashgrid_bwd_apply": N * (1024 + 128 + 12) + fused_adam_bytes,
                      "composite_fwd": N * (nstream + 4) * 4, "composite_bwd": N * (2 * B + 5) * 4,
                      "adam_step": pipe.model.field.flat.numel() * 28}
         # (wide-band models run the forward as mlp_base + heads with the per-ray band sums inside the heads kernel, and the backward

@@ -76,3 +76,4 @@ for name in os.environ.get("CASES", "C2").split(","):
             if v[k]:
                 print(f"    {NAMES[part].get(k, str(k)):34s} {v[k] / tiles:8.0f}  {100.0 * v[k] / tot:5.1f} %")
         print(f"    whole kernel (workgroup 0): LDS image {v[20]} + tile loop {v[21]} + accumulator reduce / slab {v[22]} cycles")
+        print(f"    prologue: fp32 packs {v[16]}, transposed packs {v[17]}, bf16x3 packs {v[19]}, barrier {v[23]} cycles (last launch)")

@@ -387,14 +387,29 @@ __device__ __forceinline__ void copy_segs(float* dst, const float* __restrict__ 
     const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + sg.src[k]);
     float4* d4 = reinterpret_cast<float4*>(dst + sg.dst[k]);
     const int n4 = sg.len[k] >> 2, bd = blockDim.x;
-    const int nchunks = (n4 + bd - 1) / bd;
-    const int c0 = (int)((blockIdx.x * 7u) % (unsigned)nchunks);
-    for (int c = 0; c < nchunks; ++c) {
-      int cc = c0 + c;
-      if (cc >= nchunks) cc -= nchunks;
-      const int i = cc * bd + threadIdx.x;
-      if (i < n4) d4[i] = s4[i];
+    const int nfull = n4 / bd;  // whole chunks of blockDim float4s: copied without a condition, 4 loads in flight, rotated start
+    const int c0 = nfull ? (int)((blockIdx.x * 7u) % (unsigned)nfull) : 0;
+    int c = 0;
+    for (; c + 4 <= nfull; c += 4) {
+      float4 v[4];
+      int idx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int cc = c0 + c + u;
+        cc = cc >= nfull ? cc - nfull : cc;
+        idx[u] = cc * bd + (int)threadIdx.x;
+        v[u] = s4[idx[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d4[idx[u]] = v[u];
     }
+    for (; c < nfull; ++c) {
+      int cc = c0 + c;
+      cc = cc >= nfull ? cc - nfull : cc;
+      d4[cc * bd + threadIdx.x] = s4[cc * bd + threadIdx.x];
+    }
+    const int i = nfull * bd + threadIdx.x;  // the partial last chunk
+    if (i < n4) d4[i] = s4[i];
   }
 }
 
@@ -1909,9 +1924,26 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
   const unsigned long long k_t0 = __builtin_readcyclecounter();
 #endif
   copy_segs(lds, image, seg_f);  // pd / td carry offsets local to this part's LDS image
+#ifdef UMHS_TF_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long k_ta = __builtin_readcyclecounter();
+#endif
   copy_segs(lds + wt_off, wT_image, seg_t);
+#ifdef UMHS_TF_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long k_tb = __builtin_readcyclecounter();
+#endif
   if (BF) copy_segs(lds + bf_off, bf_image, seg_b);
+#ifdef UMHS_TF_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long k_tc = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef UMHS_TF_STAMP
+  const unsigned long long k_td = __builtin_readcyclecounter();
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    g_tf_stamp[PART][16] = k_ta - k_t0, g_tf_stamp[PART][17] = k_tb - k_ta, g_tf_stamp[PART][19] = k_tc - k_tb, g_tf_stamp[PART][23] = k_td - k_tc;
+#endif
   const float* const wT = lds + wt_off;
   const uint32_t* const wbf = reinterpret_cast<const uint32_t*>(lds + bf_off);
 #define TF_GEMM_F(OT_, KS_, INIT_, ACC_, B_, LID_)                                                             \
