@@ -649,7 +649,7 @@ def test_field_bwd_overwrites_every_parameter_gradient(C, B, spec):
         assert all(n.startswith("mlp_directional") for n in untouched) and (not spec or not untouched), untouched
 
 
-@pytest.mark.parametrize("C,B,spec", [(6, 31, True), (4, 40, False), (9, 128, True), (4, 141, False)])
+@pytest.mark.parametrize("C,B,spec", [(6, 31, True), (4, 40, False), (9, 128, True), (4, 141, False), (15, 256, True), (1, 3, False)])
 def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
     """umhs_field_base_fwd -> weights -> umhs_field_heads_fwd against umhs_field_fwd + umhs_composite_fwd: per-sample outputs bit for
     bit (same kernels' arithmetic), per-ray sums to rounding (another, fixed, summation order; the mixing term summed per ray as w m
@@ -658,7 +658,7 @@ def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
     ops = _ops()
     _, _, layout, flat, fs = make_case(C, B, spec, 8, 8, log2_T=12)
     g = torch.Generator().manual_seed(B)
-    counts = torch.tensor([0, 3, 2, 0, 1, 40, 17, 16, 5, 4, 3, 200, 0, 7, 33, 1, 1, 1, 90, 0], dtype=torch.int64)
+    counts = torch.tensor([0, 3, 2, 0, 1, 40, 17, 16, 5, 4, 3, 200, 0, 7, 33, 1, 1, 1, 90, 0, 1300, 0, 0, 2], dtype=torch.int64)  # (1300 > 1024)
     R, n = counts.numel(), int(counts.sum())
     assert n % 16 != 0
     starts = torch.cumsum(counts, 0) - counts
@@ -699,7 +699,8 @@ def test_two_launch_forward_with_band_sums_in_the_kernel(C, B, spec):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("C,B,spec,gs", [(6, 31, True, True), (4, 40, False, False), (9, 128, True, True), (4, 141, False, True)])
+@pytest.mark.parametrize("C,B,spec,gs", [(6, 31, True, True), (4, 40, False, False), (9, 128, True, True), (4, 141, False, True),
+                                         (15, 160, True, False), (1, 3, False, True)])
 def test_field_backward_with_the_compositing_backward_folded_in(C, B, spec, gs):
     """umhs_field_bwd_composited (d_comp [R,B] in, d_sigma out, no [N,B] array) against umhs_composite_bwd + umhs_field_bwd on the
     same inputs: d_sigma, d_enc and every parameter gradient.  Ragged rays incl. empty and sub-tile ones; with and without
@@ -707,6 +708,9 @@ def test_field_backward_with_the_compositing_backward_folded_in(C, B, spec, gs):
     ops = _ops()
     _, _, layout, flat, fs = make_case(C, B, spec, 8, 8, log2_T=12)
     assert ops.field_bwd_composited_supported(fs)
+    # (256 bands with the specular head: the transpose-free kernels' packs no longer fit in LDS -- the query says so and the model keeps
+    # the per-sample path, umhs_model.forward_backward_from_samples)
+    assert not ops.field_bwd_composited_supported(make_case(15, 256, True, 8, 8, log2_T=12)[4])
     g = torch.Generator().manual_seed(B + 1)
     counts = torch.tensor([0, 3, 2, 0, 1, 40, 17, 16, 5, 4, 3, 200, 0, 7, 33, 1, 1, 1, 90, 0], dtype=torch.int64)
     R, n = counts.numel(), int(counts.sum())
