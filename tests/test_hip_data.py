@@ -149,7 +149,7 @@ def test_image_metrics_match_the_oracle(H, W, K):
             ops.ssim(gt[:10].to(DEV), pred[:10].to(DEV))
 
 
-def test_eval_image_path_and_metrics():
+def test_eval_image_path_and_metrics(monkeypatch):
     from umhsnerf._ns_compat import RayBundle
     from umhsnerf.data.umhs_datamanager import UMHSDataManager, UMHSDataManagerConfig
     from umhsnerf.umhs_model import UMHSConfig
@@ -170,8 +170,20 @@ def test_eval_image_path_and_metrics():
     assert out["spectral"].shape == (24, 32, B) and out["rgb"].shape == (24, 32, 3) and out["accumulation"].shape == (24, 32, 1)
     assert out["abundances"].shape == (24, 32, 3) and out["seg_pred"].shape == (24, 32, 3)
     # image == the same rays through forward() as one flat bundle
-    flat = pipe.model(RayBundle(origins=cam.origins.reshape(-1, 3), directions=cam.directions.reshape(-1, 3)))
+    with torch.no_grad():
+        flat = pipe.model(RayBundle(origins=cam.origins.reshape(-1, 3), directions=cam.directions.reshape(-1, 3)))
     assert torch.equal(flat["spectral"].view(24, 32, B), out["spectral"])
+    # gradient-free rendering takes the per-ray path (mlp_base -> weights -> heads with the per-ray sums in the kernel, no [N, bands]
+    # array); the per-sample path (what training's autograd form runs) renders the same image
+    monkeypatch.setenv("UMHS_RENDER_PER_RAY", "0")
+    ref = pipe.model.get_outputs_for_camera_ray_bundle(cam)
+    monkeypatch.delenv("UMHS_RENDER_PER_RAY")
+    assert set(ref) == set(out)
+    for k in ref:
+        if k in ("seg_raw", "seg_pred"):  # argmax outputs: equal wherever the two top classes are not within rounding of each other
+            assert float((ref[k] != out[k]).float().mean()) < 0.01, k
+        else:
+            assert float((ref[k].float() - out[k].float()).abs().max()) <= 2e-5 * max(1.0, float(ref[k].float().abs().max())), k
     md, images = pipe.model.get_image_metrics_and_images(out, batch)
     want = T.image_metrics_ref(out["rgb"].cpu(), batch["image"].cpu(), out["spectral"].cpu(), batch["hs_image"].cpu())
     assert set(md) == set(want)

@@ -266,7 +266,10 @@ class UMHSModel(ModelBase):
         # the fused query takes as long as gather + MLP back to back (both are bound by the gather's L2 request rate), so the
         # second hashing is a net loss of 0.07 ms per step; the fused launch serves the callers that keep nothing (occupancy
         # grid update, eval), where it saves the 128 B per position of the feature array.
-        reuse = self.training and isinstance(self.sampler, VolumetricSampler) and os.environ.get("UMHS_REUSE_ENC", "1") != "0"
+        # (Gradient-free rendering reuses them as well -- an eval image keeps nearly every marched candidate; 21.1 -> 20.9 ms per 256x256
+        # image, the heads kernel is what its time is made of.)
+        reuse = isinstance(self.sampler, VolumetricSampler) and os.environ.get("UMHS_REUSE_ENC", "1") != "0" and (
+            self.training or (not torch.is_grad_enabled() and os.environ.get("UMHS_RENDER_PER_RAY", "1") != "0"))
         self.field._enc_capture = {} if reuse else None
         try:
             ray_samples, ray_indices = self._sample(ray_bundle)
@@ -312,12 +315,15 @@ class UMHSModel(ModelBase):
                                  packed_info: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """Body of ``get_outputs`` after the sampler, umhs_model.py:239-327."""
         c = self.config
-        fo = self.field(ray_samples)
         fr = ray_samples.frustums
         if packed_info is None:
             packed_info = (getattr(ray_samples, "metadata", None) or {}).get("umhs_packed_info")
         if packed_info is None:
             packed_info = ops.pack_info(ray_indices, num_rays)
+        if (not torch.is_grad_enabled() and c.method != "rgb" and fr.origins.numel() > 0
+                and os.environ.get("UMHS_RENDER_PER_RAY", "1") != "0"):
+            return self._render_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
+        fo = self.field(ray_samples)
         values = [fo["spectral"]]
         if c.pred_specular:
             values += [fo["spectral2"].detach(), fo["specular"]]  # spectral2 carries no loss in the reference (:373-374)
@@ -331,6 +337,35 @@ class UMHSModel(ModelBase):
             spec_for_rgb, self.converter.transform_matrix, self.field.endmembers.detach(), accumulation, depth, mm,
             self.class_colors, 0.2)
         return self._assemble_outputs(accumulation, depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights)
+
+    def _render_outputs_from_samples(self, ray_samples, ray_indices, num_rays: int, packed_info) -> Dict[str, Tensor]:
+        """The same outputs without gradients (eval images, ``ns-render``): mlp_base -> transmittance weights -> heads with the per-ray
+        sums formed inside the kernel -- an image's samples never exist as [N, bands] arrays (an eval chunk of 32 k rays
+        x 529 samples x 31 bands x 3 streams is 6.4 GB written and read back otherwise)."""
+        c, f = self.config, self.field
+        spec = f._spec()
+        L = spec.layout
+        fr = ray_samples.frustums
+        n = fr.origins.numel() // 3
+        o, d = _hip.f32c(fr.origins).view(n, 3), _hip.f32c(fr.directions).view(n, 3)
+        t0, t1 = _hip.f32c(fr.starts).view(-1), _hip.f32c(fr.ends).view(-1)
+        flat = f.flat.detach()
+        wpos, pos01, sel = ops.positions_fwd(o, d, t0, t1, spec)
+        cached = (getattr(ray_samples, "metadata", None) or {}).get("umhs_enc")
+        if cached is not None and cached[1].numel() == n:
+            enc = ops.enc_gather(cached[0], cached[1])  # encoded once, by the sampler's density query (same positions, same table)
+        else:
+            enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
+        fo = ops.field_base_fwd(spec, flat, enc, True, sel, rows16=True)
+        del enc, cached
+        weights, acc, depth, _ = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, [])
+        ri = (ray_indices if ray_indices.dtype == torch.int64 else ray_indices.long()).contiguous()
+        ho = ops.field_heads_fwd(spec, flat, fo["base16"], wpos, d, weights, ri, packed_info, want_logits=False, pack_ready=True, release=False)
+        comp = ho["comp"] + [ho["comp_abundances"]]
+        mm = ops.tmid_minmax(t0, t1)
+        rgb, depth_c, seg_probs, seg_raw, seg_pred = ops.ray_epilogue_fwd(
+            comp[0], _hip.f32c(self.converter.transform_matrix), f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), 0.2)
+        return self._assemble_outputs(acc.view(-1, 1), depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights.view(-1, 1))
 
     def _assemble_outputs(self, accumulation, depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights, lazy_bands=False):
         """The output dict of umhs_model.py:260-327 (same keys).  ``lazy_bands``: the per-band entries (``wv_i``, ``residual_i``,
@@ -557,6 +592,7 @@ class UMHSModel(ModelBase):
         return lazy if (self.training and os.environ.get("UMHS_LAZY_METRICS", "1") != "0") else dict(lazy.materialize())
 
     @torch.no_grad()
+    @torch.no_grad()  # as nerfstudio's Model.get_outputs_for_camera_ray_bundle
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """umhs_model.py:593-620.  The reference walks the image in 512-ray chunks (its kernels are launch-bound there); here a
         chunk is ``max(eval_num_rays_per_chunk, 32768)`` rays, i.e. a 128x128 image or a quarter-megapixel strip is ONE fused
