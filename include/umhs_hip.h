@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 5
+#define UMHS_ABI_VERSION 6
 
 enum {
   UMHS_OK = 0,
@@ -170,6 +170,9 @@ int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_params* para
                         int64_t stride_l, const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
                         float* base16, void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
 size_t umhs_field_heads_fwd_scratch_bytes(const umhs_field_cfg* cfg, int64_t n, int64_t n_rays);
+/* 1 when the two-launch forward can serve this configuration (else both entries return UMHS_ERR_UNSUPPORTED and the caller keeps   */
+/* umhs_field_fwd + umhs_composite_fwd, which serve every configuration check_cfg admits).                                          */
+int umhs_field_heads_fwd_supported(const umhs_field_cfg* cfg);
 /* emb / base16: the base MLP's outputs either as the reference's [N,15] embedding (emb, emb_stride 15; any of emb / base16 may be    */
 /* NULL in umhs_field_base_fwd) or as aligned rows base16 [N,16] with sigma_raw in slot 0 (emb_stride 16: one 64-byte row per sample  */
 /* instead of 15 dword stores / loads).  The mixing term is linear in the mixing input m: the kernel sums w_n m_n (16 classes) per   */

@@ -67,6 +67,31 @@ def test_method_registration_with_nerfstudio_importable():
     assert info["viewer_chunk"] == 1 << 12
 
 
+ALIAS = r"""
+import json, os, re
+from umhsnerf import umhs_config
+a, b = umhs_config.umhs_method, umhs_config.umhs_alias_method
+text = open(os.path.join(os.path.dirname(os.path.dirname(umhs_config.__file__)), "pyproject.toml")).read()
+eps = {name: attr for name, attr in re.findall(r"^(\w+) = 'umhsnerf\.umhs_config:(\w+)'", text.split("nerfstudio.method_configs")[1], flags=re.M)}
+# what nerfstudio's method discovery does with the entry points: methods[spec.config.method_name] = spec
+methods = {getattr(umhs_config, attr).config.method_name: name for name, attr in eps.items()}
+print(json.dumps(dict(names=[a.config.method_name, b.config.method_name], distinct=a is not b and a.config is not b.config,
+                      entry_points=eps, methods=methods,
+                      same=[a.config.max_num_iterations == b.config.max_num_iterations,
+                            type(a.config.pipeline) is type(b.config.pipeline), a.config.pipeline is not b.config.pipeline])))
+"""
+
+
+@pytest.mark.parametrize("with_stub", [True, False])
+def test_both_method_names_resolve(with_stub):
+    """README.md:11 says ``ns-train umhs``, pyproject.toml:12-13 / every script ``umhsnerf``: nerfstudio keys discovered methods by
+    ``config.method_name``, so each name needs a specification of its own -- two entry points onto one object register one name twice."""
+    info = _run(ALIAS, with_stub=with_stub)
+    assert info["names"] == ["umhsnerf", "umhs"] and info["distinct"] and info["same"] == [True, True, True]
+    assert info["entry_points"] == {"umhsnerf": "umhs_method", "umhs": "umhs_alias_method"}
+    assert info["methods"] == {"umhsnerf": "umhsnerf", "umhs": "umhs"}  # what discovery ends up with: each name under its own key
+
+
 def test_method_registration_without_nerfstudio_keeps_the_same_configuration():
     info = _run(REGISTRATION, with_stub=False)
     assert info["bases"] is False and info["kind"].endswith("SimpleNamespace")
@@ -176,3 +201,78 @@ def test_pipeline_constructor_is_the_reference_one():
     assert (c.num_classes, c.check_nan, c._target) == (5, False, UMHSPipeline)
     assert {"datamanager", "model", "num_classes", "check_nan"} <= set(vars(c))
     assert inspect.ismethod(UMHSPipeline.from_packed_samples)
+
+
+TRAINER = r"""
+import json, sys, os, torch
+sys.path.insert(0, os.path.join(os.environ["UMHS_ROOT"], "tests"))
+from pathlib import Path
+from test_data_cpu import make_scene
+from umhsnerf import umhs_config
+from nerfstudio.engine.trainer import Trainer
+from nerfstudio.pipelines.base_pipeline import Pipeline
+root = Path(os.environ["UMHS_SCENE"])
+make_scene(root / "scene")
+cfg = umhs_config.make_nerfstudio_method("umhsnerf").config
+cfg.pipeline.datamanager.dataparser.data = root / "scene"
+cfg.pipeline.datamanager.train_num_rays_per_batch = 16
+cfg.pipeline.model.method, cfg.pipeline.model.log2_hashmap_size = "rgb+spectral", 12
+cfg.gradient_accumulation_steps = {"fields": 3}  # --gradient-accumulation_steps 3, scripts/rgb+spectral.sh:5
+tr = Trainer(cfg, device="cpu", base_dir=str(root / "run"))
+tr.setup()
+seen = tr.train_prologue()
+pipe = tr.pipeline
+saved = json.loads((root / "run" / "dataparser_transforms.json").read_text())
+# checkpoint round trip through the REAL method resolution order: nerfstudio's Pipeline.load_state_dict returns None
+assert Pipeline.load_state_dict(pipe, {}, strict=False) is None
+sd = {k: v.clone() for k, v in pipe.state_dict().items()}
+ref = pipe.model.field.flat.detach().clone()
+with torch.no_grad():
+    pipe.model.field.flat.zero_()
+pipe.load_pipeline({("module." + k if "mlp_head" in k else k): v for k, v in sd.items()}, step=77)
+print(json.dumps(dict(seen=seen, saved_keys=sorted(saved), transform_shape=[len(saved["transform"]), len(saved["transform"][0])],
+                      accumulation=pipe.gradient_accumulation_steps, callbacks=len(tr.callbacks), restored=bool(torch.equal(ref, pipe.model.field.flat)),
+                      step=pipe.model.step, opt=type(tr.optimizers.optimizers["fields"]).__name__, keys_model=all(k.startswith("_model.") for k in sd))))
+"""
+
+
+def test_trainer_prologue_and_checkpoint_resume_under_the_nerfstudio_bases(tmp_path):
+    """ADVICE r2 (medium x2): what nerfstudio's Trainer touches before step 0 -- pipeline / optimizer construction, the callbacks (with
+    the trainer's gradient-accumulation steps read from it), ``save_dataparser_transform``, the viewer's reads of ``train_dataset`` --
+    and ``load_pipeline`` on a pipeline whose base class overrides ``load_state_dict`` to return None (CPU only: nothing is launched)."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, ROOT, STUBS]), UMHS_ROOT=ROOT, UMHS_SCENE=str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", TRAINER], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["seen"] == {"cameras": 5, "thumbnails": [[6, 8, 4]] * 5, "names": 5, "eval_cameras": 2}
+    assert info["saved_keys"] == ["scale", "transform"] and info["transform_shape"] == [3, 4]
+    assert info["accumulation"] == 3 and info["callbacks"] == 2 and info["opt"] == "UMHSAdam"
+    assert info["restored"] and info["step"] == 77 and info["keys_model"]
+
+
+def test_deposited_gradient_follows_the_trainers_loss_scale():
+    """the launch-sequence step deposits the gradient of the plain sum of the losses; the trainer's backward()
+    then hands in the upstream gradient.  1 -> nothing to do; a uniform scale (GradScaler, loss / accumulation steps) -> param.grad is
+    scaled once; different weights per loss, or a scale inside an accumulation window -> an error, not a silently wrong step."""
+    from umhsnerf.umhs_pipeline import _DepositedGrad
+
+    def deposit(accumulated=False):
+        flat = torch.nn.Parameter(torch.zeros(4))
+        flat.grad = torch.tensor([1.0, -2.0, 3.0, 0.5])
+        st = {"accumulated": accumulated}
+        return flat, {k: _DepositedGrad.apply(torch.tensor(v), flat, st) for k, v in (("spectral_loss", 0.7), ("rgb_loss", 0.1))}
+
+    flat, ld = deposit()
+    total = sum(ld.values())
+    assert total.requires_grad and abs(float(total) - 0.8) < 1e-6
+    total.backward()
+    assert flat.grad.tolist() == [1.0, -2.0, 3.0, 0.5]
+    flat, ld = deposit()
+    (0.5 * sum(ld.values())).backward()  # e.g. a loss multiplied by 0.5 (VERDICT's example) or a GradScaler's scale
+    assert flat.grad.tolist() == [0.5, -1.0, 1.5, 0.25]
+    flat, ld = deposit()
+    with pytest.raises(RuntimeError, match="weights this step's losses differently"):
+        (ld["spectral_loss"] + 2.0 * ld["rgb_loss"]).backward()
+    flat, ld = deposit(accumulated=True)
+    with pytest.raises(RuntimeError, match="accumulation window"):
+        (sum(ld.values()) / 3).backward()

@@ -3046,6 +3046,20 @@ __global__ __launch_bounds__(256) void field_heads_finish_kernel(const float* __
   }
 }
 
+// 1 when umhs_field_base_fwd / umhs_field_heads_fwd can serve this configuration (every pack of the bf16x3 forward LDS-resident).
+extern "C" int umhs_field_heads_fwd_supported(const umhs_field_cfg* cfg) {
+  if (check_cfg(cfg) || cfg->density_only) return 0;
+  umhs_field_params dummy = {};
+  const float zero = 0.0f;
+  const float** pp = reinterpret_cast<const float**>(&dummy);
+  for (size_t i = 0; i < sizeof(dummy) / sizeof(float*); ++i) pp[i] = &zero;  // layout only, never dereferenced
+  PackDesc pd;
+  int TB;
+  if (build_pack_desc(cfg, &dummy, &pd, &TB)) return 0;
+  FwdBfPlan fp;
+  return fwd_bf_plan(pd, &fp, true) && fwd_bf_plan(pd, &fp) ? 1 : 0;
+}
+
 // scratch of umhs_field_heads_fwd: [specular partials G*2*BP (specular head only)][w m partials G*2*16][abundance partials G*2*16]
 // [mix16 R*16], G = ceil(n / 16) tiles
 static size_t heads_scratch_floats(const umhs_field_cfg* cfg, int64_t n, int64_t n_rays, size_t (&off)[4]) {

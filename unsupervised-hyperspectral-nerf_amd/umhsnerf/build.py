@@ -16,27 +16,43 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-munsafe-fp-atomics", "-std=c
 EXTRA_FLAGS = {"umhs_field.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "umhs_hip.h")]
+
+
+def _obj_stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src, *_headers()])
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    deps.append(os.path.join(INCLUDE, "umhs_hip.h"))
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
+    """Compiles the sources that changed (all of them when a header did, or with ``force``), the files side by side, and links."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, running = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and not _obj_stale(os.path.join(CSRC, src), obj):
+            continue
         cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        running.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in running:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -13,7 +13,7 @@ import torch
 
 from .. import ops
 from .._ns_compat import InstantiateConfig, RayBundle
-from .umhs_dataparser import Cameras, DataparserOutputs, UMHSDataParserConfig
+from .umhs_dataparser import Cameras, DataparserOutputs, UMHSDataParserConfig, save_dataparser_transform
 from .utils.hs_dataloader import HyperspectralDataset
 
 
@@ -30,13 +30,43 @@ class UMHSDataManagerConfig(InstantiateConfig):
 
 
 class _DatasetView:
-    """What the pipeline reads off ``datamanager.train_dataset`` (umhs_pipeline.py:96-104): scene_box, metadata, len()."""
+    """What is read off ``datamanager.train_dataset`` / ``eval_dataset``: by the pipeline (umhs_pipeline.py:96-104: scene_box,
+    metadata, len()) and by nerfstudio's Trainer / viewer before step 0 (``cameras``, ``dataset[i]["image"]``, ``image_filenames``:
+    the viewer's init_scene draws the training cameras with their thumbnails)."""
 
-    def __init__(self, split, scene_box, metadata):
+    def __init__(self, split, scene_box, metadata, image_filenames=None):
         self._split, self.scene_box, self.metadata = split, scene_box, metadata
+        self.image_filenames = list(image_filenames) if image_filenames is not None else [f"frame_{i:05d}" for i in range(len(split))]
 
     def __len__(self) -> int:
         return len(self._split)
+
+    @property
+    def cameras(self):
+        return self._split.cameras
+
+    def __getitem__(self, i: int) -> Dict:
+        i = int(i)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        item = {"image_idx": i, "image": self._split.image[i]}
+        if item["image"].dtype == torch.uint8:
+            item["image"] = item["image"].float() / 255.0
+        if self._split.hs_image is not None:
+            item["hs_image"] = self._split.hs_image[i]
+        return item
+
+
+class _ResidentOutputs:
+    """``train_dataparser_outputs`` of a datamanager that was handed resident splits directly (tests, benchmarks): the metadata, and an
+    identity world transform for the Trainer's ``save_dataparser_transform``."""
+
+    def __init__(self, metadata):
+        self.metadata, self.dataparser_scale = metadata, 1.0
+        self.dataparser_transform = torch.eye(4)[:3]
+
+    def save_dataparser_transform(self, path) -> None:
+        save_dataparser_transform(self.dataparser_transform, self.dataparser_scale, path)
 
 
 class ResidentSplit:
@@ -107,6 +137,7 @@ class UMHSDataManager:
             raise NotImplementedError("patch_size > 1 (PatchPixelSampler) is not used by the reference's scripts")
         self.config, self.device, self.world_size, self.local_rank = config, torch.device(device), world_size, local_rank
         config.dataparser.num_classes = num_classes
+        eval_names = None
         if train is None:
             parser = config.dataparser.setup()
             self.train_dataparser_outputs: DataparserOutputs = parser.get_dataparser_outputs("train")
@@ -114,15 +145,17 @@ class UMHSDataManager:
             train = ResidentSplit(tr.cameras, tr.image, tr.hs_image, self.device, on_gpu=config.images_on_gpu)
             ev_out = parser.get_dataparser_outputs("val" if test_mode != "test" else "test")
             if len(ev_out.image_filenames):
+                eval_names = ev_out.image_filenames
                 ev = HyperspectralDataset(ev_out)
                 eval = ResidentSplit(ev.cameras, ev.image, ev.hs_image, self.device, on_gpu=config.images_on_gpu)
             metadata = self.train_dataparser_outputs.metadata
             self.scene_box = self.train_dataparser_outputs.scene_box
         self.train_split, self.eval_split, self.metadata = train, eval, metadata or {}
-        self.train_dataset = _DatasetView(train, getattr(self, "scene_box", None), self.metadata)
-        self.eval_dataset = _DatasetView(eval, getattr(self, "scene_box", None), self.metadata) if eval is not None else None
-        if not hasattr(self, "train_dataparser_outputs"):  # resident splits handed in directly (tests): same attribute, metadata only
-            self.train_dataparser_outputs = type("Outputs", (), {"metadata": self.metadata})()
+        names = getattr(getattr(self, "train_dataparser_outputs", None), "image_filenames", None)
+        self.train_dataset = _DatasetView(train, getattr(self, "scene_box", None), self.metadata, names)
+        self.eval_dataset = _DatasetView(eval, getattr(self, "scene_box", None), self.metadata, eval_names) if eval is not None else None
+        if not hasattr(self, "train_dataparser_outputs"):  # resident splits handed in directly (tests): same attribute, no parser behind it
+            self.train_dataparser_outputs = _ResidentOutputs(self.metadata)
         self.train_count = self.eval_count = 0
         self.generator = torch.Generator(device=self.device)
         self.generator.manual_seed(seed + local_rank)

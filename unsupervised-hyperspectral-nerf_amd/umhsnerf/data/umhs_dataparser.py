@@ -57,6 +57,17 @@ class DataparserOutputs:
     dataparser_transform: torch.Tensor  # [3,4]
     metadata: Dict = field(default_factory=dict)
 
+    def save_dataparser_transform(self, path) -> None:
+        """nerfstudio ``DataparserOutputs.save_dataparser_transform``: ``Trainer.train()`` writes ``dataparser_transforms.json`` next to
+        the checkpoints before step 0 (ns-export / ns-render read the world transform back from it)."""
+        save_dataparser_transform(self.dataparser_transform, self.dataparser_scale, path)
+
+
+def save_dataparser_transform(transform: torch.Tensor, scale: float, path) -> None:
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    path.write_text(json.dumps({"transform": torch.as_tensor(transform).tolist(), "scale": float(scale)}, indent=4))
+
 
 @dataclass
 class UMHSDataParserConfig:

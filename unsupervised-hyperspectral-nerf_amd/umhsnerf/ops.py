@@ -406,6 +406,19 @@ def _require_free(device, slot: int, who: str) -> None:
         raise RuntimeError(f"{who} would overwrite workspace slot {slot} while {held} holds data in it for a consumer that has not run")
 
 
+def field_heads_fwd_supported(spec: FieldSpec) -> bool:
+    """Can field_base_fwd / field_heads_fwd (the two-launch forward with the per-ray sums in the kernel) serve this configuration?"""
+    ok = getattr(spec, "_heads_fwd_ok", None)
+    if ok is None:  # depends on the configuration only: asked once
+        cfg = spec.cfg(False)
+        ok = bool(_hip.lib().umhs_field_heads_fwd_supported(C.byref(cfg)))
+        try:
+            spec._heads_fwd_ok = ok
+        except AttributeError:
+            pass
+    return ok
+
+
 def field_bwd_composited_supported(spec: FieldSpec) -> bool:
     ok = getattr(spec, "_composited_ok", None)
     if ok is None:  # depends on the configuration only: asked once

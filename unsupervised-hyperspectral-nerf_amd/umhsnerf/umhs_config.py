@@ -18,7 +18,8 @@ from .optim import UMHSAdam
 from .umhs_model import UMHSConfig
 from .umhs_pipeline import UMHSPipelineConfig
 
-METHOD_NAME = "umhsnerf"
+METHOD_NAME = "umhsnerf"  # umhs_config.py:36, pyproject.toml:13, every script (scripts/hotdog.sh:1)
+ALIAS_NAME = "umhs"  # what the reference's README tells users to type (README.md:11: ``ns-train umhs``)
 DESCRIPTION = "umhs method (MI355X HIP hot path)"
 
 
@@ -39,8 +40,10 @@ OPTIMIZER_FIELDS = dict(lr=2e-2, eps=1e-15)  # AdamOptimizerConfig(lr=2e-2, eps=
 SCHEDULER_FIELDS = dict(lr_final=0.00001, max_steps=30000)  # ExponentialDecaySchedulerConfig, umhs_config.py:62
 
 
-def make_nerfstudio_method():
-    """The reference's ``MethodSpecification`` with this package's classes.  Raises ImportError without nerfstudio."""
+def make_nerfstudio_method(method_name: str = METHOD_NAME):
+    """The reference's ``MethodSpecification`` with this package's classes.  Raises ImportError without nerfstudio.
+    nerfstudio keys the discovered methods by ``config.method_name``, so the ``umhs`` alias is a second specification of its own
+    (same configuration, other name), not a second entry point onto the same object."""
     from nerfstudio.configs.base_config import ViewerConfig
     from nerfstudio.engine.optimizers import AdamOptimizerConfig
     from nerfstudio.engine.schedulers import ExponentialDecaySchedulerConfig
@@ -56,7 +59,7 @@ def make_nerfstudio_method():
 
     return MethodSpecification(
         config=TrainerConfig(
-            **TRAINER_FIELDS,
+            **dict(TRAINER_FIELDS, method_name=method_name),
             pipeline=make_pipeline_config(),
             optimizers={"fields": {"optimizer": UMHSAdamOptimizerConfig(**OPTIMIZER_FIELDS),
                                    "scheduler": ExponentialDecaySchedulerConfig(**SCHEDULER_FIELDS)}},
@@ -66,11 +69,16 @@ def make_nerfstudio_method():
     )
 
 
-try:
-    umhs_method = make_nerfstudio_method()
-except ImportError:  # nerfstudio is not installed: same configuration, plain containers
-    umhs_method = SimpleNamespace(
-        config=SimpleNamespace(**TRAINER_FIELDS, pipeline=make_pipeline_config(),
+def _offline_method(method_name: str):
+    return SimpleNamespace(
+        config=SimpleNamespace(**dict(TRAINER_FIELDS, method_name=method_name), pipeline=make_pipeline_config(),
                                optimizers={"fields": {"optimizer": dict(OPTIMIZER_FIELDS, _target=UMHSAdam), "scheduler": dict(SCHEDULER_FIELDS)}}),
         description=DESCRIPTION,
     )
+
+
+try:
+    umhs_method = make_nerfstudio_method(METHOD_NAME)
+    umhs_alias_method = make_nerfstudio_method(ALIAS_NAME)
+except ImportError:  # nerfstudio is not installed: same configuration, plain containers
+    umhs_method, umhs_alias_method = _offline_method(METHOD_NAME), _offline_method(ALIAS_NAME)

@@ -134,12 +134,11 @@ class UMHSField(nn.Module):
                 self.aabb.copy_(state_dict[prefix + "aabb"].to(self.aabb.device))
                 self._aabb_host = tuple(float(v) for v in self.aabb.flatten().tolist())
                 self._spec_cache = None  # (a dict without "aabb" keeps the constructed box: parameter-only dicts load too)
-        if True:
-            mine = {prefix + k for k in self.layout.entries} | {prefix + "aabb"}
-            kids = tuple(prefix + name + "." for name, m in self._modules.items() if m is not None)
-            for key in state_dict:
-                if key.startswith(prefix) and key not in mine and not key.startswith(kids):
-                    unexpected_keys.append(key)
+        mine = {prefix + k for k in self.layout.entries} | {prefix + "aabb"}
+        kids = tuple(prefix + name + "." for name, m in self._modules.items() if m is not None)
+        for key in state_dict:
+            if key.startswith(prefix) and key not in mine and not key.startswith(kids):
+                unexpected_keys.append(key)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         """Called on the field directly, a dict of just the reference-named parameters loads too (``strict`` then concerns those

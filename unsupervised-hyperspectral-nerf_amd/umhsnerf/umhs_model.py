@@ -321,7 +321,7 @@ class UMHSModel(ModelBase):
         if packed_info is None:
             packed_info = ops.pack_info(ray_indices, num_rays)
         if (not torch.is_grad_enabled() and c.method != "rgb" and fr.origins.numel() > 0
-                and os.environ.get("UMHS_RENDER_PER_RAY", "1") != "0"):
+                and os.environ.get("UMHS_RENDER_PER_RAY", "1") != "0" and ops.field_heads_fwd_supported(self.field._spec())):
             return self._render_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
         fo = self.field(ray_samples)
         values = [fo["spectral"]]
@@ -469,7 +469,8 @@ class UMHSModel(ModelBase):
         # compositing backward folded into the field backward.  At 31 bands both forms take the same time (C2 0.82 ms), so the
         # per-sample form stays the default there.  UMHS_FUSED_BWD=0 / 1 forces either.
         knob_b = os.environ.get("UMHS_FUSED_BWD", "")
-        fused_bwd = n > 0 and knob_b != "0" and (knob_b == "1" or L.wavelengths > 32) and ops.field_bwd_composited_supported(spec)
+        fused_bwd = (n > 0 and knob_b != "0" and (knob_b == "1" or L.wavelengths > 32) and ops.field_bwd_composited_supported(spec)
+                     and ops.field_heads_fwd_supported(spec))
         split_fwd = fused_bwd
         if split_fwd:
             # mlp_base -> weights (transmittance scan) -> heads, whose kernel forms the per-ray sums itself
@@ -551,8 +552,9 @@ class UMHSModel(ModelBase):
             gt_image = gt_image[..., :3] * gt_image[..., 3:] + bgc * (1 - gt_image[..., 3:])
         return pred_image, gt_image
 
-    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
-        """umhs_model.py:329-383: 5*MSE(spectral) + rgb_loss_weight*MSE(rgb blended with a random background)."""
+    def get_loss_dict(self, outputs, batch, metrics_dict=None, background: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """umhs_model.py:329-383: 5*MSE(spectral) + rgb_loss_weight*MSE(rgb blended with a random background).
+        ``background`` (not in the reference): the [R,3] random-background draw, for callers that fix it (parity tests)."""
         loss_dict = {}
         image = batch["image"].to(self.device)
         m = self.config.method
@@ -561,7 +563,7 @@ class UMHSModel(ModelBase):
             if m == "spectral":
                 loss_dict["spectral_loss"], _ = ops.LossFn.apply(outputs["spectral"], hs, None, None, None, None, 1.0, 0.0)
             else:
-                bg = torch.rand_like(outputs["rgb"]) if self.background_color == "random" else None
+                bg = (background if background is not None else torch.rand_like(outputs["rgb"])) if self.background_color == "random" else None
                 loss_dict["spectral_loss"], loss_dict["rgb_loss"] = ops.LossFn.apply(
                     outputs["spectral"], hs, outputs["rgb"], outputs["accumulation"], bg, image, 5.0, float(self.config.rgb_loss_weight))
             return loss_dict
@@ -591,7 +593,6 @@ class UMHSModel(ModelBase):
         lazy = LazyMetrics(md)
         return lazy if (self.training and os.environ.get("UMHS_LAZY_METRICS", "1") != "0") else dict(lazy.materialize())
 
-    @torch.no_grad()
     @torch.no_grad()  # as nerfstudio's Model.get_outputs_for_camera_ray_bundle
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """umhs_model.py:593-620.  The reference walks the image in 512-ray chunks (its kernels are launch-bound there); here a

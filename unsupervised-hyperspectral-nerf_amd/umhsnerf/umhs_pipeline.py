@@ -34,18 +34,35 @@ class UMHSPipelineConfig(PipelineConfigBase):
 
 
 class _DepositedGrad(torch.autograd.Function):
-    """Loss value whose gradient w.r.t. the flat parameter has ALREADY been written to ``param.grad`` by the launch-sequence step
-    (UMHSModel.forward_backward_from_samples).  nerfstudio's Trainer calls ``loss.backward()`` on what get_train_loss_dict returns;
-    this makes that call a no-op instead of a second backward.  Needs an upstream gradient of 1 (GradScaler off: our TrainerConfig
-    sets mixed_precision=False -- the hot path is fp32)."""
+    """Loss values whose summed gradient w.r.t. the flat parameter has ALREADY been written to ``param.grad`` by the launch-sequence
+    step (UMHSModel.forward_backward_from_samples).  nerfstudio's Trainer calls ``backward()`` on the sum of what get_train_loss_dict
+    returns (through ``grad_scaler.scale``); this turns that call into the one thing left to do: what was deposited is the gradient of
+    the PLAIN sum of the losses, so an upstream gradient g != 1 -- a GradScaler's loss scale, a division by the accumulation steps --
+    multiplies the step's contribution to ``param.grad`` by g (once per step: every loss of the step must arrive with the same g; a
+    trainer that weights the losses differently needs the autograd path, UMHS_DIRECT_STEP=0, and gets an error here, not a silently
+    wrong step).  Reading g costs one host sync per loss in trainer-driven mode; UMHS_TRUST_UNIT_LOSS_SCALE=1 skips it."""
 
     @staticmethod
-    def forward(ctx, value, flat):
+    def forward(ctx, value, flat, step_state):
+        ctx.flat, ctx.step_state = flat, step_state
         return value.clone()
 
     @staticmethod
     def backward(ctx, g):
-        return None, None
+        if os.environ.get("UMHS_TRUST_UNIT_LOSS_SCALE", "0") == "1":
+            return None, None, None
+        st, gv = ctx.step_state, float(g)
+        if "g" not in st:
+            st["g"] = gv
+            if gv != 1.0:
+                if st.get("accumulated"):  # earlier micro-steps of the window are in the same buffer: their share must not be rescaled
+                    raise RuntimeError(f"loss scaled by {gv:g} inside a gradient-accumulation window: the deposited gradient cannot be "
+                                       "rescaled per micro-step (run with UMHS_DIRECT_STEP=0)")
+                ctx.flat.grad.mul_(gv)
+        elif st["g"] != gv:
+            raise RuntimeError(f"the trainer weights this step's losses differently ({st['g']:g} vs {gv:g}): the launch-sequence step has "
+                               "deposited the gradient of their plain sum (run with UMHS_DIRECT_STEP=0)")
+        return None, None, None
 
 
 class UMHSPipeline(PipelineBase):
@@ -128,20 +145,24 @@ class UMHSPipeline(PipelineBase):
     def _deposit(self, loss_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Trainer-driven mode: the trainer will call ``.backward()`` on the summed losses -- the gradient is in ``param.grad`` already."""
         flat = self._model.field.flat
-        return {k: _DepositedGrad.apply(v, flat) for k, v in loss_dict.items()}
+        step_state = {"accumulated": self._model.field._spec().grad_sink.accumulating}
+        return {k: _DepositedGrad.apply(v, flat, step_state) for k, v in loss_dict.items()}
 
-    def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None):
+    def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None, background=None):
         """One micro-step on caller-provided packed samples (bench.py, parity tests): forward, losses, backward and -- on the last
-        micro-step of the accumulation window -- the optimizer step.  Needs ``from_packed_samples`` (an own optimizer)."""
+        micro-step of the accumulation window -- the optimizer step.  Needs ``from_packed_samples`` (an own optimizer).
+        ``background``: the [R,3] draw of the random-background blend of the rgb loss (a parity test hands the oracle's draw in;
+        None = drawn from the device generator, as nerfstudio's renderer does)."""
         if self.trainer_driven:
             raise RuntimeError("train_iteration() steps the pipeline's own optimizer; a trainer-built pipeline is driven through "
                                "get_train_loss_dict()")
         last = self._begin_micro_step(self._micro)
         if self._model.direct_step_supported(batch):  # straight launch sequence, no autograd graph
-            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, num_rays, batch, packed_info)
+            outputs, loss_dict = self._model.forward_backward_from_samples(ray_samples, ray_indices, num_rays, batch, packed_info,
+                                                                           background=background)
         else:
             outputs = self._model.get_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
-            loss_dict = self._model.get_loss_dict(outputs, batch)
+            loss_dict = self._model.get_loss_dict(outputs, batch, background=background)
             sum(loss_dict.values()).backward()
         self._micro = 0 if last else self._micro + 1
         if last:
@@ -242,7 +263,9 @@ class UMHSPipeline(PipelineBase):
         error.  (The reference's debugging side effects -- printing the dict, np.save of the endmembers -- are not reproduced.)"""
         state = _strip_module_prefix(loaded_state)
         self._model.update_to_step(step)
-        result = self.load_state_dict(state, strict=False)
+        # nn.Module's loader, called explicitly: nerfstudio's Pipeline overrides load_state_dict (it splits off the "_model." keys,
+        # loads the model strictly and returns None), and a checkpoint of the reference carries modules this build does not hold
+        result = torch.nn.Module.load_state_dict(self, state, strict=False)
         missing = [k for k in result.missing_keys if ".field." in k or k.startswith("field.")]
         if missing:
             raise RuntimeError(f"checkpoint lacks field parameters: {missing}")
@@ -252,6 +275,14 @@ class UMHSPipeline(PipelineBase):
         return self._model.get_param_groups()
 
     def get_training_callbacks(self, training_callback_attributes=None) -> list:
+        # the trainer's --gradient-accumulation_steps (scripts/rgb+spectral.sh:5) lives on the Trainer, keyed by parameter group:
+        # read it here, so that on more than one rank only the window's last micro-step exchanges gradients without a second flag
+        steps = getattr(getattr(training_callback_attributes, "trainer", None), "gradient_accumulation_steps", None)
+        if steps is not None:
+            try:
+                self.gradient_accumulation_steps = max(1, int(steps["fields"]))
+            except (KeyError, TypeError):
+                pass
         return self._model.get_training_callbacks(training_callback_attributes)
 
     @torch.no_grad()
