@@ -465,6 +465,9 @@ __device__ __forceinline__ void bf_split3_scalar(float x, uint32_t& h, uint32_t&
 #ifndef BF_PF
 #define BF_PF 2
 #endif
+#ifndef BF_TMAJOR  // fragment order of gemm_bf: 0 = k-step major (every output tile finishes at the end), 1 = output-tile major
+#define BF_TMAJOR 0
+#endif
 template <int OT, int KS, int NT, int INIT>
 __device__ __forceinline__ void gemm_bf(v4f (&acc)[NT][OT], const float (&b)[NT][KS], const uint32_t* __restrict__ w,
                                         const float* __restrict__ bias, int lane) {
@@ -497,7 +500,7 @@ __device__ __forceinline__ void gemm_bf(v4f (&acc)[NT][OT], const float (&b)[NT]
   constexpr int PF = BF_PF < NF ? BF_PF : NF;
   v4u A[PF + 1][3];
   auto load = [&](int f, int slot) __attribute__((always_inline)) {
-    const int t = f % OT, S = f / OT;
+    const int t = BF_TMAJOR ? f / K8 : f % OT, S = BF_TMAJOR ? f % K8 : f / OT;
     const uint32_t* pw = w + (((t * K8 + S) * 3) * 64 + lane) * 4;
 #pragma unroll
     for (int p = 0; p < 3; ++p) A[slot][p] = *reinterpret_cast<const v4u*>(pw + p * 256);
@@ -508,7 +511,7 @@ __device__ __forceinline__ void gemm_bf(v4f (&acc)[NT][OT], const float (&b)[NT]
   for (int f = 0; f < NF; ++f) {
     if (f + PF < NF) load(f + PF, (f + PF) % (PF + 1));
     __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
-    const int t = f % OT, S = f / OT, k = f % (PF + 1);
+    const int t = BF_TMAJOR ? f / K8 : f % OT, S = BF_TMAJOR ? f % K8 : f / OT, k = f % (PF + 1);
     constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};  // hh, hm, mh, hl, lh, mm
 #pragma unroll
     for (int p = 0; p < 6; ++p)
