@@ -468,10 +468,39 @@ __device__ __forceinline__ void bf_split3_scalar(float x, uint32_t& h, uint32_t&
 #ifndef BF_TMAJOR  // fragment order of gemm_bf: 0 = k-step major (every output tile finishes at the end), 1 = output-tile major
 #define BF_TMAJOR 0
 #endif
+#ifndef BF_PIN  // 1: every step of gemm_bf pinned with full scheduling barriers, the first fragments requested in front of the B splits
+#define BF_PIN 1
+#endif
 template <int OT, int KS, int NT, int INIT>
 __device__ __forceinline__ void gemm_bf(v4f (&acc)[NT][OT], const float (&b)[NT][KS], const uint32_t* __restrict__ w,
                                         const float* __restrict__ bias, int lane) {
   constexpr int K8 = (KS + 7) / 8;
+  constexpr int NF = OT * K8;  // fragment f = S * OT + t: three 16-byte pieces each, requested BF_PF fragments ahead
+  constexpr int PF = BF_PF < NF ? BF_PF : NF;
+  v4u A[PF + 1][3];
+  auto load = [&](int f, int slot) __attribute__((always_inline)) {
+    const int t = BF_TMAJOR ? f / K8 : f % OT, S = BF_TMAJOR ? f % K8 : f / OT;
+    const uint32_t* pw = w + (((t * K8 + S) * 3) * 64 + lane) * 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) A[slot][p] = *reinterpret_cast<const v4u*>(pw + p * 256);
+  };
+  // Stamps of the backward (tools/stamp_fbwd.py) gave 33-42 cycles per v_mfma_f32_16x16x32 in every gemm of a one-wave-per-SIMD kernel,
+  // against the pipe's 16: the ISA had each fragment's ds_read_b128s right in front of its MFMAs with s_waitcnt lgkmcnt(0) in between --
+  // under register pressure the scheduler sinks the reads this loop requests ahead down to their uses (the masked barrier below only
+  // kept their order).  With BF_PIN every step is a scheduling region of its own, [reads of fragment f + PF] [products of fragment f],
+  // and the first PF fragments (and the bias tile) are requested BEFORE the bf16 splits of the B operand, ~70 VALU instructions that
+  // cover their latency: 19-20 cycles per MFMA.
+  v4f bv[OT];
+  if (BF_PIN) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < PF; ++f) load(f, f);
+    if (INIT == 2) {
+#pragma unroll
+      for (int t = 0; t < OT; ++t) bv[t] = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   v4u B[NT][3][K8];
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct)
@@ -487,30 +516,27 @@ __device__ __forceinline__ void gemm_bf(v4f (&acc)[NT][OT], const float (&b)[NT]
   if (INIT != 0) {
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
-      v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (INIT == 2) bv = *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
+      v4f bvt = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (INIT == 2) bvt = BF_PIN ? bv[t] : *reinterpret_cast<const v4f*>(bias + 16 * t + 4 * (lane >> 4));
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct][t] = bv;
+      for (int ct = 0; ct < NT; ++ct) acc[ct][t] = bvt;
     }
   }
   auto mf = [](const v4u& a, const v4u& bb, const v4f& c) __attribute__((always_inline)) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, bb), c, 0, 0, 0);
   };
-  constexpr int NF = OT * K8;  // fragment f = S * OT + t: three 16-byte pieces each, requested BF_PF fragments ahead
-  constexpr int PF = BF_PF < NF ? BF_PF : NF;
-  v4u A[PF + 1][3];
-  auto load = [&](int f, int slot) __attribute__((always_inline)) {
-    const int t = BF_TMAJOR ? f / K8 : f % OT, S = BF_TMAJOR ? f % K8 : f / OT;
-    const uint32_t* pw = w + (((t * K8 + S) * 3) * 64 + lane) * 4;
+  if (!BF_PIN) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) A[slot][p] = *reinterpret_cast<const v4u*>(pw + p * 256);
-  };
-#pragma unroll
-  for (int f = 0; f < PF; ++f) load(f, f);
+    for (int f = 0; f < PF; ++f) load(f, f);
+  }
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
+    if (BF_PIN) __builtin_amdgcn_sched_barrier(0);
     if (f + PF < NF) load(f + PF, (f + PF) % (PF + 1));
-    __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
+    if (BF_PIN)
+      __builtin_amdgcn_sched_barrier(0);
+    else
+      __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
     const int t = BF_TMAJOR ? f / K8 : f % OT, S = BF_TMAJOR ? f % K8 : f / OT, k = f % (PF + 1);
     constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};  // hh, hm, mh, hl, lh, mm
 #pragma unroll
@@ -518,6 +544,7 @@ __device__ __forceinline__ void gemm_bf(v4f (&acc)[NT][OT], const float (&b)[NT]
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) acc[ct][t] = mf(A[k][PA[p]], B[ct][PB[p]][S], acc[ct][t]);
   }
+  if (BF_PIN) __builtin_amdgcn_sched_barrier(0);
 }
 
 struct BfOffs {  // LDS dword offsets (from the bf16 region) of the converted layers' bf16x3 packs, -1: layer keeps its fp32 pack
@@ -2387,6 +2414,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
 #undef TF_GEMM_F
 #undef TF_GEMM_T
 
+#include "umhs_field_zip.h"
+
 // ---- the mixing term of the folded compositing backward, per RAY (umhs_field_bwd_composited) ---------------------------------
 // G[r][c] = sum_b d_comp[r][b] E[c][b]   (c < C, zero above): d m_n = ws_n G[ray(n)]
 __global__ __launch_bounds__(256) void field_mix_grad_kernel(const float* __restrict__ d_comp, const float* __restrict__ E, int64_t R,
@@ -3514,7 +3543,15 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
   } else {
     LAUNCH_TF_P(0, false);
   }
-  LAUNCH_TF_P(1, false);
+  static const int zip_mode = getenv("UMHS_BWD_ZIP") ? atoi(getenv("UMHS_BWD_ZIP")) : 0;
+  if ((zip_mode & 2) && (bf_mask >> 1 & 1)) {  // part 1 with the zipped instruction schedule (umhs_field_zip.h)
+    rc = set_lds(field_bwd_tfz1_kernel<TBMAX>, part[1].lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((field_bwd_tfz1_kernel<TBMAX>), dim3(grid), dim3(256), part[1].lds, umhs_s(stream), io, part[1].pd, part[1].td, img, wT,
+                       part[1].seg_f, part[1].seg_t, part[1].wt_off, bfimg, part[1].seg_b, part[1].bf_off, part[1].bo, slabs);
+  } else {
+    LAUNCH_TF_P(1, false);
+  }
 #undef LAUNCH_TF_P
 #undef LAUNCH_TF
   UMHS_CHECK_LAUNCH();

@@ -13,7 +13,9 @@ SOURCES = ("umhs_kernels.hip", "umhs_field.hip", "umhs_sampler.hip", "umhs_data.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-munsafe-fp-atomics", "-std=c++17"]
 # umhs_field.hip: MFMAs written as builtins get the VGPR C/D form even in the kernels whose register budget exceeds 256 (the
 # transpose-free backward); their long-lived dW accumulators are inline-asm MFMAs on AGPRs (see dw_row in that file)
-EXTRA_FLAGS = {"umhs_field.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# -fno-slp-vectorize: hipcc packs the two residual subtractions of a bf16 split into one v_pk_add_f32, which costs more beside MFMAs
+# than the two v_sub_f32 it replaces and needs an s_nop in front of the conversion that reads it (field backward: -8 us at C2)
+EXTRA_FLAGS = {"umhs_field.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
 
 
 def _headers():
