@@ -13,7 +13,7 @@ static void dump(const char* name, const P& plan, const O& order, int nops, int 
   }
   std::printf("%s: ok=%d  %d ops, %d slots; MFMA ops in-tile %d carried %d; VALU ops in-tile %d carried %d; last slot %d\n", name, (int)plan.ok,
               nops, nslots, m_in, m_carry, v_in, v_carry, plan.last);
-  static const char* jobs[] = {"TR", "PK", "dW_F2", "dW_F1", "dW_F0", "dW_B1", "dW_B0", "j7", "j8", "j9", "j10", "j11"};
+  static const char* jobs[] = {"TR", "PK", "dW_2", "dW_1", "dW_0", "dW_B1", "dW_B0", "j7", "j8", "j9", "j10", "j11"};
   for (int s = 0; s <= plan.last; ++s) {
     const int m = plan.m_at[s], v = plan.v_at[s];
     std::printf("%s%4d:", s == nslots ? "---- next tile ----\n" : "", s);
@@ -25,5 +25,6 @@ static void dump(const char* name, const P& plan, const O& order, int nops, int 
 
 int main() {
   dump("part 1", zp1::PLAN, zp1::ORDER, zp1::NOPS, zp1::NSLOTS);
+  dump("part 0", zp0::PLAN, zp0::ORDER, zp0::NOPS, zp0::NSLOTS);
   return 0;
 }

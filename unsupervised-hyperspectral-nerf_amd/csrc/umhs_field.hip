@@ -3532,18 +3532,48 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
         LAUNCH_TF(P_, false, false, FU_);    \
     }                                        \
   } while (0)
+  // UMHS_BWD_ZIP (A/B knob, bit p = part p): the kernels with the zipped instruction schedule (umhs_field_zip.h) -- default on.  Measured
+  // (rocprofv3, C2): part 0 114.9 -> 110.9 us, part 1 114.5 -> 106.9 us; whole backward C3 604 -> 577 us, C5 457 -> 433 us.
+  static const int zip_mode = getenv("UMHS_BWD_ZIP") ? atoi(getenv("UMHS_BWD_ZIP")) : 3;
+  // part 0: bf16x3 chain, and the band counts at which the kernel holds its registers (specular head: up to 8 band tiles, 8 only in the
+  // folded form -- the 8-tile per-sample variant spills to scratch)
+  const bool zip0 = (zip_mode & 1) && (bf_mask & 1) && (!spec || TBMAX < 8 || (TBMAX == 8 && bc != nullptr));
+#define LAUNCH_TFZ0(S_, FU_)                                                                                                          \
+  do {                                                                                                                                \
+    rc = set_lds(field_bwd_tfz0_kernel<S_, TBMAX, FU_>, part[0].lds);                                                                 \
+    if (rc) return rc;                                                                                                                \
+    hipLaunchKernelGGL((field_bwd_tfz0_kernel<S_, TBMAX, FU_>), dim3(grid), dim3(256), part[0].lds, umhs_s(stream), io, part[0].pd,  \
+                       part[0].td, img, wT, part[0].seg_f, part[0].seg_t, part[0].wt_off, bfimg, part[0].seg_b, part[0].bf_off,       \
+                       part[0].bo, slabs);                                                                                            \
+  } while (0)
+#define LAUNCH_P0(FU_)                    \
+  do {                                    \
+    if (zip0) {                           \
+      if constexpr (TBMAX <= 8) {         \
+        if (spec)                         \
+          LAUNCH_TFZ0(true, FU_);         \
+        else                              \
+          LAUNCH_TFZ0(false, FU_);        \
+      } else {                            \
+        LAUNCH_TFZ0(false, FU_);          \
+      }                                   \
+    } else {                              \
+      LAUNCH_TF_P(0, FU_);                \
+    }                                     \
+  } while (0)
   if (bc) {
     hipLaunchKernelGGL(field_mix_grad_kernel, dim3((unsigned)((bc->n_rays + 15) / 16)), dim3(256), (size_t)32 * (bc->B | 1) * 4,
                        umhs_s(stream), bc->d_comp, bc->E, bc->n_rays, bc->B, bc->C, bc->mix_g);
-    LAUNCH_TF_P(0, true);
+    LAUNCH_P0(true);
     UMHS_CHECK_LAUNCH();
     rc = umhs_composite_bwd_dots(bc->sigma, bc->t0, bc->t1, bc->packed_info, bc->n_rays, n, bc->weights, bc->dots, bc->d_acc,
                                  bc->grad_scaling, bc->d_sigma, stream);
     if (rc) return rc;
   } else {
-    LAUNCH_TF_P(0, false);
+    LAUNCH_P0(false);
   }
-  static const int zip_mode = getenv("UMHS_BWD_ZIP") ? atoi(getenv("UMHS_BWD_ZIP")) : 0;
+#undef LAUNCH_P0
+#undef LAUNCH_TFZ0
   if ((zip_mode & 2) && (bf_mask >> 1 & 1)) {  // part 1 with the zipped instruction schedule (umhs_field_zip.h)
     rc = set_lds(field_bwd_tfz1_kernel<TBMAX>, part[1].lds);
     if (rc) return rc;

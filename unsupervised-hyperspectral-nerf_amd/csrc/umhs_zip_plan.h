@@ -75,7 +75,7 @@ constexpr int S_Z0 = S_Z1 + 8 * P3;       // dZ of feature hidden 1            (
 constexpr int S_B1 = S_Z0 + 8 * P3;       // dZ of the base outputs: 1 slot + 2 pairs x P2 (behind gemm T_F0)
 constexpr int S_ZB = S_B1 + 1 + 2 * P2;   // dZ of the base hidden layer, 8 pairs x P3 (behind the fp32 gemm T_B1)
 constexpr int S_END = S_ZB + 8 * P3;      // behind gemm T_B0: stores, N_END slots
-constexpr int N_END = 4;
+constexpr int N_END = 6;
 constexpr int NSLOTS = S_END + N_END;
 
 // tiles (transposed operands): index into the tile tables below
@@ -143,7 +143,7 @@ constexpr OpTable make_ops() {
   for (int j = 0; j < 5; ++j)
     for (int i = 0; i < N_DW[j]; ++i) {
       const int to = i / (3 * DW_TI[j]), ti = i % DW_TI[j];
-      t.op[n++] = zip::Op{zip::KIND_M, J_DW_F2 + j, i, 0, {OP_PACK0 + DW_Z[j] + to, OP_PACK0 + DW_X[j] + ti, -1}, 1, -1};
+      t.op[n++] = zip::Op{zip::KIND_M, J_DW_F2 + j, i, 0, {OP_PACK0 + DW_Z[j] + to, OP_PACK0 + DW_X[j] + ti, -1}, 2, -1};
     }
   return t;
 }
@@ -192,3 +192,84 @@ static_assert(PLAN.ok, "zipped part 1: the off-chain operations do not fit into 
 static_assert(carried_in_agpr(), "zipped part 1: an operation with VGPR operand tiles was carried into the next tile");
 #endif
 }  // namespace zp1
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Part 0 (mlp_head + mlp_directional + mixing): only its two MLP stretches are zipped -- the head MLP's forward recompute and its
+// backward (the same shapes as the feature MLP's in part 1); the stretch between them (head epilogue, directional layers, band tiles,
+// head outputs) keeps the order field_bwd_tf_kernel gives it.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace zp0 {
+using zp1::M_AT;
+using zp1::P2;
+using zp1::P3;
+constexpr int S_PE = 0;                  // positional encoding: 2 slots
+constexpr int S_I = S_PE + 2;            // in27 = (pe0, pe1) (pe2, e0) (e1, e2) (e3, 0): 4 pairs x P3
+constexpr int S_X = S_I + 4 * P3;        // tile pairs (pe2, 0) (e0, e1) (e2, e3), two pieces
+constexpr int S_A1 = S_X + 3 * P2;       // head hidden 1, 8 pairs x P3     (behind gemm H0)
+constexpr int S_A2 = S_A1 + 8 * P3;      // head hidden 2, 8 pairs x P3     (behind gemm H1; gemm H2 reads all three pieces)
+constexpr int S_O = S_A2 + 8 * P3;       // d(head logits), 2 pairs x P2    (behind the unzipped middle stretch)
+constexpr int S_Z1 = S_O + 2 * P2;       // dZ of head hidden 2             (behind the fp32 gemm T_H2)
+constexpr int S_Z0 = S_Z1 + 8 * P3;      // dZ of head hidden 1             (behind gemm T_H1)
+constexpr int S_END = S_Z0 + 8 * P3;     // behind gemm T_H0: store, N_END slots
+constexpr int N_END = 6;
+constexpr int NSLOTS = S_END + N_END;
+
+enum Tile { T_X0 = 0, T_X1, T_A10, T_A11, T_A12, T_A13, T_A20, T_A21, T_A22, T_A23, T_ZO, T_Z10, T_Z11, T_Z12, T_Z13, T_Z00, T_Z01, T_Z02, T_Z03, NTILES };
+constexpr int tile_first(int t) {
+  if (t == T_X0) return S_I;
+  if (t == T_X1) return S_X + P2;
+  if (t <= T_A13) return S_A1 + 2 * P3 * (t - T_A10);
+  if (t <= T_A23) return S_A2 + 2 * P3 * (t - T_A20);
+  if (t == T_ZO) return S_O;
+  if (t <= T_Z13) return S_Z1 + 2 * P3 * (t - T_Z10);
+  return S_Z0 + 2 * P3 * (t - T_Z00);
+}
+constexpr int tile_pitch(int t) { return (t == T_X1 || t == T_ZO) ? P2 : P3; }
+constexpr int tile_ready(int t) {
+  if (t == T_X0) return S_X + M_AT + 1;  // (pe0, pe1) = in27 pair 0, then the two-piece pair (pe2, 0)
+  return tile_first(t) + tile_pitch(t) + M_AT + 1;
+}
+constexpr int tile_gate(int t) { return t <= T_X1 ? S_Z0 : 0; }  // the operands of the carried job are transposed late (see zp1)
+constexpr bool tile_colsum(int t) { return t >= T_ZO; }
+constexpr bool tile_in_agpr(int t) { return t <= T_X1 || t >= T_Z00; }  // job H0 (last in the chain) may wait for the next tile
+
+enum Job { J_TR = 0, J_PACK, J_DW_H2, J_DW_H1, J_DW_H0 };
+constexpr int NJOBS = 3;
+constexpr int N_TR = 2 * NTILES, N_PACK = NTILES;
+constexpr int N_DW[NJOBS] = {12, 48, 24};
+constexpr int NOPS = N_TR + N_PACK + 12 + 48 + 24;
+constexpr int OP_PACK0 = N_TR, OP_DW0 = N_TR + N_PACK;
+constexpr int DW_Z[NJOBS] = {T_ZO, T_Z10, T_Z00}, DW_TO[NJOBS] = {1, 4, 4};
+constexpr int DW_X[NJOBS] = {T_A20, T_A10, T_X0}, DW_TI[NJOBS] = {4, 4, 2};
+struct Order {
+  zip::Op op[NOPS];
+};
+constexpr Order make_order() {  // priority order: every tile's transposes and pack in chain order, then the dW jobs
+  Order o{};
+  for (int tile = 0; tile < NTILES; ++tile) {
+    const int rdy = tile_ready(tile) > tile_gate(tile) ? tile_ready(tile) : tile_gate(tile);
+    o.op[3 * tile + 0] = zip::Op{zip::KIND_M, J_TR, 2 * tile + 0, rdy, {-1, -1, -1}, 1, tile_first(tile)};
+    o.op[3 * tile + 1] = zip::Op{zip::KIND_M, J_TR, 2 * tile + 1, rdy, {-1, -1, -1}, 1, tile_first(tile)};
+    o.op[3 * tile + 2] = zip::Op{zip::KIND_V, J_PACK, tile, 0, {3 * tile, 3 * tile + 1, -1}, 3, -1};
+  }
+  int n = 3 * NTILES;
+  for (int j = 0; j < NJOBS; ++j)
+    for (int i = 0; i < N_DW[j]; ++i) {
+      const int to = i / (3 * DW_TI[j]), ti = i % DW_TI[j];
+      o.op[n++] = zip::Op{zip::KIND_M, J_DW_H2 + j, i, 0, {3 * (DW_Z[j] + to) + 2, 3 * (DW_X[j] + ti) + 2, -1}, 2, -1};
+    }
+  return o;
+}
+constexpr Order ORDER = make_order();
+constexpr zip::Plan<NOPS, NSLOTS> PLAN = zip::make_plan<NOPS, NSLOTS>(ORDER.op);
+constexpr bool carried_in_agpr() {
+  for (int i = 0; i < NOPS; ++i)
+    if (PLAN.slot_of[i] >= NSLOTS && !(ORDER.op[i].job >= J_DW_H2 && tile_in_agpr(DW_Z[ORDER.op[i].job - J_DW_H2]) && tile_in_agpr(DW_X[ORDER.op[i].job - J_DW_H2])))
+      return false;
+  return true;
+}
+#ifndef ZIP_PLAN_NO_ASSERT
+static_assert(PLAN.ok, "zipped part 0: the off-chain operations do not fit into two tiles' slots");
+static_assert(carried_in_agpr(), "zipped part 0: an operation with VGPR operand tiles was carried into the next tile");
+#endif
+}  // namespace zp0
