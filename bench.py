@@ -165,6 +165,90 @@ def cpu_baseline(cfg, seed, budget_s=15.0):
                 sample=f"oracle/torch_ref.py fp32 train step (fwd+loss+bwd+Adam), {R} of {cfg['R']} rays x {cfg['S']} samples, {n} steps, {dt:.2f} s/step")
 
 
+def sampler_step(cfg, device, steps=40, warm=300):
+    """The iteration `ns-train umhsnerf` runs (reference umhs_model.py:229-237,549-554): occupancy-grid update, pixel batch + ray
+    generation, the march through the grid, the density query of every candidate + visibility pruning, then the hot path on the
+    survivors, backward, Adam -- `UMHSPipeline.get_train_loss_dict` on a resident synthetic scene (6 cameras of 64 x 64 pixels on a
+    sphere around a constant-spectrum target, 4096 rays per batch, 4-level 128^3 grid; the scene of tools/profile_sampler_step.py).
+    Not the headline metric (its sample count is the scene's, not BASELINE's): reported beside it so that the share of the marcher and
+    the candidate query is on the driver's line.  -> dict(ms, rays_per_s, samples, candidates, kernels_ms, rooflines)."""
+    from umhsnerf import ops
+    from umhsnerf import sampler as smp
+    from umhsnerf.data.umhs_datamanager import ResidentSplit, UMHSDataManager, UMHSDataManagerConfig
+    from umhsnerf.data.umhs_dataparser import Cameras
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    B, Cn, R, n, H, W = cfg["B"], cfg["C"], 4096, 6, 64, 64
+    g = torch.Generator().manual_seed(3)
+    pos = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * 0.9
+    z = torch.nn.functional.normalize(pos, dim=-1)
+    x = torch.nn.functional.normalize(torch.linalg.cross(torch.tensor([[0.0, 0, 1]]).expand(n, 3), z), dim=-1)
+    c2w = torch.stack([x, torch.linalg.cross(z, x), z, pos], -1).contiguous()
+    cams = Cameras(c2w, torch.full((n,), 30.0), torch.full((n,), 30.0), torch.full((n,), W / 2), torch.full((n,), H / 2), H, W)
+    hs = torch.full((n, H, W, B), 0.6)
+    split = ResidentSplit(cams, torch.rand(n, H, W, 3, generator=g), hs, device)
+    dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=R), device=device, seed=1, train=split)
+    mc = UMHSConfig(method=cfg["method"], pred_specular=cfg["pred_specular"], temperature=cfg["temperature"], background_color="random")
+    pipe = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": list(np.linspace(400, 700, B)), "num_classes": Cn}, seed=2,
+                                            datamanager=dm)
+    with torch.no_grad():
+        split.image = pipe.model.converter(split.hs_image.view(-1, B)).view(n, H, W, 3).contiguous()
+    for step in range(warm):  # the grid settles on the target (update every 16 steps) and the model starts to fit it
+        pipe.get_train_loss_dict(step)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for step in range(warm, warm + steps):
+        out, _, _ = pipe.get_train_loss_dict(step)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    # per-operator pass (an event pair around every operator: untimed, like the main line's breakdown)
+    t_ops, t_smp = KernelTimer(ops), KernelTimer(smp)
+    for name in ("positions_fwd", "hashgrid_fwd", "field_fwd", "field_density", "enc_gather", "composite_fwd", "ray_train_tail", "composite_bwd",
+                 "field_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "adam_step_rows_range", "adam_step", "pixel_indices", "pixel_gather",
+                 "raygen"):
+        t_ops.wrap(name)
+    for name in ("march_begin", "march_finish", "visibility_mask", "compact_samples", "sample_midpoints"):
+        t_smp.wrap(name)
+    t_ops.enabled = t_smp.enabled = True
+    cand = surv = 0
+    grid = pipe.model.sampler.occupancy_grid
+    for step in range(warm + steps, warm + steps + 10):
+        out, _, _ = pipe.get_train_loss_dict(step)
+        surv += int(out["num_samples_per_ray"].sum())
+        cand += int(getattr(grid, "last_candidates", 0))
+    torch.cuda.synchronize()
+    t_ops.enabled = t_smp.enabled = False
+    ks = {**{k: v for k, v in t_ops.summary().items()}, **{k: v for k, v in t_smp.summary().items()}}
+    per_step = {k: round(v[0] * v[1] / 10.0, 4) for k, v in ks.items()}  # ms per step (an operator may run more than once per step)
+    for tm in (t_ops, t_smp):  # un-wrap: the module objects are shared with the caller
+        for name, fn in tm.orig.items():
+            setattr(tm.ops, name, fn)
+    n_surv = surv / 10.0
+    n_cand = (cand / 10.0) if cand else None
+    roofs = []
+
+    def roof(name, ops_, nbytes):
+        t = sum(per_step.get(o, 0.0) for o in ops_)
+        if t > 0 and nbytes:
+            ach = nbytes / (t * 1e-3) / 1e9
+            roofs.append(dict(kernel=name, operators=list(ops_), bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=round(ach / HBM_PEAK_GBS, 4), ms_per_step=round(t, 4)))
+
+    if n_cand:
+        # march: 16 B parked + 16 B read back + 16 B packed per candidate (t0, t1, ray index); a latency chain per ray, not a stream
+        roof("march (walk + compaction)", ("march_begin", "march_finish"), n_cand * 48)
+        # density query of every candidate: 1024 B of table rows + 128 B of features + 12 B position + 4 B sigma
+        roof("density query of the candidates", ("sample_midpoints", "positions_fwd", "hashgrid_fwd", "field_fwd", "field_density"), n_cand * (1024 + 128 + 12 + 4))
+        roof("visibility + compaction", ("visibility_mask", "compact_samples", "enc_gather"), n_cand * 13 + n_surv * (48 + 128))
+    return dict(ms=round(ms, 4), rays_per_s=round(R / ms * 1e3, 1), rays=R, survivors_per_step=round(n_surv, 1), candidates_per_step=n_cand,
+                kernels_ms=dict(sorted(per_step.items(), key=lambda kv: -kv[1])), rooflines=roofs,
+                scene="6 cameras 64x64 around a constant-spectrum target, 4-level 128^3 occupancy grid, after 300 warm-up steps",
+                note="get_train_loss_dict: grid update + pixel batch + march + candidate density query + pruning + hot path + Adam; "
+                     "kernels_ms from an untimed pass with an event pair around every operator (positions_fwd / hashgrid_fwd / field_fwd run "
+                     "for the candidates' density query AND for the survivors' forward)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +256,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampler-step", action="store_true")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -363,7 +448,11 @@ def main():
             "value": round(R * world * args.steps / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "ms_per_step_median": round(median_ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "arithmetic": "fp32 storage and accumulation; MLP chains (forward, recompute, dX) as three-piece bf16 products on the bf16 MFMA "
+                          "(24 significant bits, fp32 accumulate); dW operands as two bf16 pieces x three products (2^-16 per product, "
+                          "unbiased: tests/test_hip_fullsize.py against a float64 oracle at N = 262,144); band tiles and 16-wide layers on the fp32 MFMA",
+            "data": "synthetic",
             "config": {"workload": cfg["workload"], "rays_per_gpu": R, "samples_per_ray": S,
                        "bands": B, "endmembers": Cn, "global_rays": R * world, "hash_table": "16x2^19x2 f32", "parallelism": f"dp{world}"},
             "sanity": {"loss": {k: round(float(v), 6) for k, v in loss_dict.items()},
@@ -373,6 +462,10 @@ def main():
         }
         if dist_info is not None:
             line["dist"] = dist_info
+        if world == 1 and not args.no_sampler_step:
+            del pipe, rs, b, batch, outputs  # (the hot-path pipeline's buffers: the sampler-driven one builds its own model)
+            torch.cuda.empty_cache()
+            line["sampler_step"] = sampler_step(cfg, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, seed=42)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)

@@ -225,7 +225,7 @@ class OccGridEstimator(nn.Module):
         else:
             h = self._march_begin(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified, cone_angle)
         ri, t0, t1, pinfo = march_finish(h)
-        self.last_packed_info, self.last_pruned = pinfo, None
+        self.last_packed_info, self.last_pruned, self.last_candidates = pinfo, None, int(t0.numel())
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None and t0.numel() > 0:
             alpha_thre = min(alpha_thre, self._occs_mean())  # nerfacc reads occs.mean() per batch; it only changes in _update()
             sigmas = sigma_fn(t0, t1, ri)

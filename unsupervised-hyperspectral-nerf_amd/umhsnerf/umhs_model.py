@@ -37,8 +37,12 @@ CLASS_COLORS = torch.tensor([
 
 @dataclass
 class UMHSConfig(ModelConfigBase):
-    """``UMHSConfig(InstantNGPModelConfig)``, umhs_model.py:61-119 (same names and defaults; a nerfstudio ``ModelConfig`` when
-    nerfstudio is importable -- not an ``InstantNGPModelConfig``, whose model would build tcnn / nerfacc modules first)."""
+    """``UMHSConfig(InstantNGPModelConfig)``, umhs_model.py:61-119: same names, same defaults with ONE exception -- ``method`` defaults
+    to ``"rgb+spectral"`` where the reference has ``"rgb"`` (:108): the HIP field implements the two spectral methods (every script of
+    the reference but scripts/rgb.sh passes ``--pipeline.model.method`` anyway; ``"rgb"`` raises NotImplementedError in UMHSField).
+    ``implementation`` keeps the reference's default ``"torch"`` (:104) and its ``"tcnn"`` (scripts/hotdog.sh:7): all values select the
+    HIP kernels, whose arithmetic is the torch path's.  A nerfstudio ``ModelConfig`` when nerfstudio is importable
+    -- not an ``InstantNGPModelConfig``, whose model would build tcnn / nerfacc modules first."""
 
     _target: Type = field(default_factory=lambda: UMHSModel)
     enable_collider: bool = False
@@ -58,7 +62,7 @@ class UMHSConfig(ModelConfigBase):
     # umhs_renderer.py:108-109), and this model's rgb is converter(spectral), never a renderer's last-sample composite
     background_color: Literal["random", "last_sample", "black", "white"] = "random"
     disable_scene_contraction: bool = False
-    implementation: Literal["hip", "tcnn", "torch"] = "hip"
+    implementation: Literal["hip", "tcnn", "torch"] = "torch"
     method: Literal["rgb", "spectral", "rgb+spectral"] = "rgb+spectral"
     rgb_loss_weight: float = 1.0
     spectral_loss_weight: float = 1.0  # unused by the reference's loss too (hard-coded 5, umhs_model.py:369)
