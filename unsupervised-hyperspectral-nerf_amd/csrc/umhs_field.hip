@@ -2537,6 +2537,26 @@ __device__ __forceinline__ int tf_col(int kind, int ti, int c) {
   }
 }
 
+// First pass of the slab reduction: workgroup (item, g) adds slabs [g * TF_FOLD, (g + 1) * TF_FOLD) of one item (64 lanes x 4 floats) in a
+// fixed order and writes it as item `item` of slab g of `out`.  field_reduce_tf_kernel alone has one workgroup per item, ~76 of them: 76
+// CUs pulling 19.5 MB at ~30 GB/s each took 16.7 us; folded by all 256 CUs first, the two passes take half of that.
+constexpr int TF_FOLD = 16;
+__global__ __launch_bounds__(256) void field_slab_fold_kernel(const float* __restrict__ slabs, int nslabs, int nitems, float* __restrict__ out) {
+  __shared__ v4f part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, item = blockIdx.x, g = blockIdx.y;
+  const size_t stride = (size_t)nitems * 256, off = (size_t)item * 256 + lane * 4;
+  v4f x[TF_FOLD / 4];
+#pragma unroll
+  for (int k = 0; k < TF_FOLD / 4; ++k) {
+    const int sl = g * TF_FOLD + wv * (TF_FOLD / 4) + k;
+    x[k] = sl < nslabs ? *reinterpret_cast<const v4f*>(slabs + (size_t)sl * stride + off) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  part[wv][lane] = (x[0] + x[1]) + (x[2] + x[3]);
+  static_assert(TF_FOLD == 16, "four slabs per wave");
+  __syncthreads();
+  if (wv == 0) *reinterpret_cast<v4f*>(out + (size_t)g * stride + off) = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 // 64 outputs per workgroup; its 16 waves each sum a sixteenth of the slabs (8 loads in flight), LDS combines (one thread per output
 // walking all 256 slabs was 82 us at 128 bands: 90 workgroups of serial loads)
 __global__ __launch_bounds__(1024) void field_reduce_tf_kernel(const float* __restrict__ slabs, int nslabs, TfMap mp, PackDesc pd,
@@ -3339,7 +3359,7 @@ static int tf_nitems(int tbmax) {
 }
 static size_t bwd_slab_floats(const BwdPlan& pl, int64_t n) {  // room for either kernel family's per-workgroup slabs
   const size_t staged = (size_t)bwd_grid(n, pl.S) * pl.sl.total;
-  const size_t tf = (size_t)tf_grid(n) * tf_nitems(tf_tbmax(pl.TB) ? tf_tbmax(pl.TB) : 16) * 256;
+  const size_t tf = (size_t)(tf_grid(n) + (tf_grid(n) + 15) / 16) * tf_nitems(tf_tbmax(pl.TB) ? tf_tbmax(pl.TB) : 16) * 256;  // + the folded set
   return staged > tf ? staged : tf;
 }
 static int bf_image_dwords(const BwdPlan& pl);
@@ -3589,8 +3609,17 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
   fill_tf_map<TBMAX>(&mp, spec, pl.TB);
   if (bc)  // the endmember gradient comes from the per-ray pass below, not from the slabs
     for (int t = 0; t < TBMAX; ++t) mp.layer[SL::A_MX + t] = -1;
-  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3(SL::NACC + (SL::NDB * 16 + 63) / 64), dim3(1024), 0, umhs_s(stream),
-                     (const float*)slabs, (int)grid, mp, pl.pd_all, gp);
+  const float* rslabs = slabs;
+  int nrs = (int)grid;
+  if (grid > 2 * TF_FOLD) {  // fold the slabs 16 : 1 on every CU first (the workspace holds room for the folded set behind the slabs)
+    float* folded = slabs + (size_t)grid * SL::NITEMS * 256;
+    nrs = (int)((grid + TF_FOLD - 1) / TF_FOLD);
+    hipLaunchKernelGGL(field_slab_fold_kernel, dim3(SL::NITEMS, (unsigned)nrs), dim3(256), 0, umhs_s(stream), (const float*)slabs, (int)grid,
+                       SL::NITEMS, folded);
+    rslabs = folded;
+  }
+  hipLaunchKernelGGL(field_reduce_tf_kernel, dim3(SL::NACC + (SL::NDB * 16 + 63) / 64), dim3(1024), 0, umhs_s(stream), rslabs, nrs, mp,
+                     pl.pd_all, gp);
   UMHS_CHECK_LAUNCH();
   if (bc && bc->dE) {
     const int nchunks = (int)((bc->n_rays + MIX_CHUNK - 1) / MIX_CHUNK), CB = bc->C * bc->B;

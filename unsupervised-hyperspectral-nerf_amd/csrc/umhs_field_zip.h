@@ -58,7 +58,10 @@ __device__ __forceinline__ void dw_one(v4f* __restrict__ acc, const STile* __res
 // for every gemm of the backward instead of the pipe's 16 -- half of a tile's 14 k cycles.  Here every step is pinned with a full
 // scheduling barrier -- [reads of fragment f + PF] [the six products of fragment f] -- and the first PF fragments and the bias tile are
 // requested by gemm_bfp_pre BEFORE the VALU block in front of the gemm (they depend on the lane only), whose ~700 cycles cover them.
-constexpr int ZPF = 2;  // fragments in flight
+#ifndef ZIP_PF
+#define ZIP_PF 2
+#endif
+constexpr int ZPF = ZIP_PF;  // fragments in flight
 template <int OT, int K8>
 struct GemmPre {
   static constexpr int NF = OT * K8, PF = ZPF < NF ? ZPF : NF;
