@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 6
+#define UMHS_ABI_VERSION 7
 
 enum {
   UMHS_OK = 0,
@@ -185,14 +185,15 @@ int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
                          float* feat_logits, float* comp_spectral, float* comp_spectral2, float* comp_specular,
                          float* comp_abundances, void* scratch, size_t scratch_bytes, void* workspace, size_t workspace_bytes,
                          int pack_ready, umhs_stream_t stream);
-/* feat_logits (optional, [N,16]): the feature_mlp logits, saved so that umhs_field_bwd can run its heads as two kernels   */
-/* (head MLP + directional + mixing / feature MLP) with every weight pack LDS-resident; NULL there = one fused kernel.       */
+/* feat_logits ([N,16]): the feature_mlp logits, saved because umhs_field_bwd runs its heads as two kernels (head MLP +    */
+/* directional + mixing / feature MLP + mlp_base), the second one starting from the logits.  Optional in the forward,       */
+/* REQUIRED by umhs_field_bwd (NULL there: UMHS_ERR_ARG; there is no single-kernel backward any more, ABI 7).                */
 /* builds the pack image ahead of time (parameters only): then pass pack_ready = 1 with the same workspace */
 int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
                            size_t workspace_bytes, umhs_stream_t stream);
 
-/* Backward.  Recomputes the activations per tile; the only saved forward tensors are enc, sigma_raw [N] and    */
-/* emb [N,15] (both outputs of umhs_field_fwd).  d_sigma [N] and d_spectral [N,B] are the gradients w.r.t. the   */
+/* Backward.  Recomputes the activations per tile; the only saved forward tensors are enc, sigma_raw [N],       */
+/* emb [N,15] and feat_logits [N,16] (all outputs of umhs_field_fwd).  d_sigma [N] and d_spectral [N,B] are the gradients w.r.t. the   */
 /* forward's sigma / spectral outputs; d_emb_ext [N,15] (optional) is an extra gradient on emb.  Writes d_enc     */
 /* (same strides as enc) and the parameter gradients (OVERWRITTEN, not accumulated).                             */
 /* workspace: umhs_field_bwd_workspace_bytes.                                                                    */
@@ -317,22 +318,6 @@ int umhs_ray_train_tail(const float* spectral, const float* M, const float* endm
                         float w_spectral, float w_rgb, int rgb_loss, float* rgb, float* depth_clipped, float* seg_probs,
                         float* seg_raw, float* seg_pred, float* losses2, float* d_spectral, float* d_accumulation,
                         void* scratch, size_t scratch_bytes, umhs_stream_t stream);
-
-/* umhs_ray_train_fused: the whole per-ray part of a TRAINING step in one launch = umhs_composite_fwd (all streams; stream 0 is   */
-/*   the spectral stream that carries the losses, umhs_model.py:245-304) + umhs_ray_train_tail (:254-313,358-370) +               */
-/*   umhs_composite_bwd of stream 0 incl. scale_gradients_by_distance_squared (:241-242).  Same arguments as those three; outputs  */
-/*   weights [N], accumulation [R], depth_raw [R] (optional, unclipped), every streams->out[s] [R,k_s], the tail's rgb /           */
-/*   depth_clipped / seg_*, losses2, and the gradients d_values0 [N,k_0], d_sigma [N], d_accumulation [R] (rgb_loss only).        */
-/*   scratch: umhs_ray_train_fused_scratch_bytes() bytes, ZERO before the first call (left zeroed again).  k_0 <= 256.           */
-size_t umhs_ray_train_fused_scratch_bytes(void);
-int umhs_ray_train_fused(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info, int64_t n_rays,
-                         int64_t n, const umhs_value_streams* streams, const float* M, const float* endmembers,
-                         const float* tmid_minmax2, const float* class_colors, const float* gt_spectral, const float* gt_rgb,
-                         const float* background, int n_classes, float alpha, float w_spectral, float w_rgb, int rgb_loss,
-                         int grad_scaling, float* weights, float* accumulation, float* depth_raw, float* rgb, float* depth_clipped,
-                         float* seg_probs, float* seg_raw, float* seg_pred, float* losses2, float* d_values0, float* d_sigma,
-                         float* d_accumulation, void* scratch, size_t scratch_bytes, umhs_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------ */
 /* occupancy-grid ray marcher.  Replaces nerfacc.OccGridEstimator.sampling (traverse_grids +        */
 /* render_visibility_from_density, CUDA only) behind nerfstudio's VolumetricSampler, umhs_model.py:201-209,229-237. */

@@ -276,9 +276,12 @@ def test_field_bwd(C, B, spec, temp):
     d_enc_ref, pgrads = grads[0], dict(zip(names, grads[1:]))
     d_flat = torch.zeros_like(flat)
     e = enc.detach().view(N, 16, 2).permute(1, 0, 2).contiguous()
-    d_enc = ops.field_bwd(fs, flat, e.to(DEV), True, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV),
-                          sraw.detach().view(-1).contiguous().to(DEV), emb.detach().contiguous().to(DEV),
-                          cot_d.view(-1).to(DEV), cot_s.to(DEV), cot_e.to(DEV), d_flat)
+    args = (fs, flat, e.to(DEV), True, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV))
+    # (the backward starts from the feature logits the forward saves: part 0 = mlp_head + mlp_directional + mixing, part 1 = feature_mlp + mlp_base)
+    logits = ops.field_fwd(*args, want_emb=True, want_logits=True)["feat_logits"]
+    assert logits is not None and logits.shape == (N, 16)
+    d_enc = ops.field_bwd(*args, sraw.detach().view(-1).contiguous().to(DEV), emb.detach().contiguous().to(DEV),
+                          cot_d.view(-1).to(DEV), cot_s.to(DEV), cot_e.to(DEV), d_flat, feat_logits=logits)
     assert_close("d_enc", d_enc.permute(1, 0, 2).reshape(N, 32), d_enc_ref, 5e-5)
     key = {"base_w": "mlp_base.mlp", "head_w": "mlp_head", "feat_w": "feature_mlp", "dir_w": "mlp_directional",
            "base_b": "mlp_base.mlp", "head_b": "mlp_head", "feat_b": "feature_mlp", "dir_b": "mlp_directional"}
@@ -292,17 +295,10 @@ def test_field_bwd(C, B, spec, temp):
             assert float(got.abs().max()) == 0.0, k
         else:
             assert_close(f"grad {k}", got, gref, 5e-5)
-    # the split heads backward (two kernels, all packs LDS-resident; taken when the forward's feature logits are handed over and
-    # B <= 32) must give the same gradients as the fused kernel above
-    args = (fs, flat, e.to(DEV), True, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV))
-    logits = ops.field_fwd(*args, want_emb=True, want_logits=True)["feat_logits"]
-    assert logits is not None and logits.shape == (N, 16)
-    d_flat2 = torch.zeros_like(flat)
-    d_enc2 = ops.field_bwd(*args, sraw.detach().view(-1).contiguous().to(DEV), emb.detach().contiguous().to(DEV),
-                           cot_d.view(-1).to(DEV), cot_s.to(DEV), cot_e.to(DEV), d_flat2, feat_logits=logits)
-    assert_close("d_enc (split)", d_enc2.permute(1, 0, 2).reshape(N, 32), d_enc_ref, 5e-5)
-    tail = layout.offset("mlp_base.mlp.layers.0.weight")
-    assert_close("param grads (split vs fused)", d_flat2[tail:], d_flat[tail:], 2e-5)
+    # a missing feature-logits array is an argument error, not a silent other path
+    with pytest.raises(RuntimeError, match="umhs_field_bwd"):
+        ops.field_bwd(*args, sraw.detach().view(-1).contiguous().to(DEV), emb.detach().contiguous().to(DEV), cot_d.view(-1).to(DEV),
+                      cot_s.to(DEV), cot_e.to(DEV), torch.zeros_like(flat), feat_logits=None)
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -643,7 +639,7 @@ def test_field_bwd_overwrites_every_parameter_gradient(C, B, spec):
     out = ops.field_fwd(fs, flat, enc, True, wpos, dev_args[1], sel, want_emb=True, want_logits=True)
     g = torch.Generator().manual_seed(1)
     ds, dsp = torch.rand(N, generator=g).to(DEV), torch.rand(N, B, generator=g).to(DEV)
-    for logits in (None, out["feat_logits"]):
+    for logits in (out["feat_logits"],):
         ref = torch.zeros_like(flat)
         ops.field_bwd(fs, flat, enc, True, wpos, dev_args[1], sel, out["sigma_raw"], out["emb"], ds, dsp, None, ref, feat_logits=logits)
         dirty = torch.full_like(flat, float("nan"))

@@ -80,19 +80,20 @@ def test_full_size_field_bwd_linearity_and_reduction():
     o, d, s, e = b["origins"], b["directions"], b["starts"].view(-1), b["ends"].view(-1)
     wpos, pos01, sel = ops.positions_fwd(o, d, s, e, fs)
     enc = ops.hashgrid_fwd(pos01, layout.view(flat, "mlp_base.encoder.hash_table"), fs.scalings, 19, True)
-    out = ops.field_fwd(fs, flat, enc, True, wpos, d, sel, want_emb=True)
+    out = ops.field_fwd(fs, flat, enc, True, wpos, d, sel, want_emb=True, want_logits=True)
     g = torch.Generator(device=DEV).manual_seed(1)
     ds, dsp = torch.rand(N, device=DEV, generator=g) - 0.5, torch.rand(N, B, device=DEV, generator=g) - 0.5
 
     def bwd(dsig, dspec, idx=None):
         df = torch.zeros_like(flat)
         if idx is None:
-            de = ops.field_bwd(fs, flat, enc, True, wpos, d, sel, out["sigma_raw"], out["emb"], dsig, dspec, None, df)
+            de = ops.field_bwd(fs, flat, enc, True, wpos, d, sel, out["sigma_raw"], out["emb"], dsig, dspec, None, df,
+                               feat_logits=out["feat_logits"])
         else:
             sl = lambda t: t[idx].contiguous()
             ee = enc[:, idx].contiguous()
             de = ops.field_bwd(fs, flat, ee, True, sl(wpos), sl(d), sl(sel), sl(out["sigma_raw"]), sl(out["emb"]), sl(dsig),
-                               sl(dspec), None, df)
+                               sl(dspec), None, df, feat_logits=sl(out["feat_logits"]))
         return df[layout.offset("mlp_base.mlp.layers.0.weight"):], de
 
     g_full, de_full = bwd(ds, dsp)

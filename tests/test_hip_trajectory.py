@@ -147,7 +147,7 @@ def test_trunc_exp_clamped_backward(bias):
     args = (fs, flat, e, True, pos.to(DEV), b["directions"].to(DEV), sel.float().to(DEV))
     fwd = ops.field_fwd(*args, want_emb=True, want_logits=True)
     assert_close("sigma (forward is NOT clamped)", fwd["sigma"], density.view(-1), 2e-5)
-    for logits in (None, fwd["feat_logits"]):  # fused and split heads backward share the base kernel; run both launch sequences
+    for logits in (fwd["feat_logits"],):
         d_flat = torch.zeros_like(flat)
         d_enc = ops.field_bwd(*args, fwd["sigma_raw"], fwd["emb"], cot_d.view(-1).to(DEV), torch.zeros(N, B, device=DEV), None, d_flat,
                               feat_logits=logits)
@@ -188,7 +188,7 @@ def test_field_bwd_many_bands_many_workgroups(C, B, spec, temp):
     fwd = ops.field_fwd(*args, want_emb=True, want_logits=True)
     assert_close("spectral", fwd["spectral"], outs["spectral"].view(N, B), 2e-5)
     key = {"base": "mlp_base.mlp", "head": "mlp_head", "feat": "feature_mlp", "dir": "mlp_directional"}
-    for logits in (None, fwd["feat_logits"]):
+    for logits in (fwd["feat_logits"],):
         d_flat = torch.full_like(flat, float("nan"))
         d_flat[: layout.offset("mlp_base.mlp.layers.0.weight")] = 0
         d_enc = ops.field_bwd(*args, fwd["sigma_raw"], fwd["emb"], cot_d.view(-1).to(DEV), cot_s.to(DEV), None, d_flat, feat_logits=logits)
@@ -366,45 +366,3 @@ def test_hashgrid_bwd_propagates_non_finite_gradients(bad):
     keep = torch.ones(16 * T, dtype=torch.bool, device=DEV)
     keep[7 * T:8 * T] = False
     assert torch.equal(got[keep], clean[keep])
-
-
-@pytest.mark.parametrize("R,S,B,C,spec,both,ragged", [(512, 64, 31, 6, True, True, False), (300, 40, 141, 4, False, True, True),
-                                                       (257, 100, 128, 9, True, False, True), (64, 7, 3, 15, True, True, True)])
-def test_fused_ray_kernel_equals_composite_tail_composite(R, S, B, C, spec, both, ragged):
-    """umhs_ray_train_fused == umhs_composite_fwd + umhs_ray_train_tail + umhs_composite_bwd: the same arithmetic in the same order, so
-    every forward output is BIT-identical; the gradients agree to rounding (FMA contraction differs between kernels) and the two loss
-    sums associate differently (2e-6).  Ragged rays incl. empty
-    ones, rays longer than a wavefront, 3 .. 141 bands."""
-    ops = _ops()
-    g = torch.Generator().manual_seed(R + B)
-    b = T.synthetic_batch(R, S, B, seed=R, ragged=ragged)
-    d = dev(b)
-    N = b["origins"].shape[0]
-    t0, t1 = d["starts"].view(-1), d["ends"].view(-1)
-    sigma = (torch.rand(N, generator=g) * 30).to(DEV)
-    vals = [torch.rand(N, B, generator=g).to(DEV)] + ([torch.rand(N, B, generator=g).to(DEV), torch.rand(N, B, generator=g).to(DEV)] if spec else [])
-    vals.append(torch.rand(N, C, generator=g).to(DEV))
-    pinfo = ops.pack_info(d["ray_indices"], R)
-    M = T.colour_matrix(np.linspace(400, 700, B)).to(DEV)
-    E = torch.rand(C, B, generator=g).to(DEV)
-    colors = torch.rand(16, 3, generator=g).to(DEV)
-    gt_rgb = torch.rand(R, 3, generator=g).to(DEV) if both else None
-    bg = torch.rand(R, 3, generator=g).to(DEV) if both else None
-    mm = ops.tmid_minmax(t0, t1)
-    w = (5.0, 1.0) if both else (1.0, 0.0)
-    weights, acc, depth, comp = ops.composite_fwd(sigma, t0, t1, pinfo, vals)
-    rgb, dclip, probs, raw, pred, losses, d_spec, d_acc = ops.ray_train_tail(comp[0], M, E, acc, depth, mm, colors, d["gt_spectral"], gt_rgb, bg,
-                                                                                0.2, w[0], w[1], both)
-    d_sigma, d_values = ops.composite_bwd(sigma, t0, t1, pinfo, weights, vals[:1], [d_spec], [True], d_acc, True)
-    f = ops.ray_train_fused(sigma, t0, t1, pinfo, vals, M, E, mm, colors, d["gt_spectral"], gt_rgb, bg, 0.2, w[0], w[1], both, True)
-    fw, facc, fcomp, frgb, fdclip, fprobs, fraw, fpred, flosses, fdv, fds = f
-    assert torch.equal(fw, weights) and torch.equal(facc, acc)
-    for a_, b_ in zip(fcomp, comp):
-        assert torch.equal(a_, b_)
-    assert torch.equal(frgb, rgb) and torch.equal(fdclip, dclip) and torch.equal(fprobs, probs) and torch.equal(fraw, raw) and torch.equal(fpred, pred)
-    # the gradient expressions are contracted into FMAs per kernel by the compiler: equal to rounding, not to the bit
-    torch.testing.assert_close(fdv, d_values[0], rtol=1e-5, atol=1e-12)
-    torch.testing.assert_close(fds, d_sigma, rtol=1e-4, atol=1e-9 * float(d_sigma.abs().max()))
-    torch.testing.assert_close(flosses, losses, rtol=2e-6, atol=0)
-    f2 = ops.ray_train_fused(sigma, t0, t1, pinfo, vals, M, E, mm, colors, d["gt_spectral"], gt_rgb, bg, 0.2, w[0], w[1], both, True)
-    assert torch.equal(f2[8], flosses)  # the loss sums are reproducible run to run (fixed order; the arrival counter re-arms itself)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Field forward alone at the bench shapes; UMHS_FWD_VARIANT=0/2 selects the bf16x3 / fp32 chain.  GPU box."""
+"""Field forward alone at the bench shapes; GPU box."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd"), os.path.join(ROOT, "tools")]
@@ -31,4 +31,4 @@ for name in os.environ.get("CASES", "C2,C3,C5").split(","):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"{name}: N={N} B={B} C={C} spec={spec} variant={os.environ.get('UMHS_FWD_VARIANT', '0')}: field_fwd {us:8.1f} us = {us * 1e3 / N:.2f} ns/sample", flush=True)
+    print(f"{name}: N={N} B={B} C={C} spec={spec}: field_fwd {us:8.1f} us = {us * 1e3 / N:.2f} ns/sample", flush=True)

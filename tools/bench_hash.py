@@ -23,4 +23,4 @@ for name, pos in (("ray batch", pos_ray), ("uniform", torch.rand(262144, 3, devi
         ops.hashgrid_fwd(pos, table, fs.scalings, 19, True)
     e1.record()
     torch.cuda.synchronize()
-    print(f"UMHS_HG_LPT={os.environ.get('UMHS_HG_LPT', '1')} {name:10s}: hashgrid_fwd {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us", flush=True)
+    print(f"{name:10s}: hashgrid_fwd {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us", flush=True)

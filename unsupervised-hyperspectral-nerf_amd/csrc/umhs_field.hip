@@ -941,825 +941,6 @@ __global__ __launch_bounds__(256) void field_pack_all_kernel(PackJob jb) {
   }
 }
 
-// ---- LDS staging of [sample][feature] tiles.  Row stride FS = 16 (mod 32) makes the transposed ds_read_b32 of the dW
-// products conflict-free (4 consecutive rows per instruction); but ds_write_b128 works in 8-lane groups = 8 consecutive
-// rows, and rows r, r+2 would share banks (4-way conflict, measured: SQ_LDS_BANK_CONFLICT > SQ_ACTIVE_INST_LDS).  So each
-// row is rotated by 4*((r>>1)&3) floats inside its padding: 8 consecutive rows hit 8 distinct bank quads, while the two
-// rows of a read pair keep a common rotation.  Every tile therefore needs FS >= features + 12.
-__device__ __forceinline__ int swz(int row) { return 4 * ((row >> 1) & 3); }
-
-template <int OT>
-__device__ __forceinline__ void stage_hid(float* st, int FS, int row, int q, const float (&x)[OT * 4]) {
-#pragma unroll
-  for (int t = 0; t < OT; ++t)
-    *reinterpret_cast<v4f*>(st + row * FS + swz(row) + 16 * t + 4 * q) = v4f{x[4 * t], x[4 * t + 1], x[4 * t + 2], x[4 * t + 3]};
-}
-
-// dW tile pairs of one layer, split over the WAVES waves of the workgroup.  TI divides WAVES, so every pair of a
-// wave shares its X tile (ti = wave % TI, read once per k-step); its Z tiles are to = wave/TI + idx*(WAVES/TI).
-//   D[out=16to+4q+r][in=16ti+j] += sum_samples Z[sample][out] * X[sample][in]        (16*WAVES staged samples)
-template <int NACC, int WAVES>
-__device__ __forceinline__ void dw_accum(v4f (&acc)[NACC], const float* __restrict__ stZ, int FSz,
-                                         const float* __restrict__ stX, int FSx, int TO, int TI, int wave, int lane) {
-#ifdef UMHS_ABL_NO_DW
-  return;
-#endif
-  const int j = lane & 15, q = lane >> 4;
-  const int ti = wave % TI, to0 = wave / TI, tstep = WAVES / TI;
-  if (to0 >= TO) return;
-  // row 4ks+q is rotated by swz = 4*(((2ks)&3) + (q>>1)) = 8*(ks&1) + 4*(q>>1)
-  const float* __restrict__ px = stX + q * FSx + 16 * ti + j + 4 * (q >> 1);
-  const float* __restrict__ pz = stZ + q * FSz + 16 * to0 + j + 4 * (q >> 1);
-  // Operands of U k-steps are read together and one batch ahead of the MFMAs that consume them (left to itself hipcc emits
-  // ds_read -> s_waitcnt lgkmcnt(0) -> MFMA per k-step: the LDS latency, ~3x the MFMA's own 32 cycles, on every step).
-  constexpr int U = 4, NB = (4 * WAVES) / U;
-  float bx[2][U], az[2][U][NACC];
-  auto fetch = [&](int batch, int slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ks = batch * U + u;
-      bx[slot][u] = px[4 * ks * FSx + 8 * (ks & 1)];
-#pragma unroll
-      for (int idx = 0; idx < NACC; ++idx)
-        az[slot][u][idx] = (to0 + idx * tstep < TO) ? pz[4 * ks * FSz + 8 * (ks & 1) + 16 * idx * tstep] : 0.0f;
-    }
-  };
-  fetch(0, 0);
-#pragma unroll
-  for (int batch = 0; batch < NB; ++batch) {
-    if (batch + 1 < NB) fetch(batch + 1, (batch + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0x7ff & ~0x180);  // LDS reads stay where they are; everything else may move
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int idx = 0; idx < NACC; ++idx)
-        if (to0 + idx * tstep < TO) acc[idx] = MFMA(az[batch & 1][u][idx], bx[batch & 1][u], acc[idx]);
-  }
-}
-
-// Layers with fewer tile pairs than waves (16-wide outputs or inputs: 1, 2 or 4 pairs): instead of 1-4 waves walking all
-// 32 k-steps while the others wait at the next barrier, every wave takes pair w % np and a 1/(WAVES/np) share of the k-steps
-// (samples); the slab reduce adds the partial tiles.  np = TO*TI must divide WAVES.
-template <int WAVES>
-__device__ __forceinline__ void dw_accum_ks(v4f (&acc)[1], const float* __restrict__ stZ, int FSz, const float* __restrict__ stX,
-                                            int FSx, int TO, int TI, int wave, int lane) {
-#ifdef UMHS_ABL_NO_DW
-  return;
-#endif
-  const int j = lane & 15, q = lane >> 4;
-  const int np = TO * TI, parts = WAVES / np, pair = wave % np, part = wave / np;
-  const int to = pair / TI, ti = pair % TI;
-  const int nks = (4 * WAVES) / parts, ks0 = part * nks;  // >= 4 k-steps, a multiple of 4
-  const float* __restrict__ px = stX + q * FSx + 16 * ti + j + 4 * (q >> 1);
-  const float* __restrict__ pz = stZ + q * FSz + 16 * to + j + 4 * (q >> 1);
-  for (int kb = ks0; kb < ks0 + nks; kb += 4) {
-    float b[4], a[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int ks = kb + u;
-      b[u] = px[4 * ks * FSx + 8 * (ks & 1)], a[u] = pz[4 * ks * FSz + 8 * (ks & 1)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[0] = MFMA(a[u], b[u], acc[0]);
-  }
-}
-
-// partial column sum of a staged tile: thread -> (column, row group); the slab reduce adds the row groups.
-// COLS > 0 (split kernels, which have registers to spare): compile-time width -> the row loop is fully unrolled with 4 LDS reads
-// in flight and one base address + immediate offsets (as a runtime loop hipcc serialises read -> wait -> add, ~100 cycles a row).
-template <int WAVES, int COLS = 0>
-__device__ __forceinline__ float col_sum_part(const float* __restrict__ st, int FS, int cols, int tid) {
-#ifdef UMHS_ABL_NO_DW
-  return 0.0f;
-#endif
-  constexpr int S = 16 * WAVES, NTH = 64 * WAVES;
-  if constexpr (COLS > 0) {
-    constexpr int RG = NTH / COLS, RPG = (S + RG - 1) / RG;
-    static_assert(S % RG == 0 && (RPG % 8 == 0 || RPG == 4), "row groups must keep the swizzle phase compile-time");
-    const int rg = tid / COLS, col = tid - rg * COLS;
-    const float* __restrict__ pb = st + rg * RPG * FS + col + (RPG == 4 ? 8 * (rg & 1) : 0);
-    float s = 0.0f;
-#pragma unroll
-    for (int i0 = 0; i0 < RPG; i0 += 4) {
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = pb[(i0 + i) * FS + 4 * (((i0 + i) >> 1) & 3)];
-      s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    return s;
-  } else {
-    const int RG = NTH / cols, rg = tid / cols, col = tid - rg * cols;
-    if (rg >= RG) return 0.0f;
-    const int rpg = (S + RG - 1) / RG, r0 = rg * rpg, r1 = min(S, r0 + rpg);
-    float s = 0.0f;
-    for (int r = r0; r < r1; ++r) s += st[r * FS + swz(r) + col];
-    return s;
-  }
-}
-
-// epilogue: fold a per-thread partial bias sum (thread = row group x column) over the row groups in LDS and write
-// the `cols` column totals of layer l to the workgroup's slab
-template <int WAVES>
-__device__ __forceinline__ void flush_db(float v, float* red, float* slab_db, int cols, int tid) {
-  red[tid] = v;
-  __syncthreads();
-  if (tid < cols) {
-    const int RG = (64 * WAVES) / cols;
-    float s = 0.0f;
-    for (int rg = 0; rg < RG; ++rg) s += red[rg * cols + tid];
-    slab_db[tid] = s;
-  }
-  __syncthreads();
-}
-
-// slab layout (floats) of one workgroup's partial parameter gradients
-struct SlabLayout {
-  int off[NLAYERS];   // dW tiles of layer l: [wave WAVES][nacc][64 lanes][4]
-  int nacc[NLAYERS];
-  int TO[NLAYERS], TI[NLAYERS];
-  int off_db[NLAYERS];  // [64*WAVES] per-thread partial bias sums (thread = row group x column)
-  int cols[NLAYERS];    // padded output width 16*OT (0: layer absent)
-  int waves, total_w, total;
-};
-
-template <int N>
-__device__ __forceinline__ void zero_acc(v4f (&a)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) a[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-}
-// K-split layers (dw_accum_ks): wave w holds a partial tile of pair w % np; fold the WAVES/np partials into wave (w % np) once,
-// at the end of the launch, through the (now free) staging region -- the slab and its reduce keep the one-owner-per-tile form.
-template <int WAVES>
-__device__ __forceinline__ void fold_ksplit(v4f (&acc)[1], float* st, int np, int wave, int lane) {
-  BSYNC();
-  *reinterpret_cast<v4f*>(st + (wave * 64 + lane) * 4) = acc[0];
-  BSYNC();
-  if (wave < np) {
-    v4f s = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int w = wave; w < WAVES; w += np) s += *reinterpret_cast<const v4f*>(st + (w * 64 + lane) * 4);
-    acc[0] = s;
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void store_acc(const v4f (&a)[N], float* slab, int off, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) *reinterpret_cast<v4f*>(slab + off + ((wave * N + i) * 64 + lane) * 4) = a[i];
-}
-
-// ---------------------------------------------------------------------------------------------
-// heads
-// ---------------------------------------------------------------------------------------------
-template <bool SPEC, int NA, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_heads_kernel(FieldIO io, PackDesc pd, TPackDesc td,
-                                                                               const float* __restrict__ wT, SlabLayout sl,
-                                                                               float* __restrict__ slabs, int stage_off,
-                                                                               int FSd, const float* __restrict__ image,
-                                                                               int first) {
-  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-  load_fwd_image(lds_raw, pd, image, first);  // pd carries ALL layers' offsets; only [first, total) is resident
-  float* const lds = lds_raw - first;
-  float* const st = lds_raw + stage_off;
-  constexpr int NT = 1, S = 16 * WAVES, NH0 = 8 / WAVES, NH1 = 16 / WAVES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
-  const int row = wave * 16 + j;
-  v4f aH0[NH0], aH1[NH1], aH2[1], aF0[NH0], aF1[NH1], aF2[1], aD0[1], aD1[NA], aMX[NA];
-  zero_acc(aH0), zero_acc(aH1), zero_acc(aH2), zero_acc(aF0), zero_acc(aF1), zero_acc(aF2), zero_acc(aD0);
-  zero_acc(aD1), zero_acc(aMX);
-  float dbH0 = 0.f, dbH1 = 0.f, dbH2 = 0.f, dbF0 = 0.f, dbF1 = 0.f, dbF2 = 0.f, dbD0 = 0.f, dbD1 = 0.f;
-  BSYNC();
-  const int64_t ntiles = (io.n + S - 1) / S;
-  const int C = io.C, B = io.B, TB = io.TB;
-  float* const stZ = st;            // [S][<=80]
-  float* const stX = st + S * 80;   // [S][<=80]
-  float* const stZd = st;           // [S][FSd]   dZ of mlp_directional's output layer
-  float* const stXh = st + S * FSd; // [S][16]    hidden of mlp_directional
-  float* const stXm = stXh + S * 48;  // [S][16]  mixing coefficients m   (16-wide tiles use FS = 48: 16 + 12 + pad)
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t n0 = tile * S;
-    int64_t n = n0 + row;
-    const bool ok = n < io.n;
-    if (!ok) n = io.n - 1;
-    // =================== forward recompute of the heads (base-MLP output comes from the forward pass) ========
-    float in27[NT][7], dir28[NT][7];
-    {
-      float pe[3];
-      pe_slots(pe, io.wpos[3 * n], io.wpos[3 * n + 1], io.wpos[3 * n + 2], q);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = 4 * q + r - 1;
-        in27[0][3 + r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) has zero weight
-      }
-      if (SPEC) {
-        float sh[4];
-        sh_slots(sh, io.dirs[3 * n], io.dirs[3 * n + 1], io.dirs[3 * n + 2], q);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
-      }
-    }
-    // The feature MLP's hidden activations are NOT kept across the head MLP's backward: they are recomputed right
-    // before their own backward (+92 MFMAs per tile) so that 32 fewer registers are live -- at 2 waves/SIMD the
-    // kernel is capped at 256 VGPRs and every spilled dword costs a scratch round trip behind s_waitcnt vmcnt.
-    float a1h[NT][16], a2h[NT][16];
-    v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
-    gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
-    relu_to<4, NT>(a1h, t4);
-    gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
-    relu_to<4, NT>(a2h, t4);
-    gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
-    {
-      float a1f[NT][16], a2f[NT][16];
-      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
-      relu_to<4, NT>(a1f, t4);
-      gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
-      relu_to<4, NT>(a2f, t4);
-      gemm_pack<1, 16, NT, 2>(fl4, a2f, lds + pd.L[L_F2].off_w, lds + pd.L[L_F2].off_b, lane);
-    }
-    HeadState<NT> hs;
-    head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
-    float hdir[NT][4];
-    if (SPEC) {
-      v4f d4[NT][1];
-      gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
-      relu_to<1, NT>(hdir, d4);
-    }
-    // =================== phase A: band tiles (mixing + specular tail) ============================
-    v4f dm4[NT][1], dhd4[NT][1];
-    dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    float ds1 = 0.0f;
-    BSYNC();  // previous tile's staging reads are done
-    for (int t = 0; t < TB; ++t) {
-      float dsp[NT][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int b = 16 * t + 4 * q + r;
-        dsp[0][r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
-      }
-      gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
-      if (SPEC) {
-        v4f sc[NT][1];
-        gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
-        float dzd[NT][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sp = sigmoidf_(sc[0][0][r]);
-          ds1 += dsp[0][r] * sp;
-          dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
-        }
-        gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
-        *reinterpret_cast<v4f*>(stZd + row * FSd + swz(row) + 16 * t + 4 * q) = v4f{dzd[0][0], dzd[0][1], dzd[0][2], dzd[0][3]};
-      }
-    }
-    if (SPEC) *reinterpret_cast<v4f*>(stXh + row * 48 + swz(row) + 4 * q) = v4f{hdir[0][0], hdir[0][1], hdir[0][2], hdir[0][3]};
-    *reinterpret_cast<v4f*>(stXm + row * 48 + swz(row) + 4 * q) = v4f{hs.m[0][0], hs.m[0][1], hs.m[0][2], hs.m[0][3]};
-    ds1 = xq_sum(ds1);
-    BSYNC();
-    if (SPEC) {
-      dw_accum<NA, WAVES>(aD1, stZd, FSd, stXh, 48, TB, 1, wave, lane);
-      dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
-    }
-    {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: its rows are samples)
-      // Branch-free clamped addresses, U k-steps of loads in flight, one batch ahead of their MFMAs: a conditional load per
-      // MFMA made hipcc wait for global memory (s_waitcnt vmcnt(0)) 32 times per round.
-      const float* __restrict__ pm = stXm + q * 48 + j + 4 * (q >> 1);
-      constexpr int U = 8, NBAT = (4 * WAVES) / U;
-      float ga[2][U][NA], gb[2][U];
-      int bcol[NA];
-      bool bok[NA];
-#pragma unroll
-      for (int idx = 0; idx < NA; ++idx) {
-        const int to = wave + idx * WAVES, b = 16 * to + j;
-        bok[idx] = to < TB && b < B;
-        bcol[idx] = bok[idx] ? b : 0;
-      }
-      auto fetch = [&](int batch, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ks = batch * U + u;
-          const int64_t ns = n0 + 4 * ks + q;
-          const int64_t nsc = ns < io.n ? ns : io.n - 1;
-          gb[slot][u] = ns < io.n ? pm[4 * ks * 48 + 8 * (ks & 1)] : 0.0f;  // rows past the end carry zero weight
-#pragma unroll
-          for (int idx = 0; idx < NA; ++idx) ga[slot][u][idx] = io.d_spectral[nsc * B + bcol[idx]];
-        }
-      };
-      fetch(0, 0);
-#pragma unroll
-      for (int batch = 0; batch < NBAT; ++batch) {
-        if (batch + 1 < NBAT) fetch(batch + 1, (batch + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0x7ff & ~0x1b0);  // loads (VMEM / LDS reads) keep their place
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int idx = 0; idx < NA; ++idx)
-            if (wave + idx * WAVES < TB) aMX[idx] = MFMA(bok[idx] ? ga[batch & 1][u][idx] : 0.0f, gb[batch & 1][u], aMX[idx]);
-      }
-    }
-    // =================== phase B: heads ===========================================================
-    float dhs[NT][4], dfl[NT][4];
-    {
-      const float inv_t = 1.0f / io.temperature;
-      float da[4], dot = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float dmr = dm4[0][0][r];
-        const float dsg = dmr * hs.ab[0][r];
-        dhs[0][r] = dsg * hs.sg[0][r] * (1.0f - hs.sg[0][r]);
-        da[r] = (4 * q + r < C) ? dmr * hs.sg[0][r] : 0.0f;
-        dot += hs.ab[0][r] * da[r];
-      }
-      dot = xq_sum(dot);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 4 * q + r;
-        float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) * inv_t : 0.0f;
-        if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
-        dfl[0][r] = g;
-        if (c >= C) dhs[0][r] = 0.0f;
-      }
-    }
-    if (SPEC) {  // mlp_directional hidden layer: dZ = d_hd * [hd > 0]; X = dir28 (staging order = reference order)
-      float dz[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
-      BSYNC();
-      *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dz[0], dz[1], dz[2], dz[3]};
-      *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 4 * q) = v4f{dir28[0][0], dir28[0][1], dir28[0][2], dir28[0][3]};
-#pragma unroll
-      for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 16 + 3 * q + s] = dir28[0][4 + s];
-      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      BSYNC();
-      dw_accum<1, WAVES>(aD0, stZ, 48, stX, 48, 1, 2, wave, lane);
-      dbD0 += col_sum_part<WAVES>(stZ, 48, 16, tid);
-    }
-    v4f dbo4[NT][1];
-    dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    // one 27->64->64->out MLP (head or feature): dW for its three layers, dX down to the base-MLP slots
-    auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f(&acc2)[1],
-                        v4f(&acc1)[NH1], v4f(&acc0)[NH0], float& db2, float& db1, float& db0, int t2, int t1,
-                        int t0) __attribute__((always_inline)) {
-      BSYNC();
-      *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
-      stage_hid<4>(stX, 80, row, q, a2[0]);
-      BSYNC();
-      dw_accum<1, WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
-      db2 += col_sum_part<WAVES>(stZ, 48, 16, tid);
-      v4f g4[NT][4];
-      gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
-      float dz1[NT][16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-      BSYNC();
-      stage_hid<4>(stZ, 80, row, q, dz1[0]);
-      stage_hid<4>(stX, 80, row, q, a1[0]);
-      BSYNC();
-      dw_accum<NH1, WAVES>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
-      db1 += col_sum_part<WAVES>(stZ, 80, 64, tid);
-      gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
-      float dz0[NT][16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-      BSYNC();
-      stage_hid<4>(stZ, 80, row, q, dz0[0]);
-      // X = [pe(12) | base-MLP output slots(16)] : 28 columns, 28..31 zero
-#pragma unroll
-      for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 3 * q + s] = in27[0][s];
-      *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
-      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      BSYNC();
-      dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
-      db0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
-      gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
-    };
-    mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
-    {
-      float a1f[NT][16], a2f[NT][16];
-      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
-      relu_to<4, NT>(a1f, t4);
-      gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
-      relu_to<4, NT>(a2f, t4);
-      mlp3_bwd(dfl, a2f, a1f, aF2, aF1, aF0, dbF2, dbF1, dbF0, T_F2, T_F1, T_F0);
-    }
-    if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
-  }
-  float* const slab = slabs + (size_t)blockIdx.x * sl.total;
-  store_acc(aH0, slab, sl.off[L_H0], wave, lane), store_acc(aH1, slab, sl.off[L_H1], wave, lane);
-  store_acc(aH2, slab, sl.off[L_H2], wave, lane), store_acc(aF0, slab, sl.off[L_F0], wave, lane);
-  store_acc(aF1, slab, sl.off[L_F1], wave, lane), store_acc(aF2, slab, sl.off[L_F2], wave, lane);
-  store_acc(aD0, slab, sl.off[L_D0], wave, lane), store_acc(aD1, slab, sl.off[L_D1], wave, lane);
-  store_acc(aMX, slab, sl.off[L_MX], wave, lane);
-  BSYNC();  // staging region is free: reuse it for the bias fold
-  flush_db<WAVES>(dbH0, st, slab + sl.off_db[L_H0], sl.cols[L_H0], tid);
-  flush_db<WAVES>(dbH1, st, slab + sl.off_db[L_H1], sl.cols[L_H1], tid);
-  flush_db<WAVES>(dbH2, st, slab + sl.off_db[L_H2], sl.cols[L_H2], tid);
-  flush_db<WAVES>(dbF0, st, slab + sl.off_db[L_F0], sl.cols[L_F0], tid);
-  flush_db<WAVES>(dbF1, st, slab + sl.off_db[L_F1], sl.cols[L_F1], tid);
-  flush_db<WAVES>(dbF2, st, slab + sl.off_db[L_F2], sl.cols[L_F2], tid);
-  if (SPEC) {
-    flush_db<WAVES>(dbD0, st, slab + sl.off_db[L_D0], sl.cols[L_D0], tid);
-    flush_db<WAVES>(dbD1, st, slab + sl.off_db[L_D1], sl.cols[L_D1], tid);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// heads, split in two (B <= 32): PART 0 = mlp_head + mlp_directional + mixing, PART 1 = feature_mlp.  The forward pass saves the
-// feature logits, so PART 0 does not need the feature MLP at all and hands PART 1 the gradient of those logits (d_fl).  Each
-// part keeps BOTH its forward packs and its transposed packs in LDS beside the staging buffers (the fused kernel reads the
-// transposed packs from L2), holds half the dW accumulators, and recomputes nothing twice.
-// ---------------------------------------------------------------------------------------------
-template <int PART, bool SPEC>
-__global__ __launch_bounds__(512, 2) void field_bwd_part_kernel(FieldIO io, PackDesc pd, TPackDesc td, SlabLayout sl,
-                                                                float* __restrict__ slabs, int wt_off, int stage_off, int FSd,
-                                                                const float* __restrict__ image, const float* __restrict__ wT_image,
-                                                                ImgSegs seg_f, ImgSegs seg_t) {
-  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-  constexpr int WAVES = 8, NA = 1;
-  copy_segs(lds_raw, image, seg_f);             // pd / td carry offsets local to this part's LDS image
-  copy_segs(lds_raw + wt_off, wT_image, seg_t);
-  float* const lds = lds_raw;
-  const float* const wT = lds_raw + wt_off;
-  float* const st = lds_raw + stage_off;
-  constexpr int NT = 1, S = 16 * WAVES, NH0 = 8 / WAVES, NH1 = 16 / WAVES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
-  const int row = wave * 16 + j;
-  v4f aH0[NH0], aH1[NH1], aH2[1], aF0[NH0], aF1[NH1], aF2[1], aD0[1], aD1[NA], aMX[NA];
-  zero_acc(aH0), zero_acc(aH1), zero_acc(aH2), zero_acc(aF0), zero_acc(aF1), zero_acc(aF2), zero_acc(aD0);
-  zero_acc(aD1), zero_acc(aMX);
-  float dbH0 = 0.f, dbH1 = 0.f, dbH2 = 0.f, dbF0 = 0.f, dbF1 = 0.f, dbF2 = 0.f, dbD0 = 0.f, dbD1 = 0.f;
-  BSYNC();
-  const int64_t ntiles = (io.n + S - 1) / S;
-  const int C = io.C, B = io.B, TB = io.TB;
-  float* const stZ = st;            // [S][<=80]
-  float* const stX = st + S * 80;   // [S][<=80]
-  float* const stZd = st;           // [S][FSd]   dZ of mlp_directional's output layer
-  float* const stXh = st + S * FSd; // [S][16]    hidden of mlp_directional
-  float* const stXm = stXh + S * 48;  // [S][16]  mixing coefficients m   (16-wide tiles use FS = 48: 16 + 12 + pad)
-  // per-sample inputs of a tile, requested one tile ahead (see field_bwd_base_kernel: every wave reaches these loads together)
-  struct TileIn {
-    float w[3], d[3], emb[4];
-    v4f x;  // part 0: the saved feature logits; part 1: d(feature logits) from part 0
-  };
-  auto fetch = [&](int64_t tile, TileIn& in) {
-    int64_t n = tile * S + row;
-    if (n >= io.n) n = io.n - 1;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) in.w[s] = io.wpos[3 * n + s];
-    if (SPEC) {
-#pragma unroll
-      for (int s = 0; s < 3; ++s) in.d[s] = io.dirs[3 * n + s];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = 4 * q + r - 1;
-      in.emb[r] = e >= 0 ? io.emb_in[n * 15 + e] : 0.0f;  // slot 0 (sigma_raw) has zero weight
-    }
-    in.x = *reinterpret_cast<const v4f*>((PART == 0 ? io.feat_logits_in : io.d_fl) + n * 16 + 4 * q);
-  };
-  TileIn cur, nxt;
-#ifdef UMHS_TF_STAMP
-  const unsigned long long k_t1 = __builtin_readcyclecounter();
-#endif
-  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t n0 = tile * S;
-    int64_t n = n0 + row;
-    const bool ok = n < io.n;
-    if (!ok) n = io.n - 1;
-    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
-    // =================== forward recompute of the heads (base-MLP output comes from the forward pass) ========
-    float in27[NT][7], dir28[NT][7];
-    {
-      float pe[3];
-      pe_slots(pe, cur.w[0], cur.w[1], cur.w[2], q);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) in27[0][s] = pe[s];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) in27[0][3 + r] = cur.emb[r];
-      if (SPEC) {
-        float sh[4];
-        sh_slots(sh, cur.d[0], cur.d[1], cur.d[2], q);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dir28[0][s] = sh[s];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) dir28[0][4 + s] = pe[s];
-      }
-    }
-    float a1h[NT][16], a2h[NT][16];
-    v4f t4[NT][4], hd4[NT][1], fl4[NT][1];
-    v4f dbo4[NT][1];
-    dbo4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    // one 27->64->64->out MLP (head or feature): dW for its three layers, dX down to the base-MLP slots
-    auto mlp3_bwd = [&](const float(&dzo)[NT][4], const float(&a2)[NT][16], const float(&a1)[NT][16], v4f(&acc2)[1],
-                        v4f(&acc1)[NH1], v4f(&acc0)[NH0], float& db2, float& db1, float& db0, int t2, int t1,
-                        int t0) __attribute__((always_inline)) {
-      BSYNC();
-      *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzo[0][0], dzo[0][1], dzo[0][2], dzo[0][3]};
-      stage_hid<4>(stX, 80, row, q, a2[0]);
-      BSYNC();
-      dw_accum_ks<WAVES>(acc2, stZ, 48, stX, 80, 1, 4, wave, lane);
-      db2 += col_sum_part<WAVES, 16>(stZ, 48, 16, tid);
-      v4f g4[NT][4];
-      gemm_pack<4, 4, NT, 1>(g4, dzo, wT + td.L[t2].off, nullptr, lane);
-      float dz1[NT][16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dz1[0][i] = a2[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-      BSYNC();
-      stage_hid<4>(stZ, 80, row, q, dz1[0]);
-      stage_hid<4>(stX, 80, row, q, a1[0]);
-      BSYNC();
-      dw_accum<NH1, WAVES>(acc1, stZ, 80, stX, 80, 4, 4, wave, lane);
-      db1 += col_sum_part<WAVES, 64>(stZ, 80, 64, tid);
-      gemm_pack<4, 16, NT, 1>(g4, dz1, wT + td.L[t1].off, nullptr, lane);
-      float dz0[NT][16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dz0[0][i] = a1[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-      BSYNC();
-      stage_hid<4>(stZ, 80, row, q, dz0[0]);
-      // X = [pe(12) | base-MLP output slots(16)] : 28 columns, 28..31 zero
-#pragma unroll
-      for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 3 * q + s] = in27[0][s];
-      *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 12 + 4 * q) = v4f{in27[0][3], in27[0][4], in27[0][5], in27[0][6]};
-      if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      BSYNC();
-      dw_accum<NH0, WAVES>(acc0, stZ, 80, stX, 48, 4, 2, wave, lane);
-      db0 += col_sum_part<WAVES, 64>(stZ, 80, 64, tid);
-      gemm_pack<1, 16, NT, 0>(dbo4, dz0, wT + td.L[t0].off, nullptr, lane);
-    };
-    if constexpr (PART == 0) {
-      gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_H0].off_w, lds + pd.L[L_H0].off_b, lane);
-      relu_to<4, NT>(a1h, t4);
-      gemm_pack<4, 16, NT, 2>(t4, a1h, lds + pd.L[L_H1].off_w, lds + pd.L[L_H1].off_b, lane);
-      relu_to<4, NT>(a2h, t4);
-      gemm_pack<1, 16, NT, 2>(hd4, a2h, lds + pd.L[L_H2].off_w, lds + pd.L[L_H2].off_b, lane);
-      fl4[0][0] = cur.x;  // saved by the forward pass
-      HeadState<NT> hs;
-      head_epilogue<NT, SPEC>(hs, hd4, fl4, C, io.temperature, lane);
-      float hdir[NT][4];
-      if (SPEC) {
-        v4f d4[NT][1];
-        gemm_pack<1, 7, NT, 2>(d4, dir28, lds + pd.L[L_D0].off_w, lds + pd.L[L_D0].off_b, lane);
-        relu_to<1, NT>(hdir, d4);
-      }
-      // =================== phase A: band tiles (mixing + specular tail) ============================
-      v4f dm4[NT][1], dhd4[NT][1];
-      dm4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      dhd4[0][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      float ds1 = 0.0f;
-      BSYNC();  // previous tile's staging reads are done
-      for (int t = 0; t < TB; ++t) {
-        float dsp[NT][4];
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = 16 * t + 4 * q + r;
-          dsp[0][r] = (ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
-        }
-        gemm_pack<1, 4, NT, 0>(dm4, dsp, wT + td.L[T_MX].off + t * 256, nullptr, lane);
-        if (SPEC) {
-          v4f sc[NT][1];
-          gemm_pack<1, 4, NT, 2>(sc, hdir, lds + pd.L[L_D1].off_w + t * 256, lds + pd.L[L_D1].off_b + 16 * t, lane);
-          float dzd[NT][4];
-  #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sp = sigmoidf_(sc[0][0][r]);
-            ds1 += dsp[0][r] * sp;
-            dzd[0][r] = dsp[0][r] * hs.s1[0] * sp * (1.0f - sp);
-          }
-          gemm_pack<1, 4, NT, 0>(dhd4, dzd, wT + td.L[T_D1].off + t * 256, nullptr, lane);
-          *reinterpret_cast<v4f*>(stZd + row * FSd + swz(row) + 16 * t + 4 * q) = v4f{dzd[0][0], dzd[0][1], dzd[0][2], dzd[0][3]};
-        }
-      }
-      if (SPEC) *reinterpret_cast<v4f*>(stXh + row * 48 + swz(row) + 4 * q) = v4f{hdir[0][0], hdir[0][1], hdir[0][2], hdir[0][3]};
-      *reinterpret_cast<v4f*>(stXm + row * 48 + swz(row) + 4 * q) = v4f{hs.m[0][0], hs.m[0][1], hs.m[0][2], hs.m[0][3]};
-      ds1 = xq_sum(ds1);
-      BSYNC();
-      if (SPEC) {
-        dw_accum_ks<WAVES>(aD1, stZd, FSd, stXh, 48, TB, 1, wave, lane);
-        dbD1 += col_sum_part<WAVES>(stZd, FSd, 16 * TB, tid);
-      }
-      {  // dE^T[b][c] += sum_n d_spectral[n][b] * m[n][c]   (A operand straight from global: its rows are samples)
-        // K-split like dw_accum_ks: wave w takes band tile w % TB and a 1/(WAVES/TB) share of the 32 k-steps; clamped, branch-free
-        // addresses and all loads of the share in flight before its MFMAs.
-        const float* __restrict__ pm = stXm + q * 48 + j + 4 * (q >> 1);
-        const int to = wave % TB, part = wave / TB, nks = (4 * WAVES) / (WAVES / TB), ks0 = part * nks;
-        const int bcol = 16 * to + j;
-        const bool bok = bcol < B;
-        const int bc = bok ? bcol : 0;
-        for (int kb = ks0; kb < ks0 + nks; kb += 4) {
-          float ga[4], gb[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int ks = kb + u;
-            const int64_t ns = n0 + 4 * ks + q;
-            const int64_t nsc = ns < io.n ? ns : io.n - 1;
-            gb[u] = ns < io.n ? pm[4 * ks * 48 + 8 * (ks & 1)] : 0.0f;  // rows past the end carry zero weight
-            ga[u] = io.d_spectral[nsc * B + bc];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) aMX[0] = MFMA(bok ? ga[u] : 0.0f, gb[u], aMX[0]);
-        }
-      }
-      // =================== phase B: heads ===========================================================
-      float dhs[NT][4], dfl[NT][4];
-      {
-        const float inv_t = 1.0f / io.temperature;
-        float da[4], dot = 0.0f;
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dmr = dm4[0][0][r];
-          const float dsg = dmr * hs.ab[0][r];
-          dhs[0][r] = dsg * hs.sg[0][r] * (1.0f - hs.sg[0][r]);
-          da[r] = (4 * q + r < C) ? dmr * hs.sg[0][r] : 0.0f;
-          dot += hs.ab[0][r] * da[r];
-        }
-        dot = xq_sum(dot);
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 4 * q + r;
-          float g = (c < C) ? hs.ab[0][r] * (da[r] - dot) * inv_t : 0.0f;
-          if (SPEC && c == C) g = ds1 * hs.s1[0] * (1.0f - hs.s1[0]);
-          dfl[0][r] = g;
-          if (c >= C) dhs[0][r] = 0.0f;
-        }
-      }
-      if (ok) *reinterpret_cast<v4f*>(io.d_fl + n * 16 + 4 * q) = v4f{dfl[0][0], dfl[0][1], dfl[0][2], dfl[0][3]};
-      if (SPEC) {  // mlp_directional hidden layer: dZ = d_hd * [hd > 0]; X = dir28 (staging order = reference order)
-        float dz[4];
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) dz[r] = hdir[0][r] > 0.0f ? dhd4[0][0][r] : 0.0f;
-        BSYNC();
-        *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dz[0], dz[1], dz[2], dz[3]};
-        *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 4 * q) = v4f{dir28[0][0], dir28[0][1], dir28[0][2], dir28[0][3]};
-  #pragma unroll
-        for (int s = 0; s < 3; ++s) stX[row * 48 + swz(row) + 16 + 3 * q + s] = dir28[0][4 + s];
-        if (q == 0) *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 28) = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-        BSYNC();
-        dw_accum_ks<WAVES>(aD0, stZ, 48, stX, 48, 1, 2, wave, lane);
-        dbD0 += col_sum_part<WAVES, 16>(stZ, 48, 16, tid);
-      }
-      mlp3_bwd(dhs, a2h, a1h, aH2, aH1, aH0, dbH2, dbH1, dbH0, T_H2, T_H1, T_H0);
-      if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0][0];
-    } else {
-      float dfl[NT][4];
-      const v4f g = cur.x;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dfl[0][r] = ok ? g[r] : 0.0f;  // rows past the end must not contribute
-      {
-        float a1f[NT][16], a2f[NT][16];
-        gemm_pack<4, 7, NT, 2>(t4, in27, lds + pd.L[L_F0].off_w, lds + pd.L[L_F0].off_b, lane);
-        relu_to<4, NT>(a1f, t4);
-        gemm_pack<4, 16, NT, 2>(t4, a1f, lds + pd.L[L_F1].off_w, lds + pd.L[L_F1].off_b, lane);
-        relu_to<4, NT>(a2f, t4);
-        mlp3_bwd(dfl, a2f, a1f, aF2, aF1, aF0, dbF2, dbF1, dbF0, T_F2, T_F1, T_F0);
-      }
-      if (ok) *reinterpret_cast<v4f*>(io.d_bo2 + n * 16 + 4 * q) = dbo4[0][0];
-    }
-    cur = nxt;
-  }
-  if constexpr (PART == 0) {
-    fold_ksplit<WAVES>(aH2, st, 4, wave, lane), fold_ksplit<WAVES>(aMX, st, TB, wave, lane);
-    if (SPEC) fold_ksplit<WAVES>(aD0, st, 2, wave, lane), fold_ksplit<WAVES>(aD1, st, TB, wave, lane);
-  } else {
-    fold_ksplit<WAVES>(aF2, st, 4, wave, lane);
-  }
-  float* const slab = slabs + (size_t)blockIdx.x * sl.total;
-  if constexpr (PART == 0) {
-    store_acc(aH0, slab, sl.off[L_H0], wave, lane), store_acc(aH1, slab, sl.off[L_H1], wave, lane);
-    store_acc(aH2, slab, sl.off[L_H2], wave, lane), store_acc(aD0, slab, sl.off[L_D0], wave, lane);
-    store_acc(aD1, slab, sl.off[L_D1], wave, lane), store_acc(aMX, slab, sl.off[L_MX], wave, lane);
-  } else {
-    store_acc(aF0, slab, sl.off[L_F0], wave, lane), store_acc(aF1, slab, sl.off[L_F1], wave, lane);
-    store_acc(aF2, slab, sl.off[L_F2], wave, lane);
-  }
-  BSYNC();  // staging region is free: reuse it for the bias fold
-  if constexpr (PART == 0) {
-    flush_db<WAVES>(dbH0, st, slab + sl.off_db[L_H0], sl.cols[L_H0], tid);
-    flush_db<WAVES>(dbH1, st, slab + sl.off_db[L_H1], sl.cols[L_H1], tid);
-    flush_db<WAVES>(dbH2, st, slab + sl.off_db[L_H2], sl.cols[L_H2], tid);
-    if (SPEC) {
-      flush_db<WAVES>(dbD0, st, slab + sl.off_db[L_D0], sl.cols[L_D0], tid);
-      flush_db<WAVES>(dbD1, st, slab + sl.off_db[L_D1], sl.cols[L_D1], tid);
-    }
-  } else {
-    flush_db<WAVES>(dbF0, st, slab + sl.off_db[L_F0], sl.cols[L_F0], tid);
-    flush_db<WAVES>(dbF1, st, slab + sl.off_db[L_F1], sl.cols[L_F1], tid);
-    flush_db<WAVES>(dbF2, st, slab + sl.off_db[L_F2], sl.cols[L_F2], tid);
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// base
-// ---------------------------------------------------------------------------------------------
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void field_bwd_base_kernel(FieldIO io, PackDesc pd, TPackDesc td,
-                                                                              const float* __restrict__ wT, SlabLayout sl,
-                                                                              float* __restrict__ slabs, int stage_off) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  build_fwd_image(lds, pd);
-  float* const st = lds + stage_off;
-  constexpr int NT = 1, S = 16 * WAVES, NB0 = 8 / WAVES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
-  const int row = wave * 16 + j;
-  v4f aB0[NB0], aB1[1];
-  zero_acc(aB0), zero_acc(aB1);
-  float dbB0 = 0.f, dbB1 = 0.f;
-  BSYNC();
-  float* const stZ = st;
-  float* const stX = st + S * 80;
-  const int64_t ntiles = (io.n + S - 1) / S;
-  // The inputs of a tile (hash features, upstream gradients) are requested one tile ahead: with 2 waves per SIMD and four
-  // barriers per tile every wave of the workgroup reaches these loads together, and nothing else would cover their latency.
-  struct TileIn {
-    float2 e[4];
-    v4f g, g2;
-    float raw, dsig, sel;
-  };
-  auto fetch = [&](int64_t tile, TileIn& in) {
-    int64_t n = tile * S + row;
-    if (n >= io.n) n = io.n - 1;
-#pragma unroll
-    for (int lv = 0; lv < 4; ++lv) in.e[lv] = *reinterpret_cast<const float2*>(io.enc + n * io.sn + (int64_t)(4 * q + lv) * io.sl);
-    in.g = *reinterpret_cast<const v4f*>(io.d_bo + n * 16 + 4 * q);
-    in.g2 = io.d_bo2 ? *reinterpret_cast<const v4f*>(io.d_bo2 + n * 16 + 4 * q) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    in.raw = io.sigma_raw_in[n], in.dsig = io.d_sigma[n], in.sel = io.sel[n];
-  };
-  TileIn cur, nxt;
-#ifdef UMHS_TF_STAMP
-  const unsigned long long k_t1 = __builtin_readcyclecounter();
-#endif
-  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, cur);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int64_t n = tile * S + row;
-    const bool ok = n < io.n;
-    if (!ok) n = io.n - 1;
-    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
-    float encf[NT][8];
-#pragma unroll
-    for (int lv = 0; lv < 4; ++lv) encf[0][2 * lv] = cur.e[lv].x, encf[0][2 * lv + 1] = cur.e[lv].y;
-    v4f t4[NT][4];
-    float h[NT][16];
-    gemm_pack<4, 8, NT, 2>(t4, encf, lds + pd.L[L_B0].off_w, lds + pd.L[L_B0].off_b, lane);
-    relu_to<4, NT>(h, t4);
-    float dzb1[NT][4];
-    {
-      v4f g = ok ? cur.g : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      if (io.d_bo2 && ok) g += cur.g2;  // split heads: feature_mlp's share
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float gr = g[r];
-        const int e = 4 * q + r - 1;
-        if (io.d_emb && ok && e >= 0) gr += io.d_emb[n * 15 + e];
-        dzb1[0][r] = gr;
-      }
-      if (q == 0) {  // slot 0: d sigma_raw = d sigma * selector * exp(clamp(raw, -15, 15))   (trunc_exp backward)
-        dzb1[0][0] = ok ? cur.dsig * cur.sel * expf(fminf(fmaxf(cur.raw, -15.0f), 15.0f)) : 0.0f;
-      }
-    }
-    BSYNC();
-    *reinterpret_cast<v4f*>(stZ + row * 48 + swz(row) + 4 * q) = v4f{dzb1[0][0], dzb1[0][1], dzb1[0][2], dzb1[0][3]};
-    stage_hid<4>(stX, 80, row, q, h[0]);
-    BSYNC();
-    dw_accum_ks<WAVES>(aB1, stZ, 48, stX, 80, 1, 4, wave, lane);  // 4 tile pairs: K-split over the waves (8-wave form)
-    dbB1 += col_sum_part<WAVES>(stZ, 48, 16, tid);
-    v4f g4[NT][4];
-    gemm_pack<4, 4, NT, 1>(g4, dzb1, wT + td.L[T_B1].off, nullptr, lane);
-    float dzb0[NT][16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dzb0[0][i] = h[0][i] > 0.0f ? g4[0][i >> 2][i & 3] : 0.0f;
-    BSYNC();
-    stage_hid<4>(stZ, 80, row, q, dzb0[0]);
-    *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 8 * q) = v4f{encf[0][0], encf[0][1], encf[0][2], encf[0][3]};
-    *reinterpret_cast<v4f*>(stX + row * 48 + swz(row) + 8 * q + 4) = v4f{encf[0][4], encf[0][5], encf[0][6], encf[0][7]};
-    BSYNC();
-    dw_accum<NB0, WAVES>(aB0, stZ, 80, stX, 48, 4, 2, wave, lane);
-    dbB0 += col_sum_part<WAVES>(stZ, 80, 64, tid);
-    v4f de4[NT][2];
-    gemm_pack<2, 16, NT, 1>(de4, dzb0, wT + td.L[T_B0].off, nullptr, lane);
-    if (ok && io.d_enc) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int lv = 8 * t + 2 * q + rr;  // feature e = 16t+4q+r -> level e>>1, component e&1
-          *reinterpret_cast<float2*>(io.d_enc + n * io.sn + (int64_t)lv * io.sl) =
-              make_float2(de4[0][t][2 * rr], de4[0][t][2 * rr + 1]);
-        }
-    }
-    cur = nxt;
-  }
-  fold_ksplit<WAVES>(aB1, st, 4, wave, lane);
-  float* const slab = slabs + (size_t)blockIdx.x * sl.total;
-  store_acc(aB0, slab, sl.off[L_B0], wave, lane), store_acc(aB1, slab, sl.off[L_B1], wave, lane);
-  BSYNC();
-  flush_db<WAVES>(dbB0, st, slab + sl.off_db[L_B0], sl.cols[L_B0], tid);
-  flush_db<WAVES>(dbB1, st, slab + sl.off_db[L_B1], sl.cols[L_B1], tid);
-}
-
 // =============================================================================================
 // Transpose-free backward (the default): two kernels, no LDS staging and no barrier inside their loops.
 //   PART 0: mlp_head + mlp_directional + mixing.  Reads the forward's emb and feature logits, emits d_fl [N,16] (gradient of
@@ -1939,11 +1120,11 @@ extern "C" int umhs_debug_tf_stamps_clear() {
   } while (0)
 #endif
 
-// BF: the fp32 chain (forward recompute + dX) of every layer with >= 7 k-steps runs as three-piece bf16 products (gemm_bf); the
-// 4-step layers (the band tiles' products, the out-layer transposes) keep the fp32 MFMA.
+// The chain (forward recompute + dX) runs on the fp32 MFMA here (v_mfma_f32_16x16x4_f32: UMHS_BWD_TF=1, and the shapes whose bf16x3
+// kernels do not hold their registers); the three-piece bf16 form of the chain lives in umhs_field_zip.h.
 // (Two waves per SIMD for the part-0 kernel without specular head and with the per-ray mixing -- its accumulators alone would fit --
 // was tried: 128 + 128 registers, 103 spilled, 654 vs 485 us at 141 bands.)
-template <int PART, bool SPEC, int TBMAX, bool BF, bool FUSED = false>
+template <int PART, bool SPEC, int TBMAX, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDesc pd, TPackDesc td, const float* __restrict__ image,
                                                               const float* __restrict__ wT_image, ImgSegs seg_f, ImgSegs seg_t,
                                                               int wt_off, const float* __restrict__ bf_image, ImgSegs seg_b, int bf_off,
@@ -1963,7 +1144,6 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
   __builtin_amdgcn_s_waitcnt(0);
   const unsigned long long k_tb = __builtin_readcyclecounter();
 #endif
-  if (BF) copy_segs(lds + bf_off, bf_image, seg_b);
 #ifdef UMHS_TF_STAMP
   __builtin_amdgcn_s_waitcnt(0);
   const unsigned long long k_tc = __builtin_readcyclecounter();
@@ -1975,21 +1155,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
     g_tf_stamp[PART][16] = k_ta - k_t0, g_tf_stamp[PART][17] = k_tb - k_ta, g_tf_stamp[PART][19] = k_tc - k_tb, g_tf_stamp[PART][23] = k_td - k_tc;
 #endif
   const float* const wT = lds + wt_off;
-  const uint32_t* const wbf = reinterpret_cast<const uint32_t*>(lds + bf_off);
-#define TF_GEMM_F(OT_, KS_, INIT_, ACC_, B_, LID_)                                                             \
-  do {                                                                                                          \
-    if constexpr (BF)                                                                                           \
-      gemm_bf<OT_, KS_, NT, INIT_>(ACC_, B_, wbf + bo.f[LID_], lds + pd.L[LID_].off_b, lane);                       \
-    else                                                                                                        \
-      gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, lds + pd.L[LID_].off_w, lds + pd.L[LID_].off_b, lane);           \
-  } while (0)
-#define TF_GEMM_T(OT_, KS_, INIT_, ACC_, B_, TID_)                                            \
-  do {                                                                                         \
-    if constexpr (BF)                                                                          \
-      gemm_bf<OT_, KS_, NT, INIT_>(ACC_, B_, wbf + bo.t[TID_], nullptr, lane);                      \
-    else                                                                                       \
-      gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, wT + td.L[TID_].off, nullptr, lane);            \
-  } while (0)
+#define TF_GEMM_F(OT_, KS_, INIT_, ACC_, B_, LID_) gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, lds + pd.L[LID_].off_w, lds + pd.L[LID_].off_b, lane)
+#define TF_GEMM_T(OT_, KS_, INIT_, ACC_, B_, TID_) gemm_pack<OT_, KS_, NT, INIT_>(ACC_, B_, wT + td.L[TID_].off, nullptr, lane)
   constexpr int NT = 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const v4s ident = ident_frag(lane);
@@ -2630,72 +1797,6 @@ __global__ __launch_bounds__(1024) void field_reduce_tf_kernel(const float* __re
   if (o < pd.L[l].OUT && gp.b[l]) gp.b[l][o] = s;
 }
 
-// ---- sum the per-workgroup slabs and scatter into the reference-layout gradient tensors ------------
-
-__device__ __forceinline__ int stage_col_to_in(int kind, int col) {
-  if (kind == IN_27) return col < 12 ? col : (col >= 13 && col < 28 ? col - 1 : -1);
-  if (kind == IN_DIR28) return col < 28 ? col : -1;
-  return col;
-}
-
-__global__ __launch_bounds__(256) void field_reduce_kernel(const float* __restrict__ slabs, int nslabs, SlabLayout sl,
-                                                           PackDesc pd, GradPtrs gp, int n_bias_items) {
-  // 64 slab entries per workgroup; the 4 waves each sum a quarter of the slabs (8 loads in flight), LDS combines
-  __shared__ float part[4][64];
-  const int e = threadIdx.x & 63, pw = threadIdx.x >> 6;
-  const int item = blockIdx.x * 64 + e;
-  const int nitems = sl.total_w + n_bias_items;
-  int src = -1, bias_l = -1, bias_o = 0;  // slab offset this item sums
-  if (item < sl.total_w) {
-    src = item;
-  } else if (item < nitems) {
-    int o = item - sl.total_w, l = 0;
-    while (l < NLAYERS && o >= sl.cols[l]) o -= sl.cols[l], ++l;
-    if (l < NLAYERS && l != L_MX) bias_l = l, bias_o = o, src = sl.off_db[l] + o;
-  }
-  float acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
-  if (src >= 0) {
-    const int per = (nslabs + 3) / 4, w0 = pw * per, w1 = min(nslabs, w0 + per);
-    int w = w0;
-    for (; w + 7 < w1; w += 8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] += slabs[(size_t)(w + k) * sl.total + src];
-    }
-    for (; w < w1; ++w) acc[0] += slabs[(size_t)w * sl.total + src];
-  }
-  part[pw][e] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-  __syncthreads();
-  if (pw != 0 || src < 0) return;
-  const float s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-  if (bias_l >= 0) {
-    if (bias_o < pd.L[bias_l].OUT && gp.b[bias_l]) gp.b[bias_l][bias_o] = s;
-    return;
-  }
-  const int idx = item;
-  for (int l = 0; l < NLAYERS; ++l) {
-    const LayerDesc& L = pd.L[l];
-    const int nw = sl.waves * sl.nacc[l] * 256;
-    if (idx >= sl.off[l] && idx < sl.off[l] + nw) {
-      const int rel = idx - sl.off[l];
-      const int r = rel & 3, ln = (rel >> 2) & 63, blk = rel >> 8;
-      const int wave = blk / sl.nacc[l], i = blk % sl.nacc[l];
-      const int TI = sl.TI[l];
-      const int to = wave / TI + i * (sl.waves / TI), ti = wave % TI;
-      if (to >= sl.TO[l]) return;
-      const int out = 16 * to + 4 * (ln >> 4) + r, col = 16 * ti + (ln & 15);
-      if (l == L_MX) {  // slab holds dE^T[b][c]
-        if (out < L.OUT && col < L.IN && gp.W[l]) gp.W[l][(size_t)col * L.OUT + out] = s;
-        return;
-      }
-      const int in = stage_col_to_in(L.kind, col);
-      if (out < L.OUT && in >= 0 && in < L.IN && gp.W[l]) gp.W[l][(size_t)out * L.IN + in] = s;
-      return;
-    }
-  }
-}
-
 // =============================================================================================
 // host side
 // =============================================================================================
@@ -2913,9 +2014,9 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances, io.feat_logits = dens ? nullptr : feat_logits;
   const size_t lds_bytes = (size_t)((pd.total + 3) & ~3) * 4;
-  // UMHS_FWD_VARIANT (tuning knob): 0 = bf16x3 chain where it applies (default), 1 = fp32 chain with 8-wave workgroups, 2 = fp32 chain,
-  // 3 / 4 / 5 = bf16x3 chain forced to 12 x 1 / 16 x 1 / 8 x 2 (waves x sample tiles per wave)
-  static const int fwd_variant = getenv("UMHS_FWD_VARIANT") ? atoi(getenv("UMHS_FWD_VARIANT")) : 0;
+  // (one shape per case: the bf16x3 chain as 8 waves x 2 sample tiles wherever a prebuilt image exists and its packs fit the LDS, else
+  // the fp32 chain as 4 x 2.  The 12 x 1 / 16 x 1 / fp32 8 x 1 forms of round 2 were measured -- 16 x 1: 90 vs 97 us alone, 0.875 vs
+  // 0.846 ms inside the step, where it starves the side-stream kernels -- and removed in round 3.)
   const float* image = nullptr;
   if (workspace) {  // optional: prebuilt pack image (without it every workgroup gathers the image itself)
     if (workspace_bytes < fwd_ws_need(pd, dens)) return UMHS_ERR_WORKSPACE;
@@ -2928,10 +2029,10 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   }
   FwdBfPlan fp;
   FwdBfArgs no_bf = {};
-  const bool bf = !dens && image && (fwd_variant == 0 || fwd_variant >= 3) && fwd_bf_plan(pd, &fp);  // no image: each workgroup gathers fp32 packs
+  const bool bf = !dens && image && fwd_bf_plan(pd, &fp);  // no image: each workgroup gathers fp32 packs
   if (bf) fp.args.bf_image = image + ((pd.total + 63) & ~63);
   // samples per workgroup iteration: 16 x NT x waves
-  const int tile_samples = bf ? (fwd_variant == 3 ? 192 : 256) : 128;
+  const int tile_samples = bf ? 256 : 128;
   const int64_t ntiles = (n + tile_samples - 1) / tile_samples;
   // the fused density query gathers from the hash table inside the kernel: it wants every wave slot its 112 VGPRs allow (4 per SIMD)
   const int blocks_per_cu = bf ? 1 : ((hash && lds_bytes <= 36 * 1024) ? 4 : (lds_bytes <= 78 * 1024 ? 2 : 1));
@@ -2949,14 +2050,8 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   else if (dens)
     LAUNCH_FWD(false, true, 2, 4);
   else if (spec) {
-    if (bf && fwd_variant == 3)
-      LAUNCH_FWD(true, false, 1, 12, false, true);
-    else if (bf && fwd_variant == 4)  // 16 x 1: alone 90 vs 97 us at C2, but inside the step (side-stream kernels beside it) 0.875 vs 0.846 ms
-      LAUNCH_FWD(true, false, 1, 16, false, true);
-    else if (bf)
+    if (bf)
       LAUNCH_FWD(true, false, 2, 8, false, true);
-    else if (fwd_variant == 1)
-      LAUNCH_FWD(true, false, 1, 8);
     else
       LAUNCH_FWD(true, false, 2, 4);
   } else {
@@ -3196,24 +2291,10 @@ extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_
   return UMHS_OK;
 }
 
-struct PartPlan {  // one half of the split heads backward: rebased descriptors + how to assemble its LDS image
-  PackDesc pd;
-  TPackDesc td;
-  ImgSegs seg_f, seg_t;
-  int wt_off, stage_off;
-  size_t lds;
-};
-
 struct BwdPlan {
-  bool split;        // B <= 32, 8 waves: the heads backward runs as two kernels with all packs LDS-resident
-  PartPlan part[2];
-  int TB, waves, NA, FSd, S, first;
-  PackDesc pd_all, pd_base;
+  int TB;
+  PackDesc pd_all;
   TPackDesc td;
-  SlabLayout sl;
-  int n_bias_items;
-  int stage_off_h, stage_off_b;
-  size_t lds_h, lds_b;
 };
 
 static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p, BwdPlan* pl) {
@@ -3221,26 +2302,10 @@ static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p,
   int TB;
   int rc = build_pack_desc(cfg, p, &pl->pd_all, &TB, 0);
   if (rc) return rc;
-  pl->first = pl->pd_all.L[L_H0].off_w;  // the heads kernel keeps image[first, total) resident
-  rc = build_pack_desc(cfg, p, &pl->pd_base, &TB, 1);
-  if (rc) return rc;
   pl->TB = TB;
-  pl->FSd = 16 + 32 * ((16 * TB - 4 + 31) / 32);  // >= 16*TB + 12 (row rotation), = 16 (mod 32)
-  auto stage_floats = [&](int S) {
-    const int tail = S * pl->FSd + 2 * S * 48;
-    return tail > 2 * S * 80 ? tail : 2 * S * 80;
-  };
-  pl->stage_off_h = (pl->pd_all.total - pl->first + 3) & ~3;
-  pl->stage_off_b = (pl->pd_base.total + 3) & ~3;
-  pl->waves = 8;
-  if ((size_t)(pl->stage_off_h + stage_floats(128)) * 4 > 160 * 1024 || TB > 8) pl->waves = 4;
-  pl->S = 16 * pl->waves;
-  pl->lds_h = (size_t)(pl->stage_off_h + stage_floats(pl->S)) * 4;
-  pl->lds_b = (size_t)(pl->stage_off_b + 2 * pl->S * 80) * 4;
-  if (pl->lds_h > 160 * 1024) return UMHS_ERR_UNSUPPORTED;
-  pl->NA = (TB + pl->waves - 1) / pl->waves;
-  if (pl->waves == 8 ? pl->NA != 1 : (pl->NA < 1 || pl->NA > 4)) return UMHS_ERR_UNSUPPORTED;
-  if (pl->waves == 4 && pl->NA == 1) pl->NA = 2;  // only NA in {2,3,4} is instantiated for 4-wave workgroups
+  // with the specular head the backward serves up to 192 bands (12 band tiles): beyond, part 0's kernel does not hold its registers
+  // (110 dwords spilled at 16 tiles) and has no test behind it -- reported, and the callers keep what they can (known limits)
+  if (spec && TB > 12) return UMHS_ERR_UNSUPPORTED;
 
   TPackDesc* td = &pl->td;
   auto sett = [&](int l, const float* W, int OUT, int IN, int KS, int OT, int rowmap) {
@@ -3263,83 +2328,7 @@ static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p,
   }
   td->total = off;
 
-  // ---- split heads backward (see field_bwd_part_kernel) ----------------------------------------
-  pl->split = false;
-  if (pl->waves == 8) {
-    const int fl0[] = {L_H0, L_H1, L_H2, L_D0, L_D1, L_MX}, tl0[] = {T_H2, T_H1, T_H0, T_D1, T_MX};
-    const int fl1[] = {L_F0, L_F1}, tl1[] = {T_F2, T_F1, T_F0};
-    bool fits = true;
-    for (int part = 0; part < 2; ++part) {
-      PartPlan& pp = pl->part[part];
-      pp.pd = pl->pd_all, pp.td = *td;
-      pp.seg_f.n = pp.seg_t.n = 0;
-      const int* fl = part == 0 ? fl0 : fl1;
-      const int nfl = part == 0 ? 6 : 2;
-      const int* tl = part == 0 ? tl0 : tl1;
-      const int ntl = part == 0 ? 5 : 3;
-      auto add = [](ImgSegs& sg, int src, int dst, int len) {
-        if (len == 0) return;
-        if (sg.n && sg.src[sg.n - 1] + sg.len[sg.n - 1] == src && sg.dst[sg.n - 1] + sg.len[sg.n - 1] == dst) {
-          sg.len[sg.n - 1] += len;
-          return;
-        }
-        sg.src[sg.n] = src, sg.dst[sg.n] = dst, sg.len[sg.n] = len, ++sg.n;
-      };
-      int cur = 0;
-      for (int i = 0; i < nfl; ++i) {  // weights, then biases, in the kernel's own compact image
-        const LayerDesc& L = pl->pd_all.L[fl[i]];
-        const int len = L.OT * ((L.KS + 3) / 4) * 256;
-        add(pp.seg_f, L.off_w, cur, len);
-        pp.pd.L[fl[i]].off_w = cur, cur += len;
-      }
-      for (int i = 0; i < nfl; ++i) {
-        if (fl[i] == L_MX) continue;
-        const LayerDesc& L = pl->pd_all.L[fl[i]];
-        add(pp.seg_f, L.off_b, cur, 16 * L.OT);
-        pp.pd.L[fl[i]].off_b = cur, cur += 16 * L.OT;
-      }
-      pp.wt_off = (cur + 3) & ~3;
-      cur = 0;
-      for (int i = 0; i < ntl; ++i) {
-        const TDesc& T = td->L[tl[i]];
-        const int len = T.OT * ((T.KS + 3) / 4) * 256;
-        add(pp.seg_t, T.off, cur, len);
-        pp.td.L[tl[i]].off = cur, cur += len;
-      }
-      pp.stage_off = (pp.wt_off + cur + 3) & ~3;
-      pp.lds = (size_t)(pp.stage_off + stage_floats(128)) * 4;
-      if (pp.lds > 160 * 1024 || pp.seg_f.n > 6 || pp.seg_t.n > 6) fits = false;
-    }
-    pl->split = fits;
-  }
-
-  SlabLayout* sl = &pl->sl;
-  const int W = pl->waves;
-  const int TOs[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1, 1, TB, TB};
-  const int TIs[NLAYERS] = {2, 4, 2, 4, 4, 2, 4, 4, 2, 1, 1};
-  const int naccs[NLAYERS] = {8 / W, 1, 8 / W, 16 / W, 1, 8 / W, 16 / W, 1, 1, pl->NA, pl->NA};
-  const int OTs[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1, spec ? 1 : 0, spec ? TB : 0, 0};
-  off = 0;
-  for (int l = 0; l < NLAYERS; ++l) {
-    sl->TO[l] = TOs[l], sl->TI[l] = TIs[l], sl->nacc[l] = naccs[l], sl->off[l] = off;
-    off += W * naccs[l] * 256;
-  }
-  sl->total_w = off;
-  pl->n_bias_items = 0;
-  for (int l = 0; l < NLAYERS; ++l) {
-    sl->off_db[l] = off;
-    sl->cols[l] = 16 * OTs[l];
-    pl->n_bias_items += sl->cols[l];
-    if (l != L_MX) off += 64 * W;
-  }
-  sl->waves = W;
-  sl->total = (off + 3) & ~3;
   return UMHS_OK;
-}
-
-static unsigned bwd_grid(int64_t n, int S) {
-  const int64_t ntiles = (n + S - 1) / S;
-  return (unsigned)(ntiles < 256 ? ntiles : 256);
 }
 
 // ---- transpose-free backward: per-part LDS images and launch ------------------------------------------------------------
@@ -3357,10 +2346,9 @@ static int tf_nitems(int tbmax) {
     default: return TfSlots<16>::NITEMS;
   }
 }
-static size_t bwd_slab_floats(const BwdPlan& pl, int64_t n) {  // room for either kernel family's per-workgroup slabs
-  const size_t staged = (size_t)bwd_grid(n, pl.S) * pl.sl.total;
+static size_t bwd_slab_floats(const BwdPlan& pl, int64_t n) {  // the per-workgroup slabs
   const size_t tf = (size_t)(tf_grid(n) + (tf_grid(n) + 15) / 16) * tf_nitems(tf_tbmax(pl.TB) ? tf_tbmax(pl.TB) : 16) * 256;  // + the folded set
-  return staged > tf ? staged : tf;
+  return tf;
 }
 static int bf_image_dwords(const BwdPlan& pl);
 static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
@@ -3524,40 +2512,17 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
   typedef TfSlots<TBMAX> SL;
   const unsigned grid = tf_grid(n);
   int rc;
-#define LAUNCH_TF(P_, S_, BF_, FU_)                                                                                                \
-  do {                                                                                                                            \
-    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX, BF_, FU_>, part[P_].lds);                                                     \
-    if (rc) return rc;                                                                                                            \
-    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX, BF_, FU_>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io,   \
-                       part[P_].pd, part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, bfimg, part[P_].seg_b,  \
-                       part[P_].bf_off, part[P_].bo, slabs);                                                                      \
+#define LAUNCH_TF(P_, S_, FU_)                                                                                                   \
+  do {                                                                                                                           \
+    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX, FU_>, part[P_].lds);                                                         \
+    if (rc) return rc;                                                                                                           \
+    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX, FU_>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io,       \
+                       part[P_].pd, part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, bfimg, part[P_].seg_b, \
+                       part[P_].bf_off, part[P_].bo, slabs);                                                                     \
   } while (0)
-  // (part 0 with the specular head above 128 bands: its bf16x3 variants spill into scratch -- never selected by default -- and the
-  // 256-band one crashes this hipcc's "Rewrite AGPR-Copy-MFMA" pass outright: not instantiated, the fp32 chain serves)
-#define LAUNCH_TF_P(P_, FU_)                                          \
-  do {                                                                \
-    if (spec) {                                                       \
-      if constexpr (P_ == 0 && TBMAX > 8) {                           \
-        LAUNCH_TF(P_, true, false, FU_);                              \
-      } else {                                                        \
-        if (bf_mask >> P_ & 1)                                        \
-          LAUNCH_TF(P_, true, true, FU_);                             \
-        else                                                          \
-          LAUNCH_TF(P_, true, false, FU_);                            \
-      }                                                               \
-    } else {                                 \
-      if (bf_mask >> P_ & 1)                 \
-        LAUNCH_TF(P_, false, true, FU_);     \
-      else                                   \
-        LAUNCH_TF(P_, false, false, FU_);    \
-    }                                        \
-  } while (0)
-  // UMHS_BWD_ZIP (A/B knob, bit p = part p): the kernels with the zipped instruction schedule (umhs_field_zip.h) -- default on.  Measured
-  // (rocprofv3, C2): part 0 114.9 -> 110.9 us, part 1 114.5 -> 106.9 us; whole backward C3 604 -> 577 us, C5 457 -> 433 us.
-  static const int zip_mode = getenv("UMHS_BWD_ZIP") ? atoi(getenv("UMHS_BWD_ZIP")) : 3;
-  // part 0: bf16x3 chain, and the band counts at which the kernel holds its registers (specular head: up to 8 band tiles, 8 only in the
-  // folded form -- the 8-tile per-sample variant spills to scratch)
-  const bool zip0 = (zip_mode & 1) && (bf_mask & 1) && (!spec || TBMAX < 8 || (TBMAX == 8 && bc != nullptr));
+  // bf_mask bit p: part p runs the three-piece bf16 chain = the kernels with the zipped instruction schedule (umhs_field_zip.h); else the
+  // fp32 chain (field_bwd_tf_kernel).  Measured (rocprofv3, C2) against the unzipped bf16x3 kernels they replaced: part 0 114.9 -> 110.9 us,
+  // part 1 114.5 -> 106.9 us; whole backward C3 604 -> 577 us, C5 457 -> 433 us.
 #define LAUNCH_TFZ0(S_, FU_)                                                                                                          \
   do {                                                                                                                                \
     rc = set_lds(field_bwd_tfz0_kernel<S_, TBMAX, FU_>, part[0].lds);                                                                 \
@@ -3566,20 +2531,31 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
                        part[0].td, img, wT, part[0].seg_f, part[0].seg_t, part[0].wt_off, bfimg, part[0].seg_b, part[0].bf_off,       \
                        part[0].bo, slabs);                                                                                            \
   } while (0)
-#define LAUNCH_P0(FU_)                    \
-  do {                                    \
-    if (zip0) {                           \
-      if constexpr (TBMAX <= 8) {         \
-        if (spec)                         \
-          LAUNCH_TFZ0(true, FU_);         \
-        else                              \
-          LAUNCH_TFZ0(false, FU_);        \
-      } else {                            \
-        LAUNCH_TFZ0(false, FU_);          \
-      }                                   \
-    } else {                              \
-      LAUNCH_TF_P(0, FU_);                \
-    }                                     \
+  // (instantiated: what run_field_bwd can select -- the zipped part 0 with the specular head up to 4 band tiles, 8 in the folded form
+  // only; the fp32 chain with it up to 12)
+#define LAUNCH_P0(FU_)                                     \
+  do {                                                     \
+    if ((bf_mask & 1) && spec) {                           \
+      if constexpr (TBMAX < 8 || (TBMAX == 8 && FU_)) {    \
+        LAUNCH_TFZ0(true, FU_);                            \
+      } else {                                             \
+        return UMHS_ERR_UNSUPPORTED;                       \
+      }                                                    \
+    } else if (bf_mask & 1) {                              \
+      if constexpr (TBMAX < 16 || FU_) {                   \
+        LAUNCH_TFZ0(false, FU_);                           \
+      } else {                                             \
+        return UMHS_ERR_UNSUPPORTED;                       \
+      }                                                    \
+    } else if (spec) {                                     \
+      if constexpr (TBMAX <= 12) {                         \
+        LAUNCH_TF(0, true, FU_);                           \
+      } else {                                             \
+        return UMHS_ERR_UNSUPPORTED;                       \
+      }                                                    \
+    } else {                                               \
+      LAUNCH_TF(0, false, FU_);                            \
+    }                                                      \
   } while (0)
   if (bc) {
     hipLaunchKernelGGL(field_mix_grad_kernel, dim3((unsigned)((bc->n_rays + 15) / 16)), dim3(256), (size_t)32 * (bc->B | 1) * 4,
@@ -3594,15 +2570,14 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
   }
 #undef LAUNCH_P0
 #undef LAUNCH_TFZ0
-  if ((zip_mode & 2) && (bf_mask >> 1 & 1)) {  // part 1 with the zipped instruction schedule (umhs_field_zip.h)
+  if (bf_mask >> 1 & 1) {
     rc = set_lds(field_bwd_tfz1_kernel<TBMAX>, part[1].lds);
     if (rc) return rc;
     hipLaunchKernelGGL((field_bwd_tfz1_kernel<TBMAX>), dim3(grid), dim3(256), part[1].lds, umhs_s(stream), io, part[1].pd, part[1].td, img, wT,
                        part[1].seg_f, part[1].seg_t, part[1].wt_off, bfimg, part[1].seg_b, part[1].bf_off, part[1].bo, slabs);
   } else {
-    LAUNCH_TF_P(1, false);
+    LAUNCH_TF(1, false, false);  // (part 1 does not depend on the specular head)
   }
-#undef LAUNCH_TF_P
 #undef LAUNCH_TF
   UMHS_CHECK_LAUNCH();
   TfMap mp;
@@ -3683,9 +2658,9 @@ static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (cfg->density_only) return UMHS_ERR_UNSUPPORTED;
-  if (!params || !enc || !selector || !world_pos || !sigma_raw || !emb || !d_sigma || (!bc && !d_spectral) || !grads || n < 0)
+  if (!params || !enc || !selector || !world_pos || !sigma_raw || !emb || !feat_logits || !d_sigma || (!bc && !d_spectral) || !grads || n < 0)
     return UMHS_ERR_ARG;
-  if (bc && (!feat_logits || !bc->sigma || !bc->t0 || !bc->t1 || !bc->weights || !bc->d_comp || !bc->packed_info || !bc->ray_of ||
+  if (bc && (!bc->sigma || !bc->t0 || !bc->t1 || !bc->weights || !bc->d_comp || !bc->packed_info || !bc->ray_of ||
              bc->n_rays < 0))
     return UMHS_ERR_ARG;
   const bool spec = cfg->pred_specular != 0;
@@ -3695,7 +2670,6 @@ static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   BwdPlan pl;
   rc = build_bwd_plan(cfg, params, &pl);
   if (rc) return rc;
-  const unsigned grid = bwd_grid(n, pl.S);
   if (!workspace || workspace_bytes < bwd_workspace_need(pl, n)) return UMHS_ERR_WORKSPACE;
   // workspace: [transposed packs][forward pack image][bf16x3 images] (independent of n: umhs_field_bwd_prepare fills them) [slabs][d_bo]
   float* wT = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -3705,8 +2679,6 @@ static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   float* d_bo = slabs + ((bwd_slab_floats(pl, n) + 63) & ~(size_t)63);
   float* d_bo2 = d_bo + (((size_t)n * 16 + 63) & ~(size_t)63);
   float* d_fl = d_bo2 + (((size_t)n * 16 + 63) & ~(size_t)63);
-  static const int no_split = getenv("UMHS_BWD_NO_SPLIT") ? atoi(getenv("UMHS_BWD_NO_SPLIT")) : 0;  // A/B knob
-  const bool split = pl.split && feat_logits != nullptr && !no_split;
   if (!packs_ready) {
     launch_bwd_packs(pl, wT, img, bfimg, stream);
     UMHS_CHECK_LAUNCH();
@@ -3726,20 +2698,18 @@ static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* par
                                 nullptr};
     for (int l = 0; l < NLAYERS; ++l) gp.W[l] = gw[l], gp.b[l] = gb[l];
   }
-  // ---- transpose-free kernels (default; they need the forward's feature logits like the split kernels below) ---------------
-  // Measured (tools/bench_fbwd.py, one MI355X, whole backward): C2 328 vs 351 us, 128 bands 833 vs 1454 us, 141 bands 660 vs 1243 us
-  // for the LDS-staged kernels below (whose fused heads kernel spills and keeps its transposed packs in L2 above 32 bands); in the
-  // full C2 step 0.903 / 0.908 vs 0.917 / 0.916 ms (A/B/A/B).  UMHS_BWD_TF=0 forces the staged kernels.
-  // UMHS_BWD_TF: 0 = the LDS-staged kernels, 1 = transpose-free with the fp32 MFMA chain, 2 = transpose-free with the chain as
-  // three-piece bf16 products (gemm_bf)
-  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : 3;
-  static const int bf_env = getenv("UMHS_BWD_BF") ? atoi(getenv("UMHS_BWD_BF")) : -1;  // A/B knob: bit p = part p on the bf16x3 chain
+  // Two kernels (umhs_field_bwd needs the forward's feature logits: part 0 starts from them, part 1 from part 0's d_fl).  The chain runs
+  // as three-piece bf16 products (the kernels of umhs_field_zip.h) wherever those hold their registers, else on the fp32 MFMA
+  // (field_bwd_tf_kernel); UMHS_BWD_TF=1 (A/B knob) forces the fp32 chain everywhere.  (The LDS-staged kernels of round 1 -- 351 vs
+  // 228 us at C2, 1454 vs 577 us at 128 bands -- were removed in round 3.)
+  static const bool fp32_chain = getenv("UMHS_BWD_TF") && atoi(getenv("UMHS_BWD_TF")) == 1;
   const int tbmax = tf_tbmax(pl.TB);
-  if (tf_mode != 0 && feat_logits != nullptr && tbmax != 0) {
-    // mode 3 (default): the bf16x3 chain where its kernel holds its registers -- part 1 always, part 0 up to 128 bands or without
-    // the directional MLP (resource usage: the part-0 kernels with specular above 128 bands spill into scratch)
-    int bf_mask = tf_mode == 2 ? 3 : tf_mode == 3 ? (2 | ((!spec || tbmax <= 8) ? 1 : 0)) : 0;
-    if (bf_env >= 0) bf_mask = bf_env & 3;
+  if (tbmax == 0) return UMHS_ERR_UNSUPPORTED;  // more than 256 bands
+  {
+    // bf16x3: part 1 always (part 0: up to 7 band tiles with the specular head, 8 in the folded form only -- its 8-tile per-sample kernel spills to scratch --
+    // and any band count without it)
+    const bool p0 = spec ? (tbmax < 8 || (tbmax == 8 && bc != nullptr)) : (tbmax < 16 || bc != nullptr);
+    int bf_mask = fp32_chain ? 0 : (2 | (p0 ? 1 : 0));
     TfPart part[2];
     bool ok = true;
     for (int p = 0; p < 2; ++p) {
@@ -3765,71 +2735,7 @@ static int run_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* par
       }
     }
   }
-  if (bc) return UMHS_ERR_UNSUPPORTED;  // only the transpose-free kernels carry the folded compositing backward
-#define LAUNCH_HEADS(S_, NA_, W_)                                                                                  \
-  do {                                                                                                             \
-    rc = set_lds(field_bwd_heads_kernel<S_, NA_, W_>, pl.lds_h);                                                   \
-    if (rc) return rc;                                                                                             \
-    hipLaunchKernelGGL((field_bwd_heads_kernel<S_, NA_, W_>), dim3(grid), dim3(64 * W_), pl.lds_h, umhs_s(stream), \
-                       io, pl.pd_all, pl.td, (const float*)wT, pl.sl, slabs, pl.stage_off_h, pl.FSd,               \
-                       (const float*)img, pl.first);                                                               \
-  } while (0)
-#define LAUNCH_HEADS_S(NA_, W_)          \
-  do {                                   \
-    if (spec)                            \
-      LAUNCH_HEADS(true, NA_, W_);       \
-    else                                 \
-      LAUNCH_HEADS(false, NA_, W_);      \
-  } while (0)
-  if (split) {
-    io.feat_logits_in = feat_logits, io.d_fl = d_fl, io.d_bo2 = d_bo2;
-#define LAUNCH_PART(P_, S_)                                                                                              \
-  do {                                                                                                                   \
-    const PartPlan& pp = pl.part[P_];                                                                                    \
-    rc = set_lds(field_bwd_part_kernel<P_, S_>, pp.lds);                                                                 \
-    if (rc) return rc;                                                                                                   \
-    hipLaunchKernelGGL((field_bwd_part_kernel<P_, S_>), dim3(grid), dim3(512), pp.lds, umhs_s(stream), io, pp.pd, pp.td, \
-                       pl.sl, slabs, pp.wt_off, pp.stage_off, pl.FSd, (const float*)img, (const float*)wT, pp.seg_f,       \
-                       pp.seg_t);                                                                                        \
-  } while (0)
-    if (spec) {
-      LAUNCH_PART(0, true);
-      LAUNCH_PART(1, true);
-    } else {
-      LAUNCH_PART(0, false);
-      LAUNCH_PART(1, false);
-    }
-#undef LAUNCH_PART
-  } else if (pl.waves == 8) {
-    LAUNCH_HEADS_S(1, 8);
-  } else if (pl.NA == 2) {
-    LAUNCH_HEADS_S(2, 4);
-  } else if (pl.NA == 3) {
-    LAUNCH_HEADS_S(3, 4);
-  } else {
-    LAUNCH_HEADS_S(4, 4);
-  }
-#undef LAUNCH_HEADS_S
-#undef LAUNCH_HEADS
-  UMHS_CHECK_LAUNCH();
-  if (pl.waves == 8) {
-    rc = set_lds(field_bwd_base_kernel<8>, pl.lds_b);
-    if (rc) return rc;
-    hipLaunchKernelGGL((field_bwd_base_kernel<8>), dim3(grid), dim3(512), pl.lds_b, umhs_s(stream), io, pl.pd_base, pl.td,
-                       (const float*)wT, pl.sl, slabs, pl.stage_off_b);
-  } else {
-    rc = set_lds(field_bwd_base_kernel<4>, pl.lds_b);
-    if (rc) return rc;
-    hipLaunchKernelGGL((field_bwd_base_kernel<4>), dim3(grid), dim3(256), pl.lds_b, umhs_s(stream), io, pl.pd_base, pl.td,
-                       (const float*)wT, pl.sl, slabs, pl.stage_off_b);
-  }
-  UMHS_CHECK_LAUNCH();
-  const PackDesc& pd_all = pl.pd_all;
-  const int items = pl.sl.total_w + pl.n_bias_items;
-  hipLaunchKernelGGL(field_reduce_kernel, dim3((items + 63) / 64), dim3(256), 0, umhs_s(stream), (const float*)slabs,
-                     (int)grid, pl.sl, pd_all, gp, pl.n_bias_items);
-  UMHS_CHECK_LAUNCH();
-  return UMHS_OK;
+  return UMHS_ERR_UNSUPPORTED;  // (a part whose weight images exceed the LDS in either arithmetic: no configuration check_cfg admits)
 }
 
 extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
@@ -3845,8 +2751,6 @@ extern "C" int umhs_field_bwd(const umhs_field_cfg* cfg, const umhs_field_params
 // 1 when umhs_field_bwd_composited can serve this configuration (the transpose-free kernels with every pack LDS-resident).
 extern "C" int umhs_field_bwd_composited_supported(const umhs_field_cfg* cfg) {
   if (check_cfg(cfg) || cfg->density_only) return 0;
-  static const int tf_mode = getenv("UMHS_BWD_TF") ? atoi(getenv("UMHS_BWD_TF")) : 3;
-  if (tf_mode == 0) return 0;
   umhs_field_params dummy = {};
   const float zero = 0.0f;
   const float** pp = reinterpret_cast<const float**>(&dummy);

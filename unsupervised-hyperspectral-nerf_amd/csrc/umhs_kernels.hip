@@ -81,7 +81,8 @@ extern "C" int umhs_positions_fwd(const float* origins, const float* directions,
 // level-major and the resident waves of an XCD gather from one 4 MiB level slab (= one XCD L2) at
 // a time instead of from the whole 64 MiB table.
 // =============================================================================================
-template <int LPT>  // levels per thread: blockIdx.y covers levels [LPT*y, LPT*y + LPT); all their gathers are in flight together
+// (Two / four levels per thread -- shared position math, more gathers in flight -- were measured in round 2: 92 / 110 / 128 us; a
+// thread that walks two level slabs undoes the one-slab-per-XCD locality.  Removed in round 3.)
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restrict__ pos01,
                                                            const float2* __restrict__ table,
                                                            const float* __restrict__ scalings, int64_t n, int n_levels,
@@ -90,26 +91,16 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float px = pos01[3 * i], py = pos01[3 * i + 1], pz = pos01[3 * i + 2];
-  float2 f[LPT][8];
-  float off[LPT][3];
-#pragma unroll
-  for (int k = 0; k < LPT; ++k) {
-    const int l = min((int)blockIdx.y * LPT + k, n_levels - 1);
-    const HashCorners h = hash_corners(px, py, pz, scalings[l], (1u << log2_T) - 1u, (uint32_t)l << log2_T);
-    off[k][0] = h.ox, off[k][1] = h.oy, off[k][2] = h.oz;
-    hash_gather8(table, h, f[k]);
-  }
-#pragma unroll
-  for (int k = 0; k < LPT; ++k) {
-    const int l = (int)blockIdx.y * LPT + k;
-    if (l >= n_levels) break;
-    const float2 r = hash_trilerp(f[k], off[k][0], off[k][1], off[k][2]);
-    float* o = enc + i * stride_n + (int64_t)l * stride_l;
-    if (((stride_n | stride_l) & 1) == 0) {
-      *reinterpret_cast<float2*>(o) = r;
-    } else {
-      o[0] = r.x, o[1] = r.y;
-    }
+  const int l = (int)blockIdx.y;
+  const HashCorners h = hash_corners(px, py, pz, scalings[l], (1u << log2_T) - 1u, (uint32_t)l << log2_T);
+  float2 f[8];
+  hash_gather8(table, h, f);
+  const float2 r = hash_trilerp(f, h.ox, h.oy, h.oz);
+  float* o = enc + i * stride_n + (int64_t)l * stride_l;
+  if (((stride_n | stride_l) & 1) == 0) {
+    *reinterpret_cast<float2*>(o) = r;
+  } else {
+    o[0] = r.x, o[1] = r.y;
   }
 }
 
@@ -120,23 +111,9 @@ extern "C" int umhs_hashgrid_fwd(const float* pos01, const float* table, const f
   if (n_levels < 1 || n_levels > 32 || log2_T < 1 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
   if (((uintptr_t)table & 15) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;  // (16-byte slot pairs are fetched with one load)
   if (n == 0) return UMHS_OK;
-  // Levels per thread (tuning knob UMHS_HG_LPT): 2 shares the position loads / address set-up between two levels and doubles the
-  // gathers in flight per thread at half the threads.  Measured on one MI355X at C2 (tools/bench_field.py): see DESIGN.md section 5.
-  static const int lpt = getenv("UMHS_HG_LPT") ? atoi(getenv("UMHS_HG_LPT")) : 1;
   const float2* t2 = reinterpret_cast<const float2*>(table);
-  if (lpt == 2) {
-    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n_levels + 1) / 2));
-    hipLaunchKernelGGL(hashgrid_fwd_kernel<2>, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n,
-                       stride_l);
-  } else if (lpt == 4) {
-    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n_levels + 3) / 4));
-    hipLaunchKernelGGL(hashgrid_fwd_kernel<4>, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n,
-                       stride_l);
-  } else {
-    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
-    hipLaunchKernelGGL(hashgrid_fwd_kernel<1>, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n,
-                       stride_l);
-  }
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
+  hipLaunchKernelGGL(hashgrid_fwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n, stride_l);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
@@ -1635,355 +1612,9 @@ extern "C" int umhs_ray_train_tail(const float* spectral, const float* M, const 
   return UMHS_OK;
 }
 
-// =============================================================================================
-// The whole per-ray part of a training step in ONE launch: compositing forward (umhs_composite_fwd), the training tail
-// (umhs_ray_train_tail) and compositing backward (umhs_composite_bwd), a wave per ray.  All three are local to a ray; fused, the ray's
-// sigma / t / weights stay where they are between the passes, the composited spectrum and its gradient never leave the CU (LDS rows), and
-// two launches with their dependency gaps disappear (C2: 32 + 24 + 23 us as three kernels).  Same arithmetic, in the same order, as the
-// three kernels (a 16-lane group of the wave runs the tail's per-ray code); only the final loss sums associate differently (fixed order).
-// Stream 0 is the one that carries the loss (spectral); the others are composited only.
-// =============================================================================================
-struct FusedArgs {
-  const float *sigma, *t0, *t1;
-  const int64_t* pinfo;
-  int64_t n_rays;
-  CompStreams st;           // forward: every composited stream; stream 0 = spectral [N,B]
-  float *weights, *acc, *depth_raw;
-  TailArgs tail;            // spec / acc / depth inputs are this kernel's own outputs (unused fields: spec, acc, depth, d_spec)
-  float* d_values0;         // [N,B] gradient w.r.t. stream 0's per-sample values
-  float* d_sigma;           // [N]
-  int grad_scaling, nblocks_partial, kpad;
-};
-
-// (4 waves per SIMD: at 4096 rays every ray's wave is resident at once -- the kernel is one latency chain per ray, so a second round of
-// waves would double it; 128 VGPRs and <= 40 KiB of LDS per workgroup keep it at one)
-__global__ __launch_bounds__(256, 4) void ray_train_fused_kernel(FusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float fused_lds[];  // per wave: [64][33] value tile, 64 weights, 2 rows of kpad floats
-  __shared__ float ee_inv[16];
-  __shared__ float part[2][4];
-  __shared__ bool last;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15;
-  const TailArgs& ta = a.tail;
-  const int B = ta.B, C = ta.C;
-  float* const tile = fused_lds + wv * (64 * 33 + 64 + 2 * a.kpad);
-  float* const wsl = tile + 64 * 33;
-  float* const sr = wsl + 64;       // the ray's composited spectrum
-  float* const dr = sr + a.kpad;    // ... and its gradient
-  {  // 1 / max(||E_c||, 1e-12) once per block, 16 lanes per class (as ray_train_tail_kernel)
-    const int grp = tid >> 4;
-    float ee = 0.0f;
-    if (grp < C)
-      for (int b = l; b < B; b += 16) ee += ta.E[grp * B + b] * ta.E[grp * B + b];
-    ee = red16(ee);
-    if (l == 0) ee_inv[grp] = 1.0f / fmaxf(sqrtf(ee), 1e-12f);
-  }
-  __syncthreads();
-  const float cs = ta.w_spec * 2.0f / ((float)a.n_rays * (float)B);
-  const float cr = ta.w_rgb * 2.0f / ((float)a.n_rays * 3.0f);
-  const float tlo = ord2f(ta.mm[0]), thi = ord2f(ta.mm[1]);
-  float ls = 0.0f, lr = 0.0f;  // lanes 0..15 of each wave: partial loss sums over the wave's rays
-  for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < a.n_rays; r0 += (int64_t)gridDim.x * 4) {  // block-uniform trip count
-    const int64_t r = r0 + wv;
-    if (r < a.n_rays) {  // wave-uniform
-      const int64_t start = a.pinfo[2 * r];
-      const int cnt = (int)a.pinfo[2 * r + 1];
-      // ---------------- compositing forward (composite_fwd_kernel) ----------------------------------------------------
-      float carry = 0.0f, acc = 0.0f, dnum = 0.0f;
-      for (int base = 0; base < cnt || base == 0; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < cnt;
-        const int64_t nidx = start + i;
-        float ta_ = 0.0f, tb_ = 0.0f, x = 0.0f;
-        if (valid) {
-          ta_ = a.t0[nidx], tb_ = a.t1[nidx];
-          x = a.sigma[nidx] * (tb_ - ta_);
-        }
-        float incl = wave_inclusive_scan(x, lane);
-        float T = expf(-(carry + (incl - x)));
-        float alpha = 1.0f - expf(-x);
-        float w = valid ? alpha * T : 0.0f;
-        if (valid) a.weights[nidx] = w;
-        acc += w;
-        dnum += w * ((ta_ + tb_) / 2.0f);
-        carry += __shfl(incl, 63, 64);
-        const int nvalid = min(64, cnt - base);
-        for (int s = 0; s < a.st.n;) {
-          const bool pair = s + 1 < a.st.n && a.st.k[s] <= 32 && a.st.k[s + 1] <= 32;
-          const int half = pair ? (lane >> 5) : 0;
-          const int K = half ? a.st.k[s + 1] : a.st.k[s];
-          const float* __restrict__ v = (half ? a.st.v[s + 1] : a.st.v[s]) + (start + base) * (int64_t)K;
-          float* __restrict__ outp = half ? a.st.out[s + 1] : a.st.out[s];
-          const bool is0 = s == 0 && half == 0;  // stream 0 also lands in the wave's LDS row for the tail
-          const int kspan = pair ? 32 : 64, klane = pair ? (lane & 31) : lane;
-          const int kmax = pair ? 32 : a.st.k[s];
-          for (int kc = 0; kc < kmax; kc += kspan) {
-            const int k = kc + klane;
-            const bool kv = k < K;
-            float p0 = 0.0f, p1 = 0.0f;
-            const float* __restrict__ vk = v + (kv ? k : 0);
-            int j = 0;
-            for (; j + 15 < nvalid; j += 16) {
-              float xx[16];
-#pragma unroll
-              for (int u = 0; u < 16; ++u) xx[u] = vk[(int64_t)(j + u) * K];
-#pragma unroll
-              for (int u = 0; u < 16; u += 2) p0 += __shfl(w, j + u, 64) * xx[u], p1 += __shfl(w, j + u + 1, 64) * xx[u + 1];
-            }
-            for (; j + 7 < nvalid; j += 8) {
-              float xx[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) xx[u] = vk[(int64_t)(j + u) * K];
-#pragma unroll
-              for (int u = 0; u < 8; u += 2) p0 += __shfl(w, j + u, 64) * xx[u], p1 += __shfl(w, j + u + 1, 64) * xx[u + 1];
-            }
-            for (; j < nvalid; ++j) p0 += __shfl(w, j, 64) * vk[(int64_t)j * K];
-            if (!kv) p0 = p1 = 0.0f;
-            if (kv) {
-              float* o = outp + r * K + k;
-              const float val = (base == 0) ? (p0 + p1) : (*o + (p0 + p1));
-              *o = val;
-              if (is0) sr[k] = val;
-            }
-          }
-          s += pair ? 2 : 1;
-        }
-        if (cnt == 0) break;
-      }
-      acc = wave_reduce_sum(acc);
-      dnum = wave_reduce_sum(dnum);
-      const float depth_raw = dnum / (acc + 1e-10f);
-      if (lane == 0) {
-        a.acc[r] = acc;
-        if (a.depth_raw) a.depth_raw[r] = depth_raw;
-      }
-      // ---------------- training tail (ray_train_tail_kernel): lanes 0..15 are the ray's group, the others idle along --------
-      float dacc = 0.0f;
-      {
-        const float* grow = ta.gt_spec + r * B;
-        float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, ss = 0.0f, dl = 0.0f;
-        float ip[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) ip[c] = 0.0f;
-        if (lane < 16) {
-          for (int b = l; b < B; b += 16) {
-            const float sv = sr[b], d = sv - grow[b];
-            x0 += sv * ta.M[3 * b], x1 += sv * ta.M[3 * b + 1], x2 += sv * ta.M[3 * b + 2];
-            ss += sv * sv, dl += d * d;
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-              if (c < C) ip[c] += sv * ta.E[c * B + b];
-          }
-        }
-        x0 = red16(x0), x1 = red16(x1), x2 = red16(x2), ss = red16(ss);
-        if (lane < 16) ls += dl;
-        const float xs[3] = {x0, x1, x2};
-        float rgbv[3], g[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) rgbv[k] = fminf(fmaxf(srgb_gamma(xs[k]), 0.0f), 1.0f);
-        if (ta.rgb_loss) {
-          float ga = 0.0f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float beta = ta.bg ? ta.bg[3 * r + k] : 0.0f;
-            const float d = rgbv[k] + beta * (1.0f - acc) - ta.gt_rgb[3 * r + k];
-            if (lane == 0) lr += d * d;
-            const float gk = cr * d;
-            ga -= gk * beta;
-            g[k] = gk * srgb_gamma_grad(xs[k]);
-          }
-          dacc = __shfl(ga, 0, 64);
-          if (lane == 0 && ta.d_acc) ta.d_acc[r] = ga;
-        }
-        if (lane < 16) {
-          for (int b = l; b < B; b += 16)
-            dr[b] = cs * (sr[b] - grow[b]) + (g[0] * ta.M[3 * b] + g[1] * ta.M[3 * b + 1] + g[2] * ta.M[3 * b + 2]);
-          if (l < 3 && ta.rgb) ta.rgb[3 * r + l] = rgbv[l];
-          if (l == 3 && ta.depth_out) ta.depth_out[r] = fminf(fmaxf(depth_raw, tlo), thi);
-        }
-        if (ta.seg_probs) {
-          const float inv_x = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-          float mx = -INFINITY, mine = 0.0f;
-          int arg = 0;
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            if (c < C) {
-              const float v = red16(ip[c]) * inv_x * ee_inv[c];
-              if (v > mx) mx = v, arg = c;
-              if (c == l) mine = v;
-            }
-          }
-          const float e = l < C ? expf(ta.alpha * (mine - mx)) : 0.0f;
-          const float sum = red16(e);
-          if (lane < 16) {
-            if (l < C) ta.seg_probs[r * C + l] = e / sum;
-            const float on = acc > 0.5f ? 1.0f : 0.0f;
-            if (l == 0 && ta.seg_raw) ta.seg_raw[r] = (float)arg * on;
-            if (l < 3 && ta.seg_pred) ta.seg_pred[3 * r + l] = ta.colors[3 * arg + l] * on;
-          }
-        }
-      }
-      // ---------------- compositing backward (composite_bwd_kernel), d_out of stream 0 = the LDS row dr ----------------------
-      if (cnt > 0) {
-        const int nchunks = (cnt + 63) >> 6;
-        float carry2 = 0.0f;
-        for (int c = 0; c < nchunks; ++c) {
-          const int i = c * 64 + lane;
-          const bool valid = i < cnt;
-          const int64_t nidx = start + i;
-          float x = valid ? a.sigma[nidx] * (a.t1[nidx] - a.t0[nidx]) : 0.0f;
-          float incl = wave_inclusive_scan(x, lane);
-          if (valid) a.d_sigma[nidx] = expf(-(carry2 + incl));
-          carry2 += __shfl(incl, 63, 64);
-        }
-        const int K = B;
-        const int KS = K <= 32 ? (K | 1) : 33;
-        float carry_after = 0.0f;
-        for (int c = nchunks - 1; c >= 0; --c) {
-          const int i = c * 64 + lane;
-          const bool valid = i < cnt;
-          const int64_t nidx = start + i;
-          float dw = 0.0f, w = 0.0f, delta = 0.0f, scale = 1.0f, tnext = 0.0f;
-          if (valid) {
-            float ta_ = a.t0[nidx], tb_ = a.t1[nidx];
-            delta = tb_ - ta_;
-            if (a.grad_scaling) {
-              float m = (ta_ + tb_) / 2.0f;
-              scale = fminf(fmaxf(m * m, 0.0f), 1.0f);
-            }
-            w = a.weights[nidx];
-            tnext = a.d_sigma[nidx];
-            dw = dacc;
-          }
-          const int nvalid = min(64, cnt - c * 64);
-          const float* __restrict__ vb = a.st.v[0] + (start + c * 64) * (int64_t)K;
-          for (int k0 = 0; k0 < K; k0 += 32) {
-            const int kw = min(32, K - k0);
-            if (K <= 32) {
-              const int tot = nvalid * K;
-              for (int e = lane; e < tot; e += 64) {
-                const int jj = e / K;
-                tile[jj * KS + (e - jj * K)] = vb[e];
-              }
-            } else {
-              const int col = lane & 31;
-              for (int jj = lane >> 5; jj < nvalid; jj += 2)
-                if (col < kw) tile[jj * 33 + col] = vb[(int64_t)jj * K + k0 + col];
-            }
-            if (valid) {
-              float d0 = 0.0f, d1 = 0.0f;
-              int k = 0;
-              for (; k + 1 < kw; k += 2) {
-                d0 += dr[k0 + k] * tile[lane * KS + k];
-                d1 += dr[k0 + k + 1] * tile[lane * KS + k + 1];
-              }
-              if (k < kw) d0 += dr[k0 + k] * tile[lane * KS + k];
-              dw += d0 + d1;
-            }
-          }
-          float p = dw * w;
-          float suf = wave_inclusive_scan_rev(p, lane);
-          float S = carry_after + (suf - p);
-          if (valid) a.d_sigma[nidx] = (dw * tnext - S) * delta * scale;
-          carry_after += __shfl(suf, 0, 64);
-          wsl[lane] = w * scale;
-          float* __restrict__ dv = a.d_values0 + (start + c * 64) * (int64_t)K;
-          if (K <= 32) {
-            const int tot = nvalid * K;
-            for (int e = lane; e < tot; e += 64) {
-              const int jj = e / K;
-              dv[e] = wsl[jj] * dr[e - jj * K];
-            }
-          } else {
-            for (int kc = 0; kc < K; kc += 64) {
-              const int k = kc + lane;
-              const bool kv = k < K;
-              const float d = kv ? dr[k] : 0.0f;
-              for (int j = 0; j < nvalid; ++j)
-                if (kv) dv[(int64_t)j * K + k] = wsl[j] * d;
-            }
-          }
-        }
-      }
-    }
-  }
-  // ---------------- loss sums: wave -> block partial -> last block (fixed order: reproducible) ---------------------------------
-  ls = red16(ls), lr = red16(lr);
-  if (lane == 0) part[0][wv] = ls, part[1][wv] = lr;
-  __syncthreads();
-  if (tid == 0) {
-    ta.partial[2 * blockIdx.x] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
-    ta.partial[2 * blockIdx.x + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
-    __threadfence();
-    last = atomicAdd(ta.counter, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (last) {
-    __threadfence();
-    float s0 = 0.0f, s1 = 0.0f;
-    for (int b = tid; b < (int)gridDim.x; b += 256) s0 += ta.partial[2 * b], s1 += ta.partial[2 * b + 1];
-    s0 = wave_reduce_sum(s0), s1 = wave_reduce_sum(s1);
-    __syncthreads();
-    if (lane == 0) part[0][wv] = s0, part[1][wv] = s1;
-    __syncthreads();
-    if (tid == 0) {
-      s0 = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
-      s1 = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
-      ta.losses[0] = s0 * (ta.w_spec / ((float)a.n_rays * (float)B));
-      ta.losses[1] = ta.rgb_loss ? s1 * (ta.w_rgb / ((float)a.n_rays * 3.0f)) : 0.0f;
-      *ta.counter = 0u;
-    }
-  }
-}
-
-#define UMHS_FUSED_MAX_BLOCKS 1024
-extern "C" size_t umhs_ray_train_fused_scratch_bytes(void) { return UMHS_FUSED_MAX_BLOCKS * 2 * sizeof(float) + 64; }
-
-extern "C" int umhs_ray_train_fused(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,
-                                    int64_t n_rays, int64_t n, const umhs_value_streams* streams, const float* M,
-                                    const float* endmembers, const float* tmid_minmax2, const float* class_colors,
-                                    const float* gt_spectral, const float* gt_rgb, const float* background, int n_classes, float alpha,
-                                    float w_spectral, float w_rgb, int rgb_loss, int grad_scaling, float* weights, float* accumulation,
-                                    float* depth_raw, float* rgb, float* depth_clipped, float* seg_probs, float* seg_raw,
-                                    float* seg_pred, float* losses2, float* d_values0, float* d_sigma, float* d_accumulation,
-                                    void* scratch, size_t scratch_bytes, umhs_stream_t stream) {
-  if (n_rays < 1 || n < 0 || !packed_info || !streams || !weights || !accumulation || !M || !gt_spectral || !tmid_minmax2 || !losses2 ||
-      !d_values0 || !d_sigma || !scratch)
-    return UMHS_ERR_ARG;
-  if (n > 0 && (!sigma || !t_starts || !t_ends)) return UMHS_ERR_ARG;
-  if (rgb_loss && (!gt_rgb || !d_accumulation)) return UMHS_ERR_ARG;
-  if (seg_probs && (!endmembers || n_classes < 1)) return UMHS_ERR_ARG;
-  if (seg_pred && (!class_colors || !seg_probs)) return UMHS_ERR_ARG;
-  if (n_classes > 16) return UMHS_ERR_UNSUPPORTED;
-  if (scratch_bytes < umhs_ray_train_fused_scratch_bytes() || ((uintptr_t)scratch & 3)) return UMHS_ERR_WORKSPACE;
-  FusedArgs a;
-  a.st.n = streams->n_streams;
-  if (a.st.n < 1 || a.st.n > UMHS_MAX_STREAMS) return UMHS_ERR_ARG;
-  for (int s = 0; s < UMHS_MAX_STREAMS; ++s) {
-    a.st.k[s] = 0, a.st.v[s] = nullptr, a.st.out[s] = nullptr;
-    if (s < a.st.n) {
-      a.st.k[s] = streams->k[s], a.st.v[s] = streams->values[s], a.st.out[s] = streams->out[s];
-      if (a.st.k[s] < 1 || !a.st.out[s] || (n > 0 && !a.st.v[s])) return UMHS_ERR_ARG;
-    }
-  }
-  if (a.st.k[0] > 256) return UMHS_ERR_UNSUPPORTED;  // the wave's LDS rows
-  a.sigma = sigma, a.t0 = t_starts, a.t1 = t_ends, a.pinfo = packed_info, a.n_rays = n_rays;
-  a.weights = weights, a.acc = accumulation, a.depth_raw = depth_raw, a.d_values0 = d_values0, a.d_sigma = d_sigma;
-  a.grad_scaling = grad_scaling;
-  TailArgs& t = a.tail;
-  t.spec = nullptr, t.M = M, t.E = endmembers, t.acc = nullptr, t.depth = nullptr, t.colors = class_colors;
-  t.gt_spec = gt_spectral, t.gt_rgb = gt_rgb, t.bg = background, t.mm = reinterpret_cast<const uint32_t*>(tmid_minmax2);
-  t.n_rays = n_rays, t.B = a.st.k[0], t.C = seg_probs ? n_classes : 0, t.rgb_loss = rgb_loss, t.alpha = alpha;
-  t.w_spec = w_spectral, t.w_rgb = w_rgb, t.rgb = rgb, t.depth_out = depth_clipped, t.seg_probs = seg_probs;
-  t.seg_raw = seg_raw, t.seg_pred = seg_pred, t.losses = losses2, t.d_spec = nullptr, t.d_acc = d_accumulation;
-  t.counter = reinterpret_cast<uint32_t*>(scratch), t.partial = reinterpret_cast<float*>(scratch) + 16;
-  const int64_t blocks = (n_rays + 3) / 4;
-  a.nblocks_partial = (int)(blocks < UMHS_FUSED_MAX_BLOCKS ? blocks : UMHS_FUSED_MAX_BLOCKS);
-  a.kpad = (a.st.k[0] + 31) & ~31;
-  const size_t lds = (size_t)4 * (64 * 33 + 64 + 2 * a.kpad) * sizeof(float);  // 35.3 KiB at 31 bands, 39.9 KiB at 141
-  hipLaunchKernelGGL(ray_train_fused_kernel, dim3((unsigned)a.nblocks_partial), dim3(256), lds, umhs_s(stream), a);
-  UMHS_CHECK_LAUNCH();
-  return UMHS_OK;
-}
+// (The per-ray part of a training step as ONE launch -- compositing forward + training tail + compositing backward, umhs_ray_train_fused --
+// was built in round 2, equal to the three kernels bit for bit, and lost its A/B twice: 0.966 vs 0.934 ms per step at C2, each of the
+// three being one latency chain per ray already.  Removed in round 3.)
 
 // =============================================================================================
 // Fused Adam over the flat "fields" parameter buffer (28 B/param of pure HBM streaming, float4 lanes)

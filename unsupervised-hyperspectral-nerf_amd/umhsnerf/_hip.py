@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 6  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
+ABI_VERSION = 7  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
 LIB_PATH = os.environ.get("UMHS_LIB_PATH") or os.path.join(_HERE, "libumhs_hip.so")  # override: A/B builds of tools/ab_lib.sh
 MAX_STREAMS = 4
 
@@ -106,9 +106,6 @@ SIGNATURES = {
     "umhs_compact_samples": (C.c_int, [_vp] * 3 + [_i64] + [_vp] * 13),
     "umhs_ray_train_tail_scratch_bytes": (C.c_size_t, []),
     "umhs_ray_train_tail": (C.c_int, [_vp] * 10 + [_i64, C.c_int, C.c_int, _f32, _f32, _f32, C.c_int] + [_vp] * 9 + [C.c_size_t, _vp]),
-    "umhs_ray_train_fused_scratch_bytes": (C.c_size_t, []),
-    "umhs_ray_train_fused": (C.c_int, [_vp] * 4 + [_i64, _i64, C.POINTER(ValueStreams)] + [_vp] * 7 + [C.c_int, _f32, _f32, _f32, C.c_int, C.c_int]
-                             + [_vp] * 13 + [C.c_size_t, _vp]),
     "umhs_enc_gather": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     "umhs_pixel_indices": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "umhs_raygen": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

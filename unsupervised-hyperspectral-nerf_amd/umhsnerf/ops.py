@@ -676,39 +676,6 @@ def ray_train_tail(s, m, E, accumulation, depth, tminmax, colors, gt_spec, gt_rg
     return rgb, dclip, probs, raw, pred, losses, d_spec, d_acc
 
 
-_fused_scratch: Dict[int, torch.Tensor] = {}
-
-
-def ray_train_fused(sigma, t0, t1, packed_info, values: Sequence[torch.Tensor], M, E, tminmax, colors, gt_spec, gt_rgb, bg, alpha: float,
-                    w_spec: float, w_rgb: float, rgb_loss: bool, grad_scaling: bool):
-    """composite_fwd (all ``values`` streams; values[0] = spectral carries the losses) + ray_train_tail + composite_bwd of stream 0 in
-    ONE launch.  -> (weights [N], accumulation [R], composited [R,k] per stream, rgb, depth_clipped, seg_probs, seg_raw, seg_pred,
-    losses[2], d_values0 [N,B], d_sigma [N])"""
-    R, n, dev = packed_info.shape[0], sigma.shape[0], sigma.device
-    B, Cn = values[0].shape[-1], E.shape[0]
-    new_ = lambda *shp: torch.empty(shp, device=dev, dtype=torch.float32)
-    st = _hip.ValueStreams()
-    st.n_streams = len(values)
-    outs = []
-    for i, v in enumerate(values):
-        o = new_(R, v.shape[-1])
-        st.k[i], st.values[i], st.out[i] = v.shape[-1], v.data_ptr(), o.data_ptr()
-        outs.append(o)
-    weights, acc = new_(n), new_(R)
-    rgb, dclip, probs, raw, pred = new_(R, 3), new_(R, 1), new_(R, Cn), new_(R), new_(R, 3)
-    losses, d_values0, d_sigma = new_(2), new_(n, B), new_(n)
-    d_acc = new_(R) if rgb_loss else None
-    sc = _fused_scratch.get(dev.index or 0)
-    if sc is None:
-        sc = _fused_scratch[dev.index or 0] = torch.zeros(_hip.lib().umhs_ray_train_fused_scratch_bytes(), dtype=torch.uint8, device=dev)
-    _hip.check(_hip.lib().umhs_ray_train_fused(ptr(sigma), ptr(t0), ptr(t1), ptr(packed_info), R, n, C.byref(st), ptr(M), ptr(E), ptr(tminmax),
-                                               ptr(colors), ptr(gt_spec), ptr(gt_rgb), ptr(bg), Cn, float(alpha), float(w_spec), float(w_rgb),
-                                               int(rgb_loss), int(grad_scaling), ptr(weights), ptr(acc), None, ptr(rgb), ptr(dclip), ptr(probs),
-                                               ptr(raw), ptr(pred), ptr(losses), ptr(d_values0), ptr(d_sigma), ptr(d_acc), ptr(sc), sc.numel(),
-                                               _hip.stream()), "umhs_ray_train_fused")
-    return weights, acc, outs, rgb, dclip, probs, raw, pred, losses, d_values0, d_sigma
-
-
 def loss_fwd(s, g, r, a, bg, gr, w_spec: float, w_rgb: float):
     R, B = s.shape
     losses = torch.empty(2, device=s.device, dtype=torch.float32)

@@ -498,30 +498,20 @@ class UMHSModel(ModelBase):
         bg = (background if background is not None else torch.rand_like(image)) if (both and self.background_color == "random") else None
         w = (5.0, float(c.rgb_loss_weight)) if both else (1.0, 0.0)
         bwd_comp = None
-        if os.environ.get("UMHS_FUSED_RAY", "0") == "1" and L.wavelengths <= 256 and not split_fwd:
-            # Everything that is local to a ray -- compositing forward, epilogue + losses + their backward, compositing backward -- in
-            # one launch (umhs_ray_train_fused; equal to the three kernels below, tests/test_hip_trajectory.py).  Measured at C2 on one
-            # MI355X, A/B/A/B in one session: 0.966 / 0.967 ms per step fused vs 0.934 / 0.936 with the three kernels.  Each of the three
-            # is already ONE latency chain per ray with every ray's wave resident (4 per SIMD); fused, the chains add up in one wave
-            # (and the tail's 16-lane group leaves 48 lanes idle), so the two saved launches buy nothing.  Kept as an opt-in.
-            weights, acc, comp, rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spectral_samples, d_sigma = ops.ray_train_fused(
-                fo["sigma"], t0, t1, packed_info, values, M, f.endmembers.detach(), mm, _hip.f32c(self.class_colors), hs,
-                image if both else None, bg, 0.2, w[0], w[1], both, bool(c.use_gradient_scaling))
+        if not split_fwd:
+            weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
+        # ray epilogue + both losses + their backward down to d_spectral / d_accumulation: one launch
+        rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(
+            comp[0], M, f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), hs, image if both else None, bg, 0.2,
+            w[0], w[1], both)
+        if fused_bwd:
+            d_sigma = d_spectral_samples = None
+            bwd_comp = dict(sigma=fo["sigma"], t0=t0, t1=t1, packed_info=packed_info, ray_indices=ri, weights=weights, d_comp=d_spec,
+                            d_acc=d_acc, grad_scaling=bool(c.use_gradient_scaling))
         else:
-            if not split_fwd:
-                weights, acc, depth, comp = ops.composite_fwd(fo["sigma"], t0, t1, packed_info, values)
-            # ray epilogue + both losses + their backward down to d_spectral / d_accumulation: one launch
-            rgb, depth_c, seg_probs, seg_raw, seg_pred, losses, d_spec, d_acc = ops.ray_train_tail(
-                comp[0], M, f.endmembers.detach(), acc, depth, mm, _hip.f32c(self.class_colors), hs, image if both else None, bg, 0.2,
-                w[0], w[1], both)
-            if fused_bwd:
-                d_sigma = d_spectral_samples = None
-                bwd_comp = dict(sigma=fo["sigma"], t0=t0, t1=t1, packed_info=packed_info, ray_indices=ri, weights=weights, d_comp=d_spec,
-                                d_acc=d_acc, grad_scaling=bool(c.use_gradient_scaling))
-            else:
-                d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
-                                                      bool(c.use_gradient_scaling))
-                d_spectral_samples = d_values[0]
+            d_sigma, d_values = ops.composite_bwd(fo["sigma"], t0, t1, packed_info, weights, values[:1], [d_spec], [True], d_acc,
+                                                  bool(c.use_gradient_scaling))
+            d_spectral_samples = d_values[0]
         left = ops.field_backward_into(spec, f.flat, pos01, sel, wpos, d, enc, fo["sigma_raw"], fo["emb"], d_sigma, d_spectral_samples, None,
                                        prepared=prepared, feat_logits=fo["feat_logits"], hash_ready=ev_done if side is not None else None,
                                        comp=bwd_comp)
