@@ -407,16 +407,16 @@ def main():
         # HBM traffic / MFMA-busy from the committed rocprofv3 --pmc passes of this same command -- only when they were taken on
         # THIS build of the kernels (the summary records the source hash); counters cannot be read from inside the process
         pmc, pmc_src = {}, None
-        for rd in ("r02", "r01"):
+        for rel in (f"profiles/r03/pmc_summary_{args.config}.json", "profiles/r02/pmc_summary.json", "profiles/r01/pmc_summary.json"):
             try:
-                with open(os.path.join(ROOT, "profiles", rd, "pmc_summary.json")) as f:
+                with open(os.path.join(ROOT, rel)) as f:
                     js = json.load(f)
                 if js.get("csrc_sha") == csrc_hash() and js.get("config", "C2") == args.config:
-                    pmc, pmc_src = js["kernels"], f"profiles/{rd}/pmc_summary.json"
+                    pmc, pmc_src = js["kernels"], rel
                     break
             except Exception:
                 pass
-        op_kernels = {"field_bwd": ("field_bwd_part_kernel", "field_bwd_heads_kernel", "field_bwd_base_kernel", "field_reduce", "field_bwd_tf_kernel"),
+        op_kernels = {"field_bwd": ("field_bwd_tf_kernel", "field_bwd_tfz0_kernel", "field_bwd_tfz1_kernel", "field_slab_fold", "field_reduce_tf", "field_mix_"),
                       "field_fwd": ("field_fwd_kernel", "field_pack_all"), "field_base_fwd": ("field_fwd_kernel<false, true",),
                       "field_heads_fwd": ("field_fwd_kernel", "field_heads_finish"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
                       "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"),
@@ -432,9 +432,11 @@ def main():
                             traffic=traffic, avg_ms=round(ms, 4), launches=launches)
             if op in alg_flops:
                 ach = alg_flops[op] / (ms * 1e-3) / 1e12
-                busy = [v["mfma_util"] for k, v in pmc.items() if "mfma_util" in v and any(k.startswith(p_) for p_ in op_kernels[op])]
+                # MFMA-busy share of the operator = of all its kernels (the reductions included), weighted by their cycles
+                mk = [v for k, v in pmc.items() if v.get("kernel_cycles_per_xcd") and any(k.startswith(p_) for p_ in op_kernels[op])]
+                busy = round(sum(v.get("mfma_util", 0.0) * v["kernel_cycles_per_xcd"] for v in mk) / sum(v["kernel_cycles_per_xcd"] for v in mk), 4) if mk else None
                 return dict(kernel=op, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4),
-                            traffic=traffic, avg_ms=round(ms, 4), launches=launches, mfma_busy_frac_pmc=(max(busy) if busy else None))
+                            traffic=traffic, avg_ms=round(ms, 4), launches=launches, mfma_busy_frac_pmc=busy)
             return None
 
         rooflines = [r for r in (roof_of(op) for op in kern) if r is not None]

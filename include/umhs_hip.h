@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 7
+#define UMHS_ABI_VERSION 8
 
 enum {
   UMHS_OK = 0,
@@ -148,13 +148,9 @@ int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, c
                    int64_t n, float* sigma, float* sigma_raw, float* emb, float* spectral, float* spectral2,
                    float* specular, float* abundances, float* feat_logits, void* workspace, size_t workspace_bytes,
                    int pack_ready, umhs_stream_t stream);
-/* density_fn in ONE launch (SURVEY 8a R1-R3 for the sampler / occupancy-grid callers, umhs_model.py:208,553): the hash-grid     */
-/* gather feeds mlp_base inside the kernel, the [N,32] feature array is never written or read.  cfg->density_only must be set;  */
-/* pos01 [N,3] from umhs_positions_fwd, table [L*T,2], scalings [L]; outputs as umhs_field_fwd's (sigma_raw / emb optional).     */
-/* Same bits as umhs_hashgrid_fwd followed by umhs_field_fwd.                                                                    */
-int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* pos01, const float* table,
-                       const float* scalings, int log2_T, const float* selector, int64_t n, float* sigma, float* sigma_raw,
-                       float* emb, void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream);
+/* density_fn (SURVEY 8a R1-R3 for the sampler / occupancy-grid callers, umhs_model.py:208,553) = umhs_hashgrid_fwd followed by   */
+/* umhs_field_fwd with cfg->density_only.  (A one-launch form with the gather inside the MLP kernel existed up to ABI 7: it took  */
+/* as long as the two launches -- both are bound by the gather's L2 request rate -- and spilled registers; removed.)              */
 /* The training step's forward as two launches with the rendering weights known in between (umhs_model.py:239-327: field ->    */
 /* renderers; here the per-ray band sums of the [N,B] outputs are formed inside the heads kernel, so spectral2 / specular --     */
 /* which carry no loss, umhs_model.py:373-374 -- never exist per sample):                                                        */

@@ -234,21 +234,20 @@ def test_density_only():
     assert_close("density_fn emb", emb, h[:, 1:], 2e-5)
 
 
-def test_fused_density_query_is_the_two_kernel_one(monkeypatch):
-    """umhs_field_density (hash gather inside the MLP kernel, no [N,32] feature array) vs umhs_hashgrid_fwd + umhs_field_fwd: the
-    same bits, at the reference table size and on ragged sample counts; sigma-only callers get no embedding."""
+def test_density_query_scratch_and_kept_features():
+    """density_fn = hash gather + density-only forward: the same bits whether the features go to the per-device scratch or are kept
+    for the caller (the sampler reuses them), at the reference table size and on ragged sample counts; sigma-only callers get no embedding."""
     ops = _ops()
     for n_rays, n_samp, log2_T in ((5, 40, 14), (37, 29, 19), (1, 1, 12)):
         p, b, layout, flat, fs = make_case(6, 31, True, n_rays, n_samp, log2_T=log2_T)
         pos = (T.frustum_positions(b["origins"], b["directions"], b["starts"], b["ends"]) * 1.7).to(DEV)
-        res = {}
-        for fused in ("1", "0"):
-            monkeypatch.setenv("UMHS_FUSED_DENSITY", fused)
-            res[fused] = ops.DensityFn.apply(flat, pos, fs)
-        assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
-        monkeypatch.setenv("UMHS_FUSED_DENSITY", "1")
+        keep = {}
+        kept = ops.DensityFn.apply(flat, pos, fs, keep)
+        scratch = ops.DensityFn.apply(flat, pos, fs)
+        assert torch.equal(kept[0], scratch[0]) and torch.equal(kept[1], scratch[1])
+        assert keep["enc"].shape == (16, pos.shape[0] * pos.shape[1] if pos.dim() == 3 else pos.shape[0], 2)
         sig, emb = ops.DensityFn.apply(flat, pos, fs, None, False)
-        assert torch.equal(sig, res["0"][0]) and emb.numel() == 0
+        assert torch.equal(sig, kept[0]) and emb.numel() == 0
 
 
 @pytest.mark.parametrize("C,B,spec,temp", CASES)

@@ -28,9 +28,9 @@ def test_no_inline_asm_mfma_reads_a_freshly_written_vgpr():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_hazards
 
-    obj = os.path.join(CSRC, "umhs_field.o")
-    assert os.path.exists(obj), "run __graft_entry__.build() first"
-    text = isa_hazards.disassemble(obj)
+    objs = [os.path.join(CSRC, f"umhs_field{u}.o") for u in ("", "_p0", "_p1", "_p0f")]  # the file's four translation units (umhsnerf/build.py)
+    assert all(os.path.exists(o) for o in objs), "run __graft_entry__.build() first"
+    text = "".join(isa_hazards.disassemble(o) for o in objs)
     assert text.count("v_mfma_f32_16x16x16_bf16 a[") > 1000, "the dW products of the transpose-free backward were not found in the disassembly"
     bad = isa_hazards.check(text)
     assert not bad, bad[:5]

@@ -67,9 +67,11 @@ def check(text):
 
 
 def main():
-    name = sys.argv[1] if len(sys.argv) > 1 else "umhs_field"
-    obj = name if name.endswith(".o") else os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd", "csrc", name + ".o")
-    bad = check(disassemble(obj))
+    names = sys.argv[1:] or ["umhs_field", "umhs_field_p0", "umhs_field_p1", "umhs_field_p0f"]  # default: the field file's four translation units
+    bad = []
+    for name in names:
+        obj = name if name.endswith(".o") else os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd", "csrc", name + ".o")
+        bad += check(disassemble(obj))
     for kernel, prev, ins in bad[:20]:
         print(f"{kernel[:60]}: '{prev}' right in front of '{ins}'")
     print(f"{len(bad)} inline-asm MFMA(s) read a VGPR written fewer than two wait states earlier")

@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmcb_{fetch,write,sq,grbm}/**/*counter_collection.csv (tools/pmc_bench.sh) -> per-kernel medians as JSON.
+"""gpurun_out/pmcb_<config>_{fetch,write,sq,grbm}/**/*counter_collection.csv (tools/pmc_bench.sh) -> per-kernel medians as JSON.
+   usage: python tools/pmc_summarize.py <root> <out.json> <config>
 FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md); FETCH/WRITE_SIZE are in KiB;
 SQ_WAVE_CYCLES / SQ_WAIT_* are quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
 import csv, glob, json, os, re, statistics, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02/pmc_summary.json"
 config = sys.argv[3] if len(sys.argv) > 3 else "C2"
+out = sys.argv[2] if len(sys.argv) > 2 else f"profiles/r03/pmc_summary_{config}.json"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_hash  # the build the counters were taken on: bench.py reports them only for the same kernel sources
 vals = {}
 for tag in ("fetch", "write", "sq", "grbm"):
-    for f in glob.glob(os.path.join(root, f"pmcb_{tag}", "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(root, f"pmcb_{config}_{tag}", "**", "*counter_collection.csv"), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
             name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
@@ -45,7 +46,7 @@ for name, c in vals.items():
     if "SQ_INSTS_MFMA" in med:
         e["mfma_insts"] = med["SQ_INSTS_MFMA"]
     res[name] = e
-json.dump({"source": "rocprofv3 --pmc passes of tools/pmc_bench.sh over `bench.py --steps 6 --warmup 2` (C2, 1 GPU); median per launch; "
+json.dump({"source": "rocprofv3 --pmc passes of tools/pmc_bench.sh over `bench.py --config " + config + " --steps 6 --warmup 2 --no-cpu-baseline --no-sampler-step` (1 GPU); median per launch; "
            "FETCH_SIZE doubled per MI355X_MICROARCH.md; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)",
            "csrc_sha": csrc_hash(), "config": config, "kernels": res}, open(out, "w"), indent=1)
 print("wrote", out, len(res), "kernels")

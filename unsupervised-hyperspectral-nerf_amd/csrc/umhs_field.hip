@@ -11,15 +11,34 @@
 // k order, paid once by packing each weight matrix in the matching order (fwd image in LDS; the
 // transposed images for dX come from global/L2).  Bias rides in as the initial accumulator.
 //
-// Backward recomputes the forward per 16-sample tile (nothing but the hash features is saved), runs
-// the dX chain the same way with transposed packs, and forms dW = dZ X^T (contraction over samples,
-// i.e. over lanes) by staging [sample][feature] tiles of dZ and X in LDS and re-reading them
-// transposed as MFMA operands; each wave keeps a quarter of every layer's dW tiles in registers for
-// the whole launch, partial slabs are summed by a small reduce kernel.
+// Backward recomputes the forward per 16-sample tile (saved: hash features, sigma_raw, emb, feature logits), runs the dX chain the
+// same way with transposed packs, and forms dW = dZ X^T (contraction over samples, i.e. over lanes) from tiles transposed by an
+// identity MFMA, as three bf16 products into accumulators every wave keeps in AGPRs for the whole launch ("transpose-free": no LDS
+// staging); per-workgroup slabs are folded and summed by two small kernels.  Two main kernels: part 0 = head MLP + directional MLP +
+// mixing, part 1 = feature MLP + mlp_base; their instruction schedule is in umhs_field_zip.h / umhs_zip_plan.h.
+//
+// Translation units: this file compiles four times side by side (umhsnerf/build.py): -DUMHS_FIELD_TU=0 the forward, the small
+// kernels and the host side; =1 the zipped part-0 backward kernels; =2 the part-1 backward kernels; =3 the fp32-chain part-0 kernels
+// (the long poles of the build).  Without the define (tools/stamp_fbwd.py, tools/build_alt.sh) everything is one unit.
 #include <cstdlib>
 
 #include "umhs_common.h"
 #include <atomic>
+
+#ifndef UMHS_FIELD_TU
+#define UMHS_TU_MAIN 1
+#define UMHS_TU_P0Z 1
+#define UMHS_TU_P0F 1
+#define UMHS_TU_P1 1
+#else
+#define UMHS_TU_MAIN (UMHS_FIELD_TU == 0)
+#define UMHS_TU_P0Z (UMHS_FIELD_TU == 1)
+#define UMHS_TU_P0F (UMHS_FIELD_TU == 3)
+#define UMHS_TU_P1 (UMHS_FIELD_TU == 2)
+#if defined(UMHS_TF_STAMP)
+#error "the stamped build is a single translation unit (the stamp buffer is a __device__ variable)"
+#endif
+#endif
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -223,11 +242,6 @@ __device__ __forceinline__ float sel4(const v4f& v, int r) { return r == 0 ? v[0
 struct FieldIO {
   const float* enc;
   int64_t sn, sl;
-  // fused density query (field_fwd_kernel<.., HASH = true>): the hash features are gathered by the kernel itself
-  const float* pos01;
-  const float2* table;
-  const float* scalings;
-  int log2_T;
   const float *wpos, *dirs, *sel;
   int64_t n;
   int B, C, TB;
@@ -573,7 +587,7 @@ struct FwdBfArgs {
 // Z[g][stream][b] = the same for its LAST sample's ray (when that is another ray), and writes rays that lie strictly inside the
 // tile straight to comp (no other tile contributes to them).  field_heads_finish_kernel then adds, for every other ray, the A / Z
 // entries of its tiles in tile order.  part[((g*2 + az)*n_streams + stream)*16*TB + b].
-template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES, bool HASH = false, bool BF = false, bool HEADS = false>
+template <bool SPEC, bool DENSITY_ONLY, int NT, int WAVES, bool BF = false, bool HEADS = false>
 __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void field_fwd_kernel(FieldIO io, PackDesc pd,
                                                                                         const float* __restrict__ image, FwdBfArgs fb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -607,29 +621,6 @@ __global__ __launch_bounds__(64 * WAVES, BF ? WAVES / 4 : (2 * WAVES) / 4) void 
     float encf[NT][8];
     if (HEADS) {
       // nothing to load here: the base MLP's outputs are read below
-    } else if (HASH) {
-      // The lane's operand slots are the features of levels 4q .. 4q+3 of its sample: it gathers exactly those (8 corners x 4
-      // levels, all 32 loads of a sample in flight together) -- the [N,32] feature array never exists.  16 consecutive samples
-      // of a ray per quad and level: the same line reuse as the stand-alone gather kernel.
-      const uint32_t mask = (1u << io.log2_T) - 1u;
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) {
-        const float px = io.pos01[3 * nn[ct]], py = io.pos01[3 * nn[ct] + 1], pz = io.pos01[3 * nn[ct] + 2];
-        float2 f[4][8];
-        float off[4][3];
-#pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-          const int l = 4 * q + lv;
-          const HashCorners h = hash_corners(px, py, pz, io.scalings[l], mask, (uint32_t)l << io.log2_T);
-          off[lv][0] = h.ox, off[lv][1] = h.oy, off[lv][2] = h.oz;
-          hash_gather8(io.table, h, f[lv]);
-        }
-#pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-          const float2 v = hash_trilerp(f[lv], off[lv][0], off[lv][1], off[lv][2]);
-          encf[ct][2 * lv] = v.x, encf[ct][2 * lv + 1] = v.y;
-        }
-      }
     } else {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
@@ -897,6 +888,7 @@ struct PackJob {
   float* wT;     // [td.total] or null
   uint32_t* bf;  // [bp.total] or null
 };
+#if UMHS_TU_MAIN
 __global__ __launch_bounds__(256) void field_pack_all_kernel(PackJob jb) {
   const int n_img = jb.img ? jb.pd.total : 0, n_wT = jb.wT ? jb.td.total : 0, n_bf = jb.bf ? jb.bp.total : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n_img + n_wT + n_bf; i += gridDim.x * 256) {
@@ -940,6 +932,7 @@ __global__ __launch_bounds__(256) void field_pack_all_kernel(PackJob jb) {
     }
   }
 }
+#endif
 
 // =============================================================================================
 // Transpose-free backward (the default): two kernels, no LDS staging and no barrier inside their loops.
@@ -1583,6 +1576,115 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
 
 #include "umhs_field_zip.h"
 
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return UMHS_ERR_UNSUPPORTED;
+  static std::atomic<size_t> granted[16];  // per instantiation (a function-local static of a template) x device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  if (dev >= 0 && granted[dev].load(std::memory_order_relaxed) >= bytes) return UMHS_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+      hipSuccess)
+    return UMHS_ERR_LAUNCH;
+  if (dev >= 0) granted[dev].store(bytes, std::memory_order_relaxed);
+  return UMHS_OK;
+}
+
+
+static unsigned tf_grid(int64_t n) {
+  const int64_t ntiles = (n + 63) / 64;
+  return (unsigned)(ntiles < 256 ? ntiles : 256);
+}
+
+struct TfPart {  // one transpose-free kernel: descriptors rebased to its own LDS image + how to assemble that image
+  PackDesc pd;
+  TPackDesc td;
+  ImgSegs seg_f, seg_t, seg_b;
+  BfOffs bo;
+  int wt_off, bf_off;
+  size_t lds;
+};
+
+
+// ---- the two main kernels of the backward, per band-tile bound TBMAX; each part compiles in its own translation unit (see the top of the file)
+// zipped: the three-piece bf16 chain = the kernels with the zipped instruction schedule (umhs_field_zip.h); else the fp32 chain
+// (field_bwd_tf_kernel).  Measured (rocprofv3, C2) against the unzipped bf16x3 kernels they replaced: part 0 114.9 -> 110.9 us,
+// part 1 114.5 -> 106.9 us; whole backward C3 604 -> 577 us, C5 457 -> 433 us.
+struct TfLaunch {
+  FieldIO io;
+  const float *img, *wT, *bfimg;
+  float* slabs;
+  unsigned grid;
+  umhs_stream_t stream;
+};
+template <int TBMAX>
+int launch_tf_p0z(const TfPart& pt, const TfLaunch& a, bool spec, bool fused);  // zipped (three-piece bf16 chain)
+template <int TBMAX>
+int launch_tf_p0f(const TfPart& pt, const TfLaunch& a, bool spec, bool fused);  // fp32 chain
+template <int TBMAX>
+int launch_tf_p1(const TfPart& pt, const TfLaunch& a, bool zipped);
+
+#define TF_ARGS_ a.io, pt.pd, pt.td, a.img, a.wT, pt.seg_f, pt.seg_t, pt.wt_off, a.bfimg, pt.seg_b, pt.bf_off, pt.bo, a.slabs
+#define LAUNCH_K_(...)                                                                                          \
+  do {                                                                                                          \
+    int rc_ = set_lds(__VA_ARGS__, pt.lds);                                                                     \
+    if (rc_) return rc_;                                                                                        \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(a.grid), dim3(256), pt.lds, umhs_s(a.stream), TF_ARGS_);             \
+    return UMHS_OK;                                                                                             \
+  } while (0)
+#define INSTANTIATE_(fn_, ...)         \
+  template int fn_<2>(__VA_ARGS__);    \
+  template int fn_<4>(__VA_ARGS__);    \
+  template int fn_<8>(__VA_ARGS__);    \
+  template int fn_<12>(__VA_ARGS__);   \
+  template int fn_<16>(__VA_ARGS__)
+// (instantiated: what run_field_bwd can select -- the zipped part 0 with the specular head up to 4 band tiles, 8 in the folded form
+// only; the fp32 chain with it up to 12)
+#if UMHS_TU_P0Z
+template <int TBMAX, bool FU>
+static int launch_tf_p0z_(const TfPart& pt, const TfLaunch& a, bool spec) {
+  if (spec) {
+    if constexpr (TBMAX < 8 || (TBMAX == 8 && FU)) LAUNCH_K_(field_bwd_tfz0_kernel<true, TBMAX, FU>);
+    return UMHS_ERR_UNSUPPORTED;
+  }
+  if constexpr (TBMAX < 16 || FU) LAUNCH_K_(field_bwd_tfz0_kernel<false, TBMAX, FU>);
+  return UMHS_ERR_UNSUPPORTED;
+}
+template <int TBMAX>
+int launch_tf_p0z(const TfPart& pt, const TfLaunch& a, bool spec, bool fused) {
+  return fused ? launch_tf_p0z_<TBMAX, true>(pt, a, spec) : launch_tf_p0z_<TBMAX, false>(pt, a, spec);
+}
+INSTANTIATE_(launch_tf_p0z, const TfPart&, const TfLaunch&, bool, bool);
+#endif
+#if UMHS_TU_P0F
+template <int TBMAX, bool FU>
+static int launch_tf_p0f_(const TfPart& pt, const TfLaunch& a, bool spec) {
+  if (spec) {
+    if constexpr (TBMAX <= 12) LAUNCH_K_(field_bwd_tf_kernel<0, true, TBMAX, FU>);
+    return UMHS_ERR_UNSUPPORTED;
+  }
+  LAUNCH_K_(field_bwd_tf_kernel<0, false, TBMAX, FU>);
+}
+template <int TBMAX>
+int launch_tf_p0f(const TfPart& pt, const TfLaunch& a, bool spec, bool fused) {
+  return fused ? launch_tf_p0f_<TBMAX, true>(pt, a, spec) : launch_tf_p0f_<TBMAX, false>(pt, a, spec);
+}
+INSTANTIATE_(launch_tf_p0f, const TfPart&, const TfLaunch&, bool, bool);
+#endif
+#if UMHS_TU_P1
+template <int TBMAX>
+int launch_tf_p1(const TfPart& pt, const TfLaunch& a, bool zipped) {  // (part 1 does not depend on the specular head)
+  if (zipped) LAUNCH_K_(field_bwd_tfz1_kernel<TBMAX>);
+  LAUNCH_K_(field_bwd_tf_kernel<1, false, TBMAX, false>);
+}
+INSTANTIATE_(launch_tf_p1, const TfPart&, const TfLaunch&, bool);
+#endif
+#undef INSTANTIATE_
+#undef LAUNCH_K_
+#undef TF_ARGS_
+
+#if UMHS_TU_MAIN  // ---- everything below: the small kernels, the forward launchers, the host side of the C-ABI ----------------------
+
 // ---- the mixing term of the folded compositing backward, per RAY (umhs_field_bwd_composited) ---------------------------------
 // G[r][c] = sum_b d_comp[r][b] E[c][b]   (c < C, zero above): d m_n = ws_n G[ray(n)]
 __global__ __launch_bounds__(256) void field_mix_grad_kernel(const float* __restrict__ d_comp, const float* __restrict__ E, int64_t R,
@@ -1853,20 +1955,6 @@ static int check_cfg(const umhs_field_cfg* cfg) {
 
 // Raises a kernel's dynamic-LDS limit; remembered per kernel instantiation and device, so the driver call (which showed up as
 // a ~6 us bubble in front of every launch it preceded) is made once, not on every step.
-template <typename K>
-static int set_lds(K kernel, size_t bytes) {
-  if (bytes > 160 * 1024) return UMHS_ERR_UNSUPPORTED;
-  static std::atomic<size_t> granted[16];  // per instantiation (a function-local static of a template) x device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
-  if (dev >= 0 && granted[dev].load(std::memory_order_relaxed) >= bytes) return UMHS_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
-      hipSuccess)
-    return UMHS_ERR_LAUNCH;
-  if (dev >= 0) granted[dev].store(bytes, std::memory_order_relaxed);
-  return UMHS_OK;
-}
-
 // ---- forward on the bf16x3 chain: which layers convert, the compact LDS image, the global bf16x3 image ---------------------------
 struct FwdBfPlan {
   PackDesc pd;  // offsets local to the compact fp32 part
@@ -1979,26 +2067,16 @@ extern "C" int umhs_field_fwd_prepare(const umhs_field_cfg* cfg, const umhs_fiel
   return UMHS_OK;
 }
 
-struct HashIn {  // inputs of the fused density query (instead of enc)
-  const float* pos01;
-  const float* table;
-  const float* scalings;
-  int log2_T;
-};
-
-static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc, const HashIn* hash,
+static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* enc,
                          int64_t stride_n, int64_t stride_l, const float* world_pos, const float* directions,
                          const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
                          float* spectral, float* spectral2, float* specular, float* abundances, float* feat_logits,
                          void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
-  if (!params || (!enc && !hash) || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
-  if (enc && ((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7))) return UMHS_ERR_ARG;
+  if (!params || !enc || !selector || !sigma || n < 0) return UMHS_ERR_ARG;
+  if (((stride_n & 1) || (stride_l & 1) || ((uintptr_t)enc & 7))) return UMHS_ERR_ARG;
   const bool dens = cfg->density_only != 0, spec = cfg->pred_specular != 0;
-  if (hash && (!dens || !hash->pos01 || !hash->table || !hash->scalings || ((uintptr_t)hash->table & 15) || hash->log2_T < 1 ||
-               hash->log2_T > 24))
-    return UMHS_ERR_ARG;
   if (!dens && (!world_pos || !spectral || (spec && !directions))) return UMHS_ERR_ARG;
   if (n == 0) return UMHS_OK;
   PackDesc pd;
@@ -2007,9 +2085,6 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   if (rc) return rc;
   FieldIO io = {};
   io.enc = enc, io.sn = stride_n, io.sl = stride_l, io.wpos = world_pos, io.dirs = directions, io.sel = selector;
-  if (hash)
-    io.pos01 = hash->pos01, io.table = reinterpret_cast<const float2*>(hash->table), io.scalings = hash->scalings,
-    io.log2_T = hash->log2_T;
   io.n = n, io.B = cfg->n_bands, io.C = cfg->n_classes, io.TB = TB, io.temperature = cfg->temperature;
   io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.spectral = spectral, io.spectral2 = spectral2;
   io.specular = specular, io.abund = abundances, io.feat_logits = dens ? nullptr : feat_logits;
@@ -2034,8 +2109,7 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
   // samples per workgroup iteration: 16 x NT x waves
   const int tile_samples = bf ? 256 : 128;
   const int64_t ntiles = (n + tile_samples - 1) / tile_samples;
-  // the fused density query gathers from the hash table inside the kernel: it wants every wave slot its 112 VGPRs allow (4 per SIMD)
-  const int blocks_per_cu = bf ? 1 : ((hash && lds_bytes <= 36 * 1024) ? 4 : (lds_bytes <= 78 * 1024 ? 2 : 1));
+  const int blocks_per_cu = bf ? 1 : (lds_bytes <= 78 * 1024 ? 2 : 1);
   const unsigned grid = (unsigned)(ntiles < 256 * blocks_per_cu ? ntiles : 256 * blocks_per_cu);
   const size_t lds_launch = bf ? fp.lds : lds_bytes;
 #define LAUNCH_FWD(S, D, NT_, W_, ...)                                                                                       \
@@ -2045,18 +2119,16 @@ static int run_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params* par
     hipLaunchKernelGGL((field_fwd_kernel<S, D, NT_, W_, ##__VA_ARGS__>), dim3(grid), dim3(64 * W_), lds_launch, umhs_s(stream), \
                        io, bf ? fp.pd : pd, image, bf ? fp.args : no_bf);                                                    \
   } while (0)
-  if (dens && hash)
-    LAUNCH_FWD(false, true, 2, 4, true);
-  else if (dens)
+  if (dens)
     LAUNCH_FWD(false, true, 2, 4);
   else if (spec) {
     if (bf)
-      LAUNCH_FWD(true, false, 2, 8, false, true);
+      LAUNCH_FWD(true, false, 2, 8, true);
     else
       LAUNCH_FWD(true, false, 2, 4);
   } else {
     if (bf)
-      LAUNCH_FWD(false, false, 2, 8, false, true);
+      LAUNCH_FWD(false, false, 2, 8, true);
     else
       LAUNCH_FWD(false, false, 2, 4);
   }
@@ -2070,20 +2142,8 @@ extern "C" int umhs_field_fwd(const umhs_field_cfg* cfg, const umhs_field_params
                               const float* selector, int64_t n, float* sigma, float* sigma_raw, float* emb,
                               float* spectral, float* spectral2, float* specular, float* abundances, float* feat_logits,
                               void* workspace, size_t workspace_bytes, int pack_ready, umhs_stream_t stream) {
-  if (!enc) return UMHS_ERR_ARG;
-  return run_field_fwd(cfg, params, enc, nullptr, stride_n, stride_l, world_pos, directions, selector, n, sigma, sigma_raw, emb,
+  return run_field_fwd(cfg, params, enc, stride_n, stride_l, world_pos, directions, selector, n, sigma, sigma_raw, emb,
                        spectral, spectral2, specular, abundances, feat_logits, workspace, workspace_bytes, pack_ready, stream);
-}
-
-// density_fn in one launch: hash-grid gather + mlp_base + trunc_exp * selector, without the [N,32] feature array in between
-// (cfg->density_only must be set).  Same bits as umhs_hashgrid_fwd followed by umhs_field_fwd.
-extern "C" int umhs_field_density(const umhs_field_cfg* cfg, const umhs_field_params* params, const float* pos01,
-                                  const float* table, const float* scalings, int log2_T, const float* selector, int64_t n,
-                                  float* sigma, float* sigma_raw, float* emb, void* workspace, size_t workspace_bytes,
-                                  int pack_ready, umhs_stream_t stream) {
-  const HashIn hash = {pos01, table, scalings, log2_T};
-  return run_field_fwd(cfg, params, nullptr, &hash, 0, 0, nullptr, nullptr, selector, n, sigma, sigma_raw, emb, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, workspace, workspace_bytes, pack_ready, stream);
 }
 
 // ---- the forward as two launches with the rendering weights known in between (training step) --------------------------------
@@ -2121,9 +2181,9 @@ extern "C" int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_p
   // backward runs on the side stream at that moment, and a kernel that fills every CU pushes it under the heads kernel instead.
   static const int base_wgs = getenv("UMHS_BASE_WGS") ? atoi(getenv("UMHS_BASE_WGS")) : 1;
   const unsigned grid = (unsigned)(ntiles < 256 * base_wgs ? ntiles : 256 * base_wgs);
-  rc = set_lds(field_fwd_kernel<false, true, 2, 4, false, true>, fp.lds);
+  rc = set_lds(field_fwd_kernel<false, true, 2, 4, true>, fp.lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((field_fwd_kernel<false, true, 2, 4, false, true>), dim3(grid), dim3(256), fp.lds, umhs_s(stream), io, fp.pd,
+  hipLaunchKernelGGL((field_fwd_kernel<false, true, 2, 4, true>), dim3(grid), dim3(256), fp.lds, umhs_s(stream), io, fp.pd,
                      (const float*)img, fp.args);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
@@ -2272,14 +2332,14 @@ extern "C" int umhs_field_heads_fwd(const umhs_field_cfg* cfg, const umhs_field_
     const int64_t ntiles = (n + 255) / 256;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     if (spec) {
-      rc = set_lds(field_fwd_kernel<true, false, 2, 8, false, true, true>, fp.lds);
+      rc = set_lds(field_fwd_kernel<true, false, 2, 8, true, true>, fp.lds);
       if (rc) return rc;
-      hipLaunchKernelGGL((field_fwd_kernel<true, false, 2, 8, false, true, true>), dim3(grid), dim3(512), fp.lds, umhs_s(stream), io,
+      hipLaunchKernelGGL((field_fwd_kernel<true, false, 2, 8, true, true>), dim3(grid), dim3(512), fp.lds, umhs_s(stream), io,
                          fp.pd, (const float*)img, fp.args);
     } else {
-      rc = set_lds(field_fwd_kernel<false, false, 2, 8, false, true, true>, fp.lds);
+      rc = set_lds(field_fwd_kernel<false, false, 2, 8, true, true>, fp.lds);
       if (rc) return rc;
-      hipLaunchKernelGGL((field_fwd_kernel<false, false, 2, 8, false, true, true>), dim3(grid), dim3(512), fp.lds, umhs_s(stream), io,
+      hipLaunchKernelGGL((field_fwd_kernel<false, false, 2, 8, true, true>), dim3(grid), dim3(512), fp.lds, umhs_s(stream), io,
                          fp.pd, (const float*)img, fp.args);
     }
     UMHS_CHECK_LAUNCH();
@@ -2332,10 +2392,6 @@ static int build_bwd_plan(const umhs_field_cfg* cfg, const umhs_field_params* p,
 }
 
 // ---- transpose-free backward: per-part LDS images and launch ------------------------------------------------------------
-static unsigned tf_grid(int64_t n) {
-  const int64_t ntiles = (n + 63) / 64;
-  return (unsigned)(ntiles < 256 ? ntiles : 256);
-}
 static int tf_tbmax(int TB) { return TB <= 2 ? 2 : (TB <= 4 ? 4 : (TB <= 8 ? 8 : (TB <= 12 ? 12 : (TB <= 16 ? 16 : 0)))); }
 static int tf_nitems(int tbmax) {
   switch (tbmax) {
@@ -2354,15 +2410,6 @@ static int bf_image_dwords(const BwdPlan& pl);
 static size_t bwd_workspace_need(const BwdPlan& pl, int64_t n) {
   return ((size_t)pl.td.total + bwd_slab_floats(pl, n) + (size_t)n * 48 + pl.pd_all.total + bf_image_dwords(pl)) * 4 + 4096 + 1024;
 }
-
-struct TfPart {  // one transpose-free kernel: descriptors rebased to its own LDS image + how to assemble that image
-  PackDesc pd;
-  TPackDesc td;
-  ImgSegs seg_f, seg_t, seg_b;
-  BfOffs bo;
-  int wt_off, bf_off;
-  size_t lds;
-};
 
 // The layers whose products run as three-piece bf16 MFMAs (every layer with >= 7 k-steps), in the order of the global bf16x3 image:
 // part 0's first (head MLP, directional hidden layer, their transposes), then part 1's.
@@ -2511,74 +2558,23 @@ static int launch_tf(const BwdPlan& pl, const TfPart (&part)[2], int bf_mask, Fi
                      const float* bfimg, float* slabs, const GradPtrs& gp, int64_t n, umhs_stream_t stream, const BwdComp* bc) {
   typedef TfSlots<TBMAX> SL;
   const unsigned grid = tf_grid(n);
+  const TfLaunch la = {io, img, wT, bfimg, slabs, grid, stream};
   int rc;
-#define LAUNCH_TF(P_, S_, FU_)                                                                                                   \
-  do {                                                                                                                           \
-    rc = set_lds(field_bwd_tf_kernel<P_, S_, TBMAX, FU_>, part[P_].lds);                                                         \
-    if (rc) return rc;                                                                                                           \
-    hipLaunchKernelGGL((field_bwd_tf_kernel<P_, S_, TBMAX, FU_>), dim3(grid), dim3(256), part[P_].lds, umhs_s(stream), io,       \
-                       part[P_].pd, part[P_].td, img, wT, part[P_].seg_f, part[P_].seg_t, part[P_].wt_off, bfimg, part[P_].seg_b, \
-                       part[P_].bf_off, part[P_].bo, slabs);                                                                     \
-  } while (0)
-  // bf_mask bit p: part p runs the three-piece bf16 chain = the kernels with the zipped instruction schedule (umhs_field_zip.h); else the
-  // fp32 chain (field_bwd_tf_kernel).  Measured (rocprofv3, C2) against the unzipped bf16x3 kernels they replaced: part 0 114.9 -> 110.9 us,
-  // part 1 114.5 -> 106.9 us; whole backward C3 604 -> 577 us, C5 457 -> 433 us.
-#define LAUNCH_TFZ0(S_, FU_)                                                                                                          \
-  do {                                                                                                                                \
-    rc = set_lds(field_bwd_tfz0_kernel<S_, TBMAX, FU_>, part[0].lds);                                                                 \
-    if (rc) return rc;                                                                                                                \
-    hipLaunchKernelGGL((field_bwd_tfz0_kernel<S_, TBMAX, FU_>), dim3(grid), dim3(256), part[0].lds, umhs_s(stream), io, part[0].pd,  \
-                       part[0].td, img, wT, part[0].seg_f, part[0].seg_t, part[0].wt_off, bfimg, part[0].seg_b, part[0].bf_off,       \
-                       part[0].bo, slabs);                                                                                            \
-  } while (0)
-  // (instantiated: what run_field_bwd can select -- the zipped part 0 with the specular head up to 4 band tiles, 8 in the folded form
-  // only; the fp32 chain with it up to 12)
-#define LAUNCH_P0(FU_)                                     \
-  do {                                                     \
-    if ((bf_mask & 1) && spec) {                           \
-      if constexpr (TBMAX < 8 || (TBMAX == 8 && FU_)) {    \
-        LAUNCH_TFZ0(true, FU_);                            \
-      } else {                                             \
-        return UMHS_ERR_UNSUPPORTED;                       \
-      }                                                    \
-    } else if (bf_mask & 1) {                              \
-      if constexpr (TBMAX < 16 || FU_) {                   \
-        LAUNCH_TFZ0(false, FU_);                           \
-      } else {                                             \
-        return UMHS_ERR_UNSUPPORTED;                       \
-      }                                                    \
-    } else if (spec) {                                     \
-      if constexpr (TBMAX <= 12) {                         \
-        LAUNCH_TF(0, true, FU_);                           \
-      } else {                                             \
-        return UMHS_ERR_UNSUPPORTED;                       \
-      }                                                    \
-    } else {                                               \
-      LAUNCH_TF(0, false, FU_);                            \
-    }                                                      \
-  } while (0)
   if (bc) {
     hipLaunchKernelGGL(field_mix_grad_kernel, dim3((unsigned)((bc->n_rays + 15) / 16)), dim3(256), (size_t)32 * (bc->B | 1) * 4,
                        umhs_s(stream), bc->d_comp, bc->E, bc->n_rays, bc->B, bc->C, bc->mix_g);
-    LAUNCH_P0(true);
+    rc = (bf_mask & 1) ? launch_tf_p0z<TBMAX>(part[0], la, spec, true) : launch_tf_p0f<TBMAX>(part[0], la, spec, true);
+    if (rc) return rc;
     UMHS_CHECK_LAUNCH();
     rc = umhs_composite_bwd_dots(bc->sigma, bc->t0, bc->t1, bc->packed_info, bc->n_rays, n, bc->weights, bc->dots, bc->d_acc,
                                  bc->grad_scaling, bc->d_sigma, stream);
     if (rc) return rc;
   } else {
-    LAUNCH_P0(false);
-  }
-#undef LAUNCH_P0
-#undef LAUNCH_TFZ0
-  if (bf_mask >> 1 & 1) {
-    rc = set_lds(field_bwd_tfz1_kernel<TBMAX>, part[1].lds);
+    rc = (bf_mask & 1) ? launch_tf_p0z<TBMAX>(part[0], la, spec, false) : launch_tf_p0f<TBMAX>(part[0], la, spec, false);
     if (rc) return rc;
-    hipLaunchKernelGGL((field_bwd_tfz1_kernel<TBMAX>), dim3(grid), dim3(256), part[1].lds, umhs_s(stream), io, part[1].pd, part[1].td, img, wT,
-                       part[1].seg_f, part[1].seg_t, part[1].wt_off, bfimg, part[1].seg_b, part[1].bf_off, part[1].bo, slabs);
-  } else {
-    LAUNCH_TF(1, false, false);  // (part 1 does not depend on the specular head)
   }
-#undef LAUNCH_TF
+  rc = launch_tf_p1<TBMAX>(part[1], la, bf_mask >> 1 & 1);
+  if (rc) return rc;
   UMHS_CHECK_LAUNCH();
   TfMap mp;
   fill_tf_map<TBMAX>(&mp, spec, pl.TB);
@@ -2797,3 +2793,4 @@ extern "C" int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_f
   return run_field_bwd(cfg, params, enc, stride_n, stride_l, world_pos, directions, selector, sigma_raw, emb, feat_logits, n, d_sigma,
                        nullptr, nullptr, d_enc, grads, workspace, workspace_bytes, packs_ready, stream, &bc);
 }
+#endif  // UMHS_TU_MAIN

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 7  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
+ABI_VERSION = 8  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
 LIB_PATH = os.environ.get("UMHS_LIB_PATH") or os.path.join(_HERE, "libumhs_hip.so")  # override: A/B builds of tools/ab_lib.sh
 MAX_STREAMS = 4
 
@@ -60,8 +60,6 @@ SIGNATURES = {
     "umhs_field_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FieldCfg)]),
     "umhs_field_fwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _vp, _vp, _i64,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
-    "umhs_field_density": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _vp, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp, _vp,
-                                     C.c_size_t, C.c_int, _vp]),
     "umhs_field_fwd_prepare": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, C.c_size_t, _vp]),
     "umhs_field_base_fwd": (C.c_int, [C.POINTER(FieldCfg), C.POINTER(FieldParams), _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                      C.c_size_t, C.c_int, _vp]),

@@ -4,12 +4,16 @@ from __future__ import annotations
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libumhs_hip.so")
 SOURCES = ("umhs_kernels.hip", "umhs_field.hip", "umhs_sampler.hip", "umhs_data.hip", "umhs_metrics.hip")
+# umhs_field.hip compiles as four translation units side by side (its header comment): object suffix -> extra defines
+UNITS = {"umhs_field.hip": (("_p0", ["-DUMHS_FIELD_TU=1", "-Wno-unused-function"]), ("_p1", ["-DUMHS_FIELD_TU=2", "-Wno-unused-function"]),
+                            ("_p0f", ["-DUMHS_FIELD_TU=3", "-Wno-unused-function"]), ("", ["-DUMHS_FIELD_TU=0"]))}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-munsafe-fp-atomics", "-std=c++17"]
 # umhs_field.hip: MFMAs written as builtins get the VGPR C/D form even in the kernels whose register budget exceeds 256 (the
 # transpose-free backward); their long-lived dW accumulators are inline-asm MFMAs on AGPRs (see dw_row in that file)
@@ -42,19 +46,22 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs, running = [], []
+    objs, running, t0 = [], [], time.time()
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        objs.append(obj)
-        if not force and not _obj_stale(os.path.join(CSRC, src), obj):
-            continue
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        running.append((cmd, subprocess.Popen(cmd)))
+        for suffix, defines in UNITS.get(src, (("", []),)):
+            obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
+            objs.append(obj)
+            if not force and not _obj_stale(os.path.join(CSRC, src), obj):
+                continue
+            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *defines, f"-I{INCLUDE}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
     for cmd, proc in running:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
+        if verbose:
+            print(f"[build] {os.path.basename(cmd[-1])}: done {time.time() - t0:.0f} s after the start", flush=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -354,20 +354,16 @@ def field_heads_fwd(spec: FieldSpec, flat, emb, wpos, dirs, weights, ray_indices
     return o
 
 
-def field_density(spec: FieldSpec, flat, pos01, sel, want_emb: bool = True):
-    """density_fn in one launch (hash gather inside the MLP kernel): -> {"sigma" [N], "sigma_raw" [N], "emb" [N,15] | None}."""
-    n = sel.shape[0]
-    L = spec.layout
-    dev = sel.device
-    cfg = spec.cfg(True)
-    pp = L.c_struct(flat, _hip.FieldParams)
-    o = field_fwd_outputs(spec, n, dev, True, want_emb, True, False)
-    _require_free(dev, WS_FIELD_FWD, "field_density (pack image rebuild)")
-    ws = _workspace(_hip.lib().umhs_field_fwd_workspace_bytes(C.byref(cfg)), dev, slot=2)
-    _hip.check(_hip.lib().umhs_field_density(C.byref(cfg), C.byref(pp), ptr(pos01), ptr(L.view(flat, "mlp_base.encoder.hash_table")),
-                                             ptr(spec.scalings), L.log2_hashmap_size, ptr(sel), n, ptr(o["sigma"]), ptr(o["sigma_raw"]),
-                                             ptr(o["emb"]), ptr(ws), ws.numel(), 0, _hip.stream()), "umhs_field_density")
-    return o
+def field_density(spec: FieldSpec, flat, pos01, sel, want_emb: bool = True, keep=None):
+    """density_fn: hash-grid gather + density-only field forward (two launches; the level-major features live in a per-device scratch,
+    or in ``keep["enc"]`` for a caller that reuses them) -> {"sigma" [N], "sigma_raw" [N], "emb" [N,15] | None}."""
+    n, L = sel.shape[0], spec.layout
+    if keep is None:
+        enc = _scratch(sel.device, "density_enc", NUM_LEVELS * n * 8)[: NUM_LEVELS * n * 8].view(torch.float32).view(NUM_LEVELS, n, 2)
+    else:
+        enc = keep["enc"] = torch.empty((NUM_LEVELS, n, 2), device=sel.device, dtype=torch.float32)
+    hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True, out=enc)
+    return field_fwd(spec, flat, enc, True, None, None, sel, density_only=True, want_emb=want_emb)
 
 
 _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -760,13 +756,7 @@ class DensityFn(torch.autograd.Function):
         L = spec.layout
         p = _hip.f32c(positions).view(-1, 3)
         _, pos01, sel = positions_fwd(None, None, None, None, spec, world_pos_in=p)
-        if keep is None and os.environ.get("UMHS_FUSED_DENSITY", "1") != "0":
-            out = field_density(spec, flat.detach(), pos01, sel, want_emb)  # one launch, no [N,32] feature array
-        else:
-            enc = hashgrid_fwd(pos01, L.view(flat.detach(), "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
-            out = field_fwd(spec, flat.detach(), enc, True, None, None, sel, density_only=True, want_emb=want_emb)
-            if keep is not None:
-                keep["enc"] = enc
+        out = field_density(spec, flat.detach(), pos01, sel, want_emb, keep)
         if out["emb"] is None:  # density_fn callers (sampler, occupancy grid) only want sigma: 60 B per sample not written
             out["emb"] = out["sigma"].new_empty(0)
         ctx.mark_non_differentiable(out["sigma"], out["emb"])
