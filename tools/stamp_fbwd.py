@@ -31,7 +31,9 @@ NAMES = {0: {1: "head fwd H0 H1 H2", 2: "epilogue + dir fwd + swaps", 3: "band t
          1: {1: "base fwd B0 B1", 2: "feature fwd F0 F1", 7: "swap x27", 8: "swap a2, dW2", 9: "T2 chain + mask", 10: "swap dz1, a1", 11: "dW1 (4x4)",
              12: "T1 chain + mask", 13: "swap dz0, dW0 (4x2)", 14: "T0 chain", 15: "base: swap z1, h, dW B1", 16: "T_B1 + swaps + dW B0",
              17: "T_B0 chain", 18: "store d_enc"}}
-if os.environ.get("UMHS_BWD_TF", "3") != "1":  # the zipped part 1 (csrc/umhs_field_zip.h): VALU blocks with their slots, gemms bare (part 0's zipped kernel carries no stamps)
+if os.environ.get("UMHS_BWD_TF", "3") != "1":  # the zipped kernels (csrc/umhs_field_zip.h): part 1 VALU blocks with their slots, gemms bare; part 0 by stretch
+    NAMES[0] = {1: "head MLP forward (zipped)", 2: "epilogue + dir hidden fwd", 3: "swaps m, dir, pe, hdir", 4: "band tiles", 5: "per-ray sums (folded)",
+                6: "head outputs", 7: "dir hidden dW", 8: "head MLP backward (zipped)", 9: "store + end slots"}
     NAMES[1] = {1: "V: pe, split enc", 2: "gemm B0", 3: "V: relu + split h", 4: "gemm B1", 5: "V: split in27", 6: "gemm F0", 7: "V: relu + split a1",
                 8: "gemm F1", 9: "V: relu + split a2, d_fl", 10: "fp32 gemm T_F2", 11: "V: mask + split dz1", 12: "gemm T_F1", 13: "V: mask + split dz0",
                 14: "gemm T_F0", 15: "V: dzb1 + fp32 gemm T_B1", 16: "V: mask + split dzb0", 17: "gemm T_B0", 18: "store + end slots"}

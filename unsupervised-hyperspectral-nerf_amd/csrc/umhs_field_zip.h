@@ -177,7 +177,11 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz1_kernel(FieldIO io, Pack
   for (int t = 0; t < NTILES; ++t) S[t].hi = S[t].lo = v4s{0, 0, 0, 0};
   auto run_op = [&](auto idc) __attribute__((always_inline)) {
     constexpr int pos = decltype(idc)::value;
+#ifdef UMHS_ABL_NO_OPS  // timing-only ablation (tools/alt_build.py): the chain alone, no transposes / packs / dW products
+    if constexpr (false) {
+#else
     if constexpr (pos >= 0) {
+#endif
       constexpr zip::Op o = ORDER.op[pos];
       if constexpr (o.job == J_TR) {
         constexpr int tile = o.idx >> 1, piece = o.idx & 1;
@@ -600,7 +604,11 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
   for (int t = 0; t < NTILES; ++t) S[t].hi = S[t].lo = v4s{0, 0, 0, 0};
   auto run_op = [&](auto idc) __attribute__((always_inline)) {
     constexpr int pos = decltype(idc)::value;
+#ifdef UMHS_ABL_NO_OPS  // timing-only ablation (tools/alt_build.py): the chain alone, no transposes / packs / dW products
+    if constexpr (false) {
+#else
     if constexpr (pos >= 0) {
+#endif
       constexpr zip::Op o = ORDER.op[pos];
       if constexpr (o.job == J_TR) {
         constexpr int tile = o.idx >> 1, piece = o.idx & 1;
@@ -669,6 +677,12 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
     if (!ok) n = io.n - 1;
     if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
     ZSB();
+#ifdef UMHS_TF_STAMP
+    unsigned long long stamp_[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) stamp_[k] = 0;
+#endif
+    TF_STAMP(0);
       // This tile's upstream gradients, all band tiles: requested here, consumed after the head MLP's forward recompute (with one
       // wave per SIMD a load issued next to its use costs its whole latency: one band tile ahead was 585 us at 128 bands)
       float dall[TBMAX][4];  // FUSED: the ray's d_comp row (unscaled; [R,B] stays in L2), else this sample's d_spectral row
@@ -771,6 +785,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
       gemm_bfp<1, 2, 2>(hd4[0], B, preH2, wbf + bo.f[L_H2], lane);
       ZSB();
     }
+    TF_STAMP(1);
     // =================== head epilogue, directional layers, band tiles, head outputs: as in field_bwd_tf_kernel<0> ====================
     float dhs[NT][4];
     {
@@ -784,6 +799,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
         gemm_bf<1, 7, 1, 2>(d4, dir28, wbf + bo.f[L_D0], lds + pd.L[L_D0].off_b, lane);
         relu_to<1, NT>(hdir, d4);
       }
+      TF_STAMP(2);
       STile dirS[2], hdirS[1], mS[1];  // dirS[0]: SH c, dirS[1]: the positional encoding (this stretch's own copy of that tile: the
       {                                // plan transposes the head MLP's input tiles late, next to the dW products that read them)
         mS[0] = to_swapped<false>(hs.m[0], ident);
@@ -795,6 +811,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
         }
       }
       
+      TF_STAMP(3);
       // =================== band tiles: mixing and the specular tail (the next tile's gradients are requested a tile ahead) ===
       // (two accumulators each for d m and d hdir, even / odd band tiles: consecutive tiles do not wait for each other's MFMAs)
       v4f dm4[NT][1], dhd4[NT][1], dm4b[NT][1], dhd4b[NT][1];
@@ -834,6 +851,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
         }
       }
       
+      TF_STAMP(4);
       dm4[0][0] += dm4b[0][0], dhd4[0][0] += dhd4b[0][0];
       if (FUSED) {
 #pragma unroll
@@ -868,6 +886,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
         }
 #endif
       }
+      TF_STAMP(5);
       ds1 = xq_sum(ds1);
       // =================== head outputs: sigmoid scalars, temperature softmax, specular gate ==========================
       {
@@ -892,6 +911,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
         }
       }
       if (ok) *reinterpret_cast<v4f*>(io.d_fl + n * 16 + 4 * q) = v4f{dfl[0][0], dfl[0][1], dfl[0][2], dfl[0][3]};
+      TF_STAMP(6);
       if (SPEC) {  // mlp_directional hidden layer
         float dz[4];
 #pragma unroll
@@ -901,6 +921,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
         dw_pairs<1, 2>(&acc_[SL::A_D0 - A0], dzS, dirS);
       }
     }
+    TF_STAMP(7);
     ZSB();
     // =================== backward: head MLP (zipped) ================================================================================
     split2(IC(S_O + 0 * P2), dhs[0][0], dhs[0][1], pH[T_ZO][0], pM[T_ZO][0]);
@@ -942,6 +963,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
       gemm_bfp<1, 2, 1>(dbo4, B, preT0, wbf + bo.t[T_H0], lane);
       ZSB();
     }
+    TF_STAMP(8);
     if (ok) *reinterpret_cast<v4f*>(io.d_bo + n * 16 + 4 * q) = dbo4[0];
     ZSLOT(S_END);
     ZNOP2();
@@ -955,6 +977,15 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
     ZNOP2();
     ZSLOT(S_END + 5);
     static_assert(N_END == 6, "end slots");
+    TF_STAMP(9);
+#ifdef UMHS_TF_STAMP
+    if (blockIdx.x == 0 && tid == 0) {
+      unsigned long long last = stamp_[0];
+      for (int k = 1; k < 19; ++k)
+        if (stamp_[k]) g_tf_stamp[0][k] += stamp_[k] - last, last = stamp_[k];
+      g_tf_stamp[0][0] += 1;
+    }
+#endif
     cur = nxt;
   }
   // ---- operations the last tile left for a next one ---------------------------------------------------------------------------------------
