@@ -99,6 +99,43 @@ def main():
     other = pa.clone()
     dist.broadcast(other, src=0)
     ok = ok and torch.equal(other, pa) and not torch.equal(pa, before)
+    # the C5 shape of the reference's scripts/rgb+spectral.sh (141 bands, 4 endmembers, no specular head, gradient accumulation 3): the
+    # folded compositing backward deposits into the sink three times per window, the exchange runs on the third micro-step only
+    B5, C5 = 141, 4
+    bands5 = list(np.linspace(400, 1000, B5))
+    b5 = synthetic_batch(R, S, B5, seed=17 + rank, device=device)
+    rs5 = packed_ray_samples(b5["origins"], b5["directions"], b5["starts"], b5["ends"])
+    pinfo5 = ops.pack_info(b5["ray_indices"], R)
+
+    def run_c5(async_reduce):
+        torch.manual_seed(13)
+        torch.cuda.manual_seed(13)
+        mc5 = UMHSConfig(method="rgb+spectral", pred_specular=False, temperature=0.4)
+        pipe = UMHSPipeline.from_packed_samples(mc5, device, metadata={"wavelengths": bands5, "num_classes": C5}, world_size=world, local_rank=dev_index,
+                                                seed=5, gradient_accumulation_steps=3)
+        trained_like_init(pipe.model.field, seed=5)
+        dist.broadcast(pipe.model.field.flat.data, src=0)
+        pipe.model.field._spec()
+        pipe.model.field._grad_sink.async_reduce = async_reduce
+        with torch.no_grad():
+            batch5 = {"image": pipe.model.converter(b5["gt_spectral"]), "hs_image": b5["gt_spectral"]}
+        start = pipe.model.field.flat.detach().clone()
+        after = []
+        for it in range(6):  # two windows = two optimizer steps
+            pipe.train_iteration(rs5, b5["ray_indices"], R, batch5, packed_info=pinfo5)
+            after.append(pipe.model.field.flat.detach().clone())
+        # parameters move on the third and sixth micro-step only
+        moved = [not torch.equal(x, y) for x, y in zip([start] + after[:-1], after)]
+        return after[-1], moved
+
+    p5a, moved_a = run_c5(True)
+    p5s, moved_s = run_c5(False)
+    other = p5a.clone()
+    dist.broadcast(other, src=0)
+    ok5 = torch.equal(other, p5a) and torch.equal(p5a, p5s) and moved_a == [False, False, True, False, False, True] == moved_s
+    if not ok5:
+        print(rank, "C5 accumulation window mismatch", moved_a, moved_s, float((p5a - p5s).abs().max()), flush=True)
+    ok = ok and ok5
     flag = torch.tensor([1 if ok else 0], device=flag_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

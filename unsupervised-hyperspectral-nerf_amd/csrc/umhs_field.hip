@@ -2176,11 +2176,10 @@ extern "C" int umhs_field_base_fwd(const umhs_field_cfg* cfg, const umhs_field_p
   io.temperature = cfg->temperature, io.sigma = sigma, io.sigma_raw = sigma_raw, io.emb = emb, io.bo16 = base16;
   if (base16 && ((uintptr_t)base16 & 15)) return UMHS_ERR_ARG;
   const int64_t ntiles = (n + 127) / 128;
-  // Workgroups per CU (UMHS_BASE_WGS).  Alone the kernel is fastest with 4 (33 us at 524 k samples; 44 us with 1) -- inside the training
+  // One workgroup per CU.  Alone the kernel is fastest with 4 (33 us at 524 k samples; 44 us with 1) -- inside the training
   // step ONE is 45-50 us faster end to end (C3 1.67 vs 1.72 ms, C5 1.49 vs 1.54, three A/B pairs): the bucket histogram of the hash-grid
   // backward runs on the side stream at that moment, and a kernel that fills every CU pushes it under the heads kernel instead.
-  static const int base_wgs = getenv("UMHS_BASE_WGS") ? atoi(getenv("UMHS_BASE_WGS")) : 1;
-  const unsigned grid = (unsigned)(ntiles < 256 * base_wgs ? ntiles : 256 * base_wgs);
+  const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
   rc = set_lds(field_fwd_kernel<false, true, 2, 4, true>, fp.lds);
   if (rc) return rc;
   hipLaunchKernelGGL((field_fwd_kernel<false, true, 2, 4, true>), dim3(grid), dim3(256), fp.lds, umhs_s(stream), io, fp.pd,

@@ -638,10 +638,7 @@ extern "C" int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalin
   HbArgs a;
   int rc = hb_args(&a, pos01, scalings, n, level_begin, n_levels, log2_T, workspace, workspace_bytes);
   if (rc) return rc;
-  static const int throttle = [] {  // workgroups per level of the hidden histogram pass (0 = unthrottled)
-    const char* e = getenv("UMHS_HB_COUNT_WGS");
-    return e ? atoi(e) : 16;
-  }();
+  const int throttle = 16;  // workgroups per level of the hidden histogram pass (unthrottled it delays the forward's workgroups)
   return hb_run_prepare(a, n_levels, throttle, stream);
 }
 

@@ -95,7 +95,7 @@ class FlatGradSink:
         # Two 8-level (33.5 MB) messages by default: RCCL's ring all-reduce over xGMI loses ~30 % of its bus bandwidth at 16 MB, so
         # finer groups buy less overlap than they cost in transfer time; UMHS_REDUCE_GROUPS overrides (1, 2, 4, 8, 16).
         self.level_groups = int(level_groups if level_groups is not None else os.environ.get("UMHS_REDUCE_GROUPS", "2"))
-        self.async_reduce = os.environ.get("UMHS_ASYNC_REDUCE", "1") != "0"
+        self.async_reduce = True  # exchanges are issued as soon as a level group's gradient is final and waited for in front of the optimizer
         self.reduced_ptr = None
         self.sparse_levels, self.sparse_rows = 0, None  # set_sparse_levels(): coarse levels travel as their live rows only
         self.fused_adam, self.adam_done = None, None  # UMHSAdam.arm_fused() / what the backward then did (step, begin, end)
@@ -105,8 +105,6 @@ class FlatGradSink:
     def set_sparse_levels(self, scalings, log2_T: int) -> None:
         """Coarse hash levels use a small, rank-independent subset of their 2^log2_T slots (4,913 of 524,288 at level 0): send the
         live rows of those levels as one compact message instead of their whole slabs (-15 MB of 67 MB at the reference sizes)."""
-        if os.environ.get("UMHS_SPARSE_REDUCE", "1") == "0":
-            return
         self.sparse_levels, rows = live_hash_rows(scalings, log2_T)
         self.sparse_rows = rows.to(self.param.device) if self.sparse_levels else None
         self.table_rows = 1 << log2_T

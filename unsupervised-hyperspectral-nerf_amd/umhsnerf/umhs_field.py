@@ -152,7 +152,7 @@ class UMHSField(nn.Module):
         return res
 
     def _spec(self) -> ops.FieldSpec:
-        if self._sparse_end and os.environ.get("UMHS_SPARSE_ADAM", "1") != "0":
+        if self._sparse_end:
             self.flat._umhs_live_rows = (self.live_rows, self._sparse_end)
         c = self._spec_cache
         if c is None or c.scalings.device != self.scalings.device or c.temperature != float(self.temperature):

@@ -585,7 +585,7 @@ class UMHSModel(ModelBase):
             md["rmse_spectral"] = lambda: torch.sqrt(torch.nn.functional.mse_loss(spec, gt))
         md["num_samples_per_batch"] = lambda: nspr.sum()
         lazy = LazyMetrics(md)
-        return lazy if (self.training and os.environ.get("UMHS_LAZY_METRICS", "1") != "0") else dict(lazy.materialize())
+        return lazy if self.training else dict(lazy.materialize())
 
     @torch.no_grad()  # as nerfstudio's Model.get_outputs_for_camera_ray_bundle
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
