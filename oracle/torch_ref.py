@@ -452,8 +452,9 @@ def field_outputs(p: FieldParams, origins, directions, starts, ends, emb: Tensor
             out["spectral"] = spec
         out["abundances"] = abund
     else:
+        # NerfactoField.mlp_head: out_activation=nn.Sigmoid()  [upstream-recalled: nerfstudio 1.1.5 fields/nerfacto_field.py]
         h = torch.cat([d, emb.view(-1, p.geo)], dim=-1)
-        out["rgb"] = mlp_forward(h, list(p.head_w), list(p.head_b)).view(N, 3)
+        out["rgb"] = mlp_forward(h, list(p.head_w), list(p.head_b), "sigmoid").view(N, 3)
     return out
 
 
@@ -470,7 +471,7 @@ def model_outputs(
     use_gradient_scaling: bool = True,
     contraction: bool = True,
 ) -> Dict[str, Tensor]:
-    """``UMHSModel.get_outputs`` after the sampler, ``umhs_model.py:239-313`` (spectral methods)."""
+    """``UMHSModel.get_outputs`` after the sampler, ``umhs_model.py:239-313`` (spectral methods; ``method="rgb"``: rgb / accumulation / depth)."""
     density, emb, _, _ = field_density(p, origins, directions, starts, ends, contraction)
     fo = field_outputs(p, origins, directions, starts, ends, emb, temperature)
     fo["density"] = density
@@ -483,6 +484,13 @@ def model_outputs(
         "accumulation": accumulate_along_rays(weights[..., 0], None, ray_indices, num_rays),
         "weights": weights,
     }
+    if p.method == "rgb":
+        # umhs_model.py:265-267.  The reference omits ray_indices / num_rays here, so nerfstudio's RGBRenderer sums over ALL packed
+        # samples of the batch (one colour for every ray) -- a defect, not a behaviour to restate: per-ray compositing, as for every
+        # other output.  background_color="random": no blend in the forward  [upstream-recalled].
+        out["rgb"] = accumulate_along_rays(weights[..., 0], fo["rgb"], ray_indices, num_rays)
+        out["num_samples_per_ray"] = pinfo[:, 1]
+        return out
     spectral = spectral_renderer(fo["spectral"], weights, ray_indices, num_rays)
     out["spectral"] = spectral
     if p.pred_specular:

@@ -139,6 +139,30 @@ def test_model_kwargs_follow_the_reference_pipeline_call():
     assert float(m.field.endmembers.min()) == 0.0 and float(m.field.endmembers.max()) == 1.0
 
 
+def test_config_defaults_are_the_references_and_the_default_method_builds_the_rgb_field():
+    """umhs_model.py:61-119: every default, ``method="rgb"`` (:108) and ``implementation="torch"`` (:104) included; the default method
+    is NerfactoField's colour head (umhs_field.py:280-294): mlp_base + mlp_head(31 -> 64 -> 64 -> 3), none of the spectral heads."""
+    from umhsnerf.umhs_model import UMHSConfig
+
+    c = UMHSConfig()
+    ref = dict(method="rgb", implementation="torch", grid_resolution=128, grid_levels=4, max_res=2048, log2_hashmap_size=19, alpha_thre=0.01,
+               cone_angle=0.004, near_plane=0.05, far_plane=1e3, use_gradient_scaling=True, use_appearance_embedding=True,
+               background_color="random", disable_scene_contraction=False, rgb_loss_weight=1.0, temperature=0.2, pred_specular=False,
+               load_vca=False, pred_dino=False)
+    assert {k: getattr(c, k) for k in ref} == ref
+    m = UMHSConfig(log2_hashmap_size=10).setup(scene_box=None, num_train_data=1, metadata={"wavelengths": [400.0 + i for i in range(8)], "num_classes": 3},
+                                               num_classes=3, seed=0)
+    assert type(m.field).__name__ == "UMHSRGBField"
+    keys = {k for k in m.state_dict() if k.startswith("field.")}
+    assert keys == {"field.aabb", "field.mlp_base.encoder.hash_table"} | {f"field.{n}.layers.{i}.{w}" for n, k in (("mlp_base.mlp", 2), ("mlp_head", 3))
+                                                                               for i in range(k) for w in ("weight", "bias")}
+    assert m.state_dict()["field.mlp_head.layers.0.weight"].shape == (64, 31) and m.state_dict()["field.mlp_head.layers.2.weight"].shape == (3, 64)
+    from umhsnerf._ns_compat import TrainingCallbackLocation as Loc
+
+    assert [cb.where_to_run for cb in m.get_training_callbacks(None)] == [[Loc.BEFORE_TRAIN_ITERATION]]  # no clamp_endmembers (umhs_model.py:567)
+    assert m.make_optimizer().defaults["clamp_range"] == (0, 0)
+
+
 def test_background_color_last_sample_of_the_spectral_script_is_black_in_the_loss_blend():
     """scripts/spectral.sh:6 passes ``--pipeline.model.background-color last_sample``; RGBRenderer.blend_background_for_loss_computation
     (umhs_renderer.py:108-109) blends the ground truth over black in that case and leaves the prediction alone."""

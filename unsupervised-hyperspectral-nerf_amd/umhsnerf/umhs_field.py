@@ -56,8 +56,8 @@ class UMHSField(nn.Module):
         super().__init__()
         # "tcnn"/"torch" in existing scripts (scripts/hotdog.sh:7) select this HIP implementation too
         if method == "rgb":
-            raise NotImplementedError("method='rgb' (umhs_field.py:280-294) is the reference's CPU plumbing config; "
-                                      "the HIP field implements the spectral methods")
+            raise NotImplementedError("method='rgb' (umhs_field.py:280-294) is NerfactoField's colour head: umhs_field_rgb.UMHSRGBField "
+                                      "(UMHSModel builds it); this class is the field of the two spectral methods")
         if pred_dino:
             raise NotImplementedError("pred_dino needs the reference's missing dino modules (SURVEY §2); out of scope")
         if num_layers_color != 3 or hidden_dim_color != 64 or max_res != 2048 or appearance_embedding_dim != 0:

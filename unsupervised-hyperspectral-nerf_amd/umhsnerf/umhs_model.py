@@ -26,6 +26,7 @@ from .sampler import OccGridEstimator, VolumetricSampler
 from .umhs_field import UMHSField
 from .umhs_renderer import SpectralRenderer
 from .utils.clusterprobe import ClusterLookup
+from .umhs_field_rgb import UMHSRGBField
 from .utils.spec_to_rgb import ColourSystem
 
 CLASS_COLORS = torch.tensor([
@@ -37,9 +38,9 @@ CLASS_COLORS = torch.tensor([
 
 @dataclass
 class UMHSConfig(ModelConfigBase):
-    """``UMHSConfig(InstantNGPModelConfig)``, umhs_model.py:61-119: same names, same defaults with ONE exception -- ``method`` defaults
-    to ``"rgb+spectral"`` where the reference has ``"rgb"`` (:108): the HIP field implements the two spectral methods (every script of
-    the reference but scripts/rgb.sh passes ``--pipeline.model.method`` anyway; ``"rgb"`` raises NotImplementedError in UMHSField).
+    """``UMHSConfig(InstantNGPModelConfig)``, umhs_model.py:61-119: same names, same defaults (``method="rgb"``, :108, included: the
+    reference's default method is NerfactoField's own colour head, served by umhs_field_rgb.py; every script of the reference but
+    scripts/rgb.sh passes ``--pipeline.model.method rgb+spectral``, the path this package exists for).
     ``implementation`` keeps the reference's default ``"torch"`` (:104) and its ``"tcnn"`` (scripts/hotdog.sh:7): all values select the
     HIP kernels, whose arithmetic is the torch path's.  A nerfstudio ``ModelConfig`` when nerfstudio is importable
     -- not an ``InstantNGPModelConfig``, whose model would build tcnn / nerfacc modules first."""
@@ -63,7 +64,7 @@ class UMHSConfig(ModelConfigBase):
     background_color: Literal["random", "last_sample", "black", "white"] = "random"
     disable_scene_contraction: bool = False
     implementation: Literal["hip", "tcnn", "torch"] = "torch"
-    method: Literal["rgb", "spectral", "rgb+spectral"] = "rgb+spectral"
+    method: Literal["rgb", "spectral", "rgb+spectral"] = "rgb"
     rgb_loss_weight: float = 1.0
     spectral_loss_weight: float = 1.0  # unused by the reference's loss too (hard-coded 5, umhs_model.py:369)
     temperature: float = 0.2
@@ -197,15 +198,12 @@ class UMHSModel(ModelBase):
             # umhs_model.py:181: the reference's flag is inverted -- False is what switches its 32-d per-image embedding ON (no script
             # does); that input of the rgb / specular heads is not built here, and ignoring the flag would silently train another model
             raise NotImplementedError("use_appearance_embedding=False (= the reference's 32-d appearance embedding, umhs_model.py:181) is not supported")
-        self.field = UMHSField(
-            aabb=self.scene_aabb_t, num_images=self.num_train_data, implementation=c.implementation,
-            log2_hashmap_size=c.log2_hashmap_size, max_res=c.max_res,
-            spatial_distortion=None if c.disable_scene_contraction else "linf",
-            appearance_embedding_dim=0,  # the reference's inverted flag yields 0 with the default config (:181)
-            method=c.method, wavelengths=len(wl) if "spectral" in c.method else 0, num_classes=self.kwargs["num_classes"],
-            temperature=c.temperature, converter=self.converter, pred_dino=c.pred_dino, pred_specular=c.pred_specular,
-            load_vca=c.load_vca, seed=self._seed,
-        )
+        if c.method == "rgb":  # the reference's default method = NerfactoField's own colour head (umhs_field.py:280-294): umhs_field_rgb.py
+            self.field = UMHSRGBField(aabb=self.scene_aabb_t, num_images=self.num_train_data, log2_hashmap_size=c.log2_hashmap_size,
+                                      max_res=c.max_res, spatial_distortion=None if c.disable_scene_contraction else "linf",
+                                      appearance_embedding_dim=0, seed=self._seed)
+        else:
+            self.field = self._spectral_field(c, wl)
         self.scene_aabb = nn.Parameter(self.scene_aabb_t.flatten(), requires_grad=False)
         if c.render_step_size is None:
             c.render_step_size = float(((self.scene_aabb_t[1] - self.scene_aabb_t[0]) ** 2).sum().sqrt() / 1000)
@@ -214,6 +212,17 @@ class UMHSModel(ModelBase):
         self.sampler = VolumetricSampler(self.occupancy_grid, density_fn=self.field.density_fn)
         self.cluster_probe = ClusterLookup(len(wl), self.kwargs["num_classes"])
         self.background_color = c.background_color
+
+    def _spectral_field(self, c, wl) -> UMHSField:
+        return UMHSField(
+            aabb=self.scene_aabb_t, num_images=self.num_train_data, implementation=c.implementation,
+            log2_hashmap_size=c.log2_hashmap_size, max_res=c.max_res,
+            spatial_distortion=None if c.disable_scene_contraction else "linf",
+            appearance_embedding_dim=0,  # the reference's inverted flag yields 0 with the default config (:181)
+            method=c.method, wavelengths=len(wl) if "spectral" in c.method else 0, num_classes=self.kwargs["num_classes"],
+            temperature=c.temperature, converter=self.converter, pred_dino=c.pred_dino, pred_specular=c.pred_specular,
+            load_vca=c.load_vca, seed=self._seed,
+        )
 
     @property
     def device(self):
@@ -228,8 +237,8 @@ class UMHSModel(ModelBase):
 
     def make_optimizer(self, lr: float = 2e-2, eps: float = 1e-15, lr_final: Optional[float] = 1e-5, max_steps: int = 30000) -> UMHSAdam:
         L = self.field.layout
-        off, shp = L.entries["endmembers"]
-        return UMHSAdam(self.get_param_groups()["fields"], lr=lr, eps=eps, clamp_range=(off, off + int(np.prod(shp))),
+        off, shp = L.entries.get("endmembers", (0, ()))  # (method="rgb" has no endmembers: nothing to clamp)
+        return UMHSAdam(self.get_param_groups()["fields"], lr=lr, eps=eps, clamp_range=(off, off + (int(np.prod(shp)) if shp else 0)),
                         lr_final=lr_final, max_steps=max_steps)
 
     def clamp_endmembers(self, step: int = 0) -> None:
@@ -264,14 +273,10 @@ class UMHSModel(ModelBase):
     def sample(self, ray_bundle: RayBundle):
         """The sampler call of umhs_model.py:229-237 (no-grad): packed ray samples + ray_indices."""
         c = self.config
-        # Two ways to feed the training forward its hash features: gather the survivors' rows out of the encoding the sampler's
-        # density query produced (default), or let that query run as one fused gather+MLP launch that never writes the
-        # [candidates, 32] array and hash the survivors again (UMHS_REUSE_ENC=0).  Measured (3.5 M candidates, 0.9 M survivors):
-        # the fused query takes as long as gather + MLP back to back (both are bound by the gather's L2 request rate), so the
-        # second hashing is a net loss of 0.07 ms per step; the fused launch serves the callers that keep nothing (occupancy
-        # grid update, eval), where it saves the 128 B per position of the feature array.
-        # (Gradient-free rendering reuses them as well -- an eval image keeps nearly every marched candidate; 21.1 -> 20.9 ms per 256x256
-        # image, the heads kernel is what its time is made of.)
+        # The training forward gathers the survivors' hash features out of the encoding the sampler's density query produced for every
+        # marched candidate (UMHS_REUSE_ENC=0: hashes them again; 0.07 ms per step slower at 3.5 M candidates / 0.9 M survivors).
+        # Gradient-free rendering reuses them as well -- an eval image keeps nearly every marched candidate (21.1 -> 20.9 ms per 256x256
+        # image, the heads kernel is what its time is made of).
         reuse = isinstance(self.sampler, VolumetricSampler) and os.environ.get("UMHS_REUSE_ENC", "1") != "0" and (
             self.training or (not torch.is_grad_enabled() and os.environ.get("UMHS_RENDER_PER_RAY", "1") != "0"))
         self.field._enc_capture = {} if reuse else None
@@ -327,6 +332,8 @@ class UMHSModel(ModelBase):
         if (not torch.is_grad_enabled() and c.method != "rgb" and fr.origins.numel() > 0
                 and os.environ.get("UMHS_RENDER_PER_RAY", "1") != "0" and ops.field_heads_fwd_supported(self.field._spec())):
             return self._render_outputs_from_samples(ray_samples, ray_indices, num_rays, packed_info)
+        if c.method == "rgb":
+            return self._rgb_outputs_from_samples(ray_samples, packed_info)
         fo = self.field(ray_samples)
         values = [fo["spectral"]]
         if c.pred_specular:
@@ -341,6 +348,24 @@ class UMHSModel(ModelBase):
             spec_for_rgb, self.converter.transform_matrix, self.field.endmembers.detach(), accumulation, depth, mm,
             self.class_colors, 0.2)
         return self._assemble_outputs(accumulation, depth_c, comp, rgb, packed_info, seg_probs, seg_raw, seg_pred, weights)
+
+    def _rgb_outputs_from_samples(self, ray_samples: RaySamples, packed_info: Tensor) -> Dict[str, Tensor]:
+        """``method="rgb"`` (umhs_model.py:265-267): the field's colour composited per ray -> rgb, accumulation, depth.
+        Deliberate deviation: the reference calls ``renderer_rgb(rgb=, weights=)`` WITHOUT ``ray_indices`` / ``num_rays`` on packed
+        samples, which makes nerfstudio's RGBRenderer sum over ALL samples of the batch (one colour for every ray); this composites
+        per ray, as the reference does for every other output.  Background: "random" leaves the colour unblended here (it is blended
+        in the loss, ``blend_background_for_loss_computation``), "white" / "black" add ``bg (1 - accumulation)``, as RGBRenderer does."""
+        c, fr = self.config, ray_samples.frustums
+        fo = self.field(ray_samples)
+        weights, accumulation, depth, rgb = ops.CompositeFn.apply(fo[FieldHeadNames.DENSITY], fr.starts, fr.ends, packed_info,
+                                                                  bool(c.use_gradient_scaling), fo[FieldHeadNames.RGB])
+        if self.background_color in ("white", "black"):
+            rgb = rgb + (1.0 if self.background_color == "white" else 0.0) * (1.0 - accumulation)
+        if not self.training:
+            rgb = rgb.clamp(0.0, 1.0)
+        tmid = (fr.starts + fr.ends) / 2  # DepthRenderer: expected depth (the compositing kernel's), clipped to the batch-wide [min, max] of t_mid
+        depth_c = torch.minimum(torch.maximum(depth, tmid.min()), tmid.max()) if tmid.numel() else depth
+        return {"accumulation": accumulation, "depth": depth_c, "rgb": rgb, "num_samples_per_ray": packed_info[:, 1], "weights": weights}
 
     def _render_outputs_from_samples(self, ray_samples, ray_indices, num_rays: int, packed_info) -> Dict[str, Tensor]:
         """The same outputs without gradients (eval images, ``ns-render``): mlp_base -> transmittance weights -> heads with the per-ray
@@ -536,10 +561,11 @@ class UMHSModel(ModelBase):
         return t
 
     # ---- losses / metrics ----------------------------------------------------------------------------
-    def blend_background_for_loss_computation(self, pred_image, pred_accumulation, gt_image):
-        """nerfstudio RGBRenderer.blend_background_for_loss_computation as called at umhs_model.py:358-362."""
+    def blend_background_for_loss_computation(self, pred_image, pred_accumulation, gt_image, background: Optional[Tensor] = None):
+        """nerfstudio RGBRenderer.blend_background_for_loss_computation as called at umhs_model.py:358-362 (``background``: a fixed
+        draw of the random background instead of a fresh one -- parity tests)."""
         if self.background_color == "random":
-            bg = torch.rand_like(pred_image)
+            bg = background if background is not None else torch.rand_like(pred_image)
             pred_image = pred_image + bg * (1.0 - pred_accumulation)
         if gt_image.shape[-1] == 4:
             bgc = bg if self.background_color == "random" else torch.full_like(pred_image, 1.0 if self.background_color == "white" else 0.0)
@@ -561,7 +587,7 @@ class UMHSModel(ModelBase):
                 loss_dict["spectral_loss"], loss_dict["rgb_loss"] = ops.LossFn.apply(
                     outputs["spectral"], hs, outputs["rgb"], outputs["accumulation"], bg, image, 5.0, float(self.config.rgb_loss_weight))
             return loss_dict
-        pred_rgb, gt_rgb = self.blend_background_for_loss_computation(outputs["rgb"], outputs["accumulation"], image)
+        pred_rgb, gt_rgb = self.blend_background_for_loss_computation(outputs["rgb"], outputs["accumulation"], image, background)
         if m == "rgb":
             loss_dict["rgb_loss"] = torch.nn.functional.mse_loss(pred_rgb, gt_rgb)
         elif m == "spectral":
