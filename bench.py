@@ -204,7 +204,7 @@ def sampler_step(cfg, device, steps=40, warm=300):
     ms = (time.perf_counter() - t0) / steps * 1e3
     # per-operator pass (an event pair around every operator: untimed, like the main line's breakdown)
     t_ops, t_smp = KernelTimer(ops), KernelTimer(smp)
-    for name in ("positions_fwd", "hashgrid_fwd", "field_fwd", "field_density", "enc_gather", "composite_fwd", "ray_train_tail", "composite_bwd",
+    for name in ("positions_fwd", "hashgrid_fwd", "field_fwd", "enc_gather", "composite_fwd", "ray_train_tail", "composite_bwd",
                  "field_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "adam_step_rows_range", "adam_step", "pixel_indices", "pixel_gather",
                  "raygen"):
         t_ops.wrap(name)
@@ -239,7 +239,7 @@ def sampler_step(cfg, device, steps=40, warm=300):
         # march: 16 B parked + 16 B read back + 16 B packed per candidate (t0, t1, ray index); a latency chain per ray, not a stream
         roof("march (walk + compaction)", ("march_begin", "march_finish"), n_cand * 48)
         # density query of every candidate: 1024 B of table rows + 128 B of features + 12 B position + 4 B sigma
-        roof("density query of the candidates", ("sample_midpoints", "positions_fwd", "hashgrid_fwd", "field_fwd", "field_density"), n_cand * (1024 + 128 + 12 + 4))
+        roof("density query of the candidates", ("sample_midpoints", "positions_fwd", "hashgrid_fwd", "field_fwd"), n_cand * (1024 + 128 + 12 + 4))
         roof("visibility + compaction", ("visibility_mask", "compact_samples", "enc_gather"), n_cand * 13 + n_surv * (48 + 128))
     return dict(ms=round(ms, 4), rays_per_s=round(R / ms * 1e3, 1), rays=R, survivors_per_step=round(n_surv, 1), candidates_per_step=n_cand,
                 kernels_ms=dict(sorted(per_step.items(), key=lambda kv: -kv[1])), rooflines=roofs,
@@ -398,7 +398,9 @@ def main():
         fused_adam_bytes = 28 * (16 - int(getattr(sink, "sparse_levels", 0) or 0)) * (1 << 19) * 2 if world == 1 else 0
         alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12),
                      "hashgrid_bwd_apply": N * (1024 + 128 + 12) + fused_adam_bytes,
-                     "composite_fwd": N * (nstream + 4) * 4, "composite_bwd": N * (2 * B + 5) * 4,
+                     # (above 32 bands the compositing pass carries no value stream -- the band sums are formed inside the heads kernel and
+                     # the value half of its backward inside field_bwd, DESIGN 4.3: sigma, t0, t1 in, weights out + two floats per ray)
+                     "composite_fwd": (N * 16 + R * 8) if "field_heads_fwd" in ksum else N * (nstream + 4) * 4, "composite_bwd": N * (2 * B + 5) * 4,
                      "adam_step": pipe.model.field.flat.numel() * 28}
         # (wide-band models run the forward as mlp_base + heads with the per-ray band sums inside the heads kernel, and the backward
         # with the compositing backward's value half inside field_bwd: ops.field_base_fwd / field_heads_fwd; field_bwd then includes it)
