@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Field backward alone (all kernels of umhs_field_bwd) at the bench shapes; UMHS_BWD_TF=0/1 selects the kernel family.  GPU box."""
+"""Field backward alone (all kernels of umhs_field_bwd) at the bench shapes; UMHS_BWD_TF=1 selects the fp32-chain kernels.  GPU box."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd"), os.path.join(ROOT, "tools")]
