@@ -1090,6 +1090,30 @@ struct TfSlots {
 };
 constexpr int TF_CHUNK = 32;  // items per round of the end-of-launch reduction over the 4 waves (4 x 32 x 1 KiB = 128 KiB of LDS)
 
+// A lane's four bands of every band tile out of one row of d_comp / d_spectral: ``rowp`` = the row + 4q.  One 16-byte request per band
+// tile with an immediate offset (rows are only 4-byte aligned when B is not a multiple of 4: dword-aligned dwordx4 is a legal global
+// access) instead of four 4-byte loads with a 64-bit address each: at 128 bands the 32 scalar loads and their ~300 address
+// instructions were 3.1 k cycles at the top of every 20 k-cycle tile (stamps, round 3).  Quads that straddle the end of the row (the
+// last band tile when B % 4 != 0) and lanes without a sample keep the element-wise, predicated form.
+struct __attribute__((packed, aligned(4))) F4u {
+  float v[4];
+};
+template <int TBMAX>
+__device__ __forceinline__ void band_row_load(float (&dall)[TBMAX][4], const float* __restrict__ rowp, bool live, int q, int TB, int B) {
+#pragma unroll
+  for (int t = 0; t < TBMAX; ++t) {
+    const int b0 = 16 * t + 4 * q;
+    if (live && t < TB && b0 + 3 < B) {
+      const F4u v = *reinterpret_cast<const F4u*>(rowp + 16 * t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dall[t][r] = v.v[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dall[t][r] = (live && t < TB && b0 + r < B) ? rowp[16 * t + r] : 0.0f;
+    }
+  }
+}
+
 // In-kernel phase stamps of the transpose-free backward (tools/stamp_fbwd.py builds this file with -DUMHS_TF_STAMP into its own
 // library): s_memtime at the phase boundaries of every tile, pinned by scheduling barriers, summed per phase by wave 0 of workgroup 0.
 #ifdef UMHS_TF_STAMP
@@ -1278,16 +1302,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tf_kernel(FieldIO io, PackDe
       // This tile's upstream gradients, all band tiles: requested here, consumed after the head MLP's forward recompute (with one
       // wave per SIMD a load issued next to its use costs its whole latency: one band tile ahead was 585 us at 128 bands)
       float dall[TBMAX][4];  // FUSED: the ray's d_comp row (unscaled; [R,B] stays in L2), else this sample's d_spectral row
-#pragma unroll
-      for (int t = 0; t < TBMAX; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = 16 * t + 4 * q + r;
-          if (FUSED)
-            dall[t][r] = (SPEC && t < TB && ok && b < B) ? io.d_comp[cur.ray * B + b] : 0.0f;  // only the specular tail needs the row
-          else
-            dall[t][r] = (t < TB && ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
-        }
+      band_row_load<TBMAX>(dall, FUSED ? io.d_comp + cur.ray * B + 4 * q : io.d_spectral + n * B + 4 * q,
+                           FUSED ? (SPEC && ok) : ok, q, TB, B);  // (FUSED: only the specular tail needs the row)
       // FUSED: G[ray][4q .. 4q+3], requested here with the ray index the previous tile's prefetch brought (a load that depends on
       // another load inside the prefetch stalls the wave for a whole memory latency per tile: +14 us at C2) and consumed after the band loop
       v4f g4 = {0.0f, 0.0f, 0.0f, 0.0f};

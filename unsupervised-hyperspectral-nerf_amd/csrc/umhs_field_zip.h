@@ -686,16 +686,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_tfz0_kernel(FieldIO io, Pack
       // This tile's upstream gradients, all band tiles: requested here, consumed after the head MLP's forward recompute (with one
       // wave per SIMD a load issued next to its use costs its whole latency: one band tile ahead was 585 us at 128 bands)
       float dall[TBMAX][4];  // FUSED: the ray's d_comp row (unscaled; [R,B] stays in L2), else this sample's d_spectral row
-#pragma unroll
-      for (int t = 0; t < TBMAX; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = 16 * t + 4 * q + r;
-          if (FUSED)
-            dall[t][r] = (SPEC && t < TB && ok && b < B) ? io.d_comp[cur.ray * B + b] : 0.0f;  // only the specular tail needs the row
-          else
-            dall[t][r] = (t < TB && ok && b < B) ? io.d_spectral[n * B + b] : 0.0f;
-        }
+      band_row_load<TBMAX>(dall, FUSED ? io.d_comp + cur.ray * B + 4 * q : io.d_spectral + n * B + 4 * q,
+                           FUSED ? (SPEC && ok) : ok, q, TB, B);  // (FUSED: only the specular tail needs the row)
       // FUSED: G[ray][4q .. 4q+3], requested here with the ray index the previous tile's prefetch brought (a load that depends on
       // another load inside the prefetch stalls the wave for a whole memory latency per tile: +14 us at C2) and consumed after the band loop
       v4f gmix = {0.0f, 0.0f, 0.0f, 0.0f};
