@@ -19,3 +19,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def built_library():
+    """The in-tree HIP library and its objects, (re)built when a source is newer (hipcc cross-compiles for gfx950 without a GPU;
+    a no-op after ``__graft_entry__.build()``)."""
+    from umhsnerf import build
+
+    return build.build_lib(verbose=False)

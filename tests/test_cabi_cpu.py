@@ -16,7 +16,7 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b(umhs_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol():
+def test_library_exports_every_declared_symbol(built_library):
     from umhsnerf import _hip
 
     assert os.path.exists(_hip.LIB_PATH), "run __graft_entry__.build() first"

@@ -24,7 +24,7 @@ def test_zip_plans_close(tmp_path):
         assert 0 < carried < slots // 4, h
 
 
-def test_no_inline_asm_mfma_reads_a_freshly_written_vgpr():
+def test_no_inline_asm_mfma_reads_a_freshly_written_vgpr(built_library):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_hazards
 
