@@ -88,6 +88,7 @@ FULL = [
     ("C2 at its own size", 4096, 64, 31, 6, True, 0.4, None),
     ("C3 at 1024 rays", 1024, 64, 128, 9, True, 0.3, None),
     ("C5 at 1024 rays", 1024, 64, 141, 4, False, 0.7, "endmembers_hotdog"),
+    ("C4 per-GPU shard at its own size", 8192, 64, 31, 6, True, 0.4, None),  # pinecone-shaped: 65536 rays over 8 GPUs = 8192 rays per rank
 ]
 
 
