@@ -5,7 +5,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd")]
 import torch
 from umhsnerf import ops
 dev = "cuda:0"
-R, B, C, S = 4096, 31, 6, 64
+R, B, C, S = (int(x) for x in os.environ.get("SHAPE", "4096,31,6,64").split(","))  # SHAPE=8192,128,9,64: C3
 N = R * S
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s: torch.rand(*s, generator=g).to(dev)
