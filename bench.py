@@ -15,6 +15,7 @@ launch stream; `cpu_baseline` is the oracle (CPU restatement of the reference's 
 box's host cores on a bounded sample of the same workload.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -121,7 +122,13 @@ class KernelTimer:
         setattr(self.ops, name, timed)
 
     def summary(self):
-        return {k: (float(np.mean([a.elapsed_time(b) for a, b in v])), len(v)) for k, v in self.records.items()}
+        """{operator: (median ms, launches, mean ms, max ms)} -- the MEDIAN is what every table quotes: one host-side stall between an
+        event pair (BENCH_r03: 131 ms inside a 0.02 ms operator) must not poison a row; the max shows that it happened."""
+        out = {}
+        for k, v in self.records.items():
+            t = [a.elapsed_time(b) for a, b in v]
+            out[k] = (float(np.median(t)), len(t), float(np.mean(t)), float(np.max(t)))
+        return out
 
 
 def cpu_baseline(cfg, seed, budget_s=15.0):
@@ -165,15 +172,9 @@ def cpu_baseline(cfg, seed, budget_s=15.0):
                 sample=f"oracle/torch_ref.py fp32 train step (fwd+loss+bwd+Adam), {R} of {cfg['R']} rays x {cfg['S']} samples, {n} steps, {dt:.2f} s/step")
 
 
-def sampler_step(cfg, device, steps=40, warm=300):
-    """The iteration `ns-train umhsnerf` runs (reference umhs_model.py:229-237,549-554): occupancy-grid update, pixel batch + ray
-    generation, the march through the grid, the density query of every candidate + visibility pruning, then the hot path on the
-    survivors, backward, Adam -- `UMHSPipeline.get_train_loss_dict` on a resident synthetic scene (6 cameras of 64 x 64 pixels on a
-    sphere around a constant-spectrum target, 4096 rays per batch, 4-level 128^3 grid; the scene of tools/profile_sampler_step.py).
-    Not the headline metric (its sample count is the scene's, not BASELINE's): reported beside it so that the share of the marcher and
-    the candidate query is on the driver's line.  -> dict(ms, rays_per_s, samples, candidates, kernels_ms, rooflines)."""
-    from umhsnerf import ops
-    from umhsnerf import sampler as smp
+def sampler_scene(cfg, device, warm=300):
+    """The resident synthetic scene of `sampler_step` / `eval_image`: 6 cameras of 64 x 64 pixels on a sphere around a constant-spectrum
+    target, 4096 rays per batch, 4-level 128^3 occupancy grid, `warm` training steps so that the grid has settled on the target."""
     from umhsnerf.data.umhs_datamanager import ResidentSplit, UMHSDataManager, UMHSDataManagerConfig
     from umhsnerf.data.umhs_dataparser import Cameras
     from umhsnerf.umhs_model import UMHSConfig
@@ -196,6 +197,96 @@ def sampler_step(cfg, device, steps=40, warm=300):
         split.image = pipe.model.converter(split.hs_image.view(-1, B)).view(n, H, W, 3).contiguous()
     for step in range(warm):  # the grid settles on the target (update every 16 steps) and the model starts to fit it
         pipe.get_train_loss_dict(step)
+    torch.cuda.synchronize()
+    return pipe, c2w
+
+
+def eval_image(cfg, device, pipe, c2w, H=256, reps=5):
+    """Gradient-free rendering of one H x H camera of the sampler scene through `get_outputs_for_camera_ray_bundle` (reference
+    umhs_model.py:593-620): march + density query of every candidate + pruning + the per-ray heads path, whole image in
+    chunks of 32,768 rays.  Roofline: SURVEY 8d's forward-only figure, 32 + 1024 B per hashed sample (= candidate: survivors reuse the
+    query's features) + (B + C + 5) x 4 B per ray, against HBM."""
+    from umhsnerf import ops
+    from umhsnerf import sampler as smp
+    from umhsnerf.data.umhs_datamanager import ResidentSplit
+    from umhsnerf.data.umhs_dataparser import Cameras
+
+    B, Cn = cfg["B"], cfg["C"]
+    f = 30.0 * H / 64.0  # the training cameras' field of view
+    cams = Cameras(c2w[:1].clone(), torch.full((1,), f), torch.full((1,), f), torch.full((1,), H / 2), torch.full((1,), H / 2), H, H)
+    split = ResidentSplit(cams, torch.zeros(1, H, H, 3), None, device)
+    rb = split.image_rays(0)
+    m = pipe.model.eval()
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                out = m.get_outputs_for_camera_ray_bundle(rb)
+            torch.cuda.synchronize()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            t0 = time.perf_counter()
+            e[0].record()
+            for i in range(reps):
+                out = m.get_outputs_for_camera_ray_bundle(rb)
+                e[i + 1].record()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            cand, finish = 0, smp.march_finish
+
+            def counting_finish(h):  # candidates of the image = the samples every chunk's march hands to the density query
+                nonlocal cand
+                r = finish(h)
+                cand += int(r[1].numel())
+                return r
+
+            smp.march_finish = counting_finish
+            try:
+                m.get_outputs_for_camera_ray_bundle(rb)
+            finally:
+                smp.march_finish = finish
+            ms_med = float(np.median([e[i].elapsed_time(e[i + 1]) for i in range(reps)]))
+            t_ops, t_smp = KernelTimer(ops), KernelTimer(smp)
+            for name in ("positions_fwd", "hashgrid_fwd", "field_fwd", "field_base_fwd", "field_heads_fwd", "enc_gather", "composite_fwd",
+                         "ray_epilogue_fwd", "tmid_minmax", "field_fwd_prepare"):
+                t_ops.wrap(name)
+            for name in ("march_begin", "march_finish", "visibility_mask", "compact_samples", "sample_midpoints"):
+                t_smp.wrap(name)
+            t_ops.enabled = t_smp.enabled = True
+            m.get_outputs_for_camera_ray_bundle(rb)
+            torch.cuda.synchronize()
+            t_ops.enabled = t_smp.enabled = False
+            ks = {**t_ops.summary(), **t_smp.summary()}
+            for tm in (t_ops, t_smp):
+                for name, fn in tm.orig.items():
+                    setattr(tm.ops, name, fn)
+    finally:
+        m.train()
+    R = H * H
+    surv = float(out["num_samples_per_ray"].float().sum())
+    n_hashed = cand if cand else surv
+    nbytes = n_hashed * (32 + 1024) + R * (B + Cn + 5) * 4
+    ach = nbytes / (ms_med * 1e-3) / 1e9
+    per_image = {k: round(v[0] * v[1], 4) for k, v in ks.items()}  # ms per image (an operator runs once per chunk, or twice: query + render)
+    return dict(rays=R, image=f"{H}x{H}", ms=round(ms_med, 4), ms_wall=round(dt * 1e3, 4), rays_per_s=round(R / (ms_med * 1e-3), 1),
+                samples_per_ray=round(surv / R, 1), candidates_per_ray=round(cand / R, 1) if cand else None, chunks=-(-R // 32768),
+                roofline=dict(kernel="eval image (march + candidate density query + heads per ray)", bound="hbm", achieved=round(ach, 1),
+                              peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), algorithmic_bytes=int(nbytes),
+                              note="32 + 1024 B per hashed sample + (B + C + 5) x 4 B per ray (SURVEY 8d, inference)"),
+                kernels_ms=dict(sorted(per_image.items(), key=lambda kv: -kv[1])),
+                note="get_outputs_for_camera_ray_bundle on a camera of the sampler scene after its training steps; ms = median of "
+                     f"{reps} images between HIP events, kernels_ms from one more image with an event pair around every operator")
+
+
+def sampler_step(cfg, device, pipe, steps=40, warm=300):
+    """The iteration `ns-train umhsnerf` runs (reference umhs_model.py:229-237,549-554): occupancy-grid update, pixel batch + ray
+    generation, the march through the grid, the density query of every candidate + visibility pruning, then the hot path on the
+    survivors, backward, Adam -- `UMHSPipeline.get_train_loss_dict` on a resident synthetic scene (6 cameras of 64 x 64 pixels on a
+    sphere around a constant-spectrum target, 4096 rays per batch, 4-level 128^3 grid; the scene of tools/profile_sampler_step.py).
+    Not the headline metric (its sample count is the scene's, not BASELINE's): reported beside it so that the share of the marcher and
+    the candidate query is on the driver's line.  -> dict(ms, rays_per_s, samples, candidates, kernels_ms, rooflines)."""
+    from umhsnerf import ops
+    from umhsnerf import sampler as smp
+
+    R = 4096
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for step in range(warm, warm + steps):
@@ -249,6 +340,197 @@ def sampler_step(cfg, device, steps=40, warm=300):
                      "for the candidates' density query AND for the survivors' forward)")
 
 
+OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "field_base_fwd", "field_heads_fwd", "accumulate_fwd", "composite_fwd", "tmid_minmax",
+       "ray_train_tail", "composite_bwd", "field_bwd",
+       "hashgrid_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "field_fwd_prepare", "field_bwd_prepare", "adam_step",
+       "adam_step_rows", "adam_step_rows_range")  # (one GPU: the dense hash levels' Adam step rides in hashgrid_bwd_apply)
+
+
+class Case:
+    """One BASELINE configuration on this rank: the plugin-surface pipeline, its resident synthetic batch and the step closure."""
+
+    def __init__(self, name, device, world, local, rank):
+        from umhsnerf import ops
+        from umhsnerf._ns_compat import packed_ray_samples
+        from umhsnerf.umhs_model import UMHSConfig
+        from umhsnerf.umhs_pipeline import UMHSPipeline
+
+        self.name, self.cfg = name, CONFIGS[name]
+        cfg = self.cfg
+        self.R, self.S, self.B, self.Cn = cfg["R"], cfg["S"], cfg["B"], cfg["C"]
+        self.N = self.R * self.S
+        bands = list(np.linspace(400, 700, self.B))
+        mc = UMHSConfig(method=cfg["method"], pred_specular=cfg["pred_specular"], temperature=cfg["temperature"], per_band_outputs=True)
+        self.pipe = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": bands, "num_classes": self.Cn}, world_size=world,
+                                                     local_rank=local, seed=42)
+        trained_like_init(self.pipe.model.field, seed=42)
+        if world > 1:
+            dist.broadcast(self.pipe.model.field.flat.data, src=0)
+        self.b = synthetic_batch(self.R, self.S, self.B, seed=42 + rank, device=device)  # every rank draws its own rays (weak scaling)
+        self.rs = packed_ray_samples(self.b["origins"], self.b["directions"], self.b["starts"], self.b["ends"])
+        self.pinfo = ops.pack_info(self.b["ray_indices"], self.R)
+        with torch.no_grad():
+            gt_rgb = self.pipe.model.converter(self.b["gt_spectral"])
+        self.batch = {"image": gt_rgb, "hs_image": self.b["gt_spectral"]}
+
+    def step(self):
+        return self.pipe.train_iteration(self.rs, self.b["ray_indices"], self.R, self.batch, packed_info=self.pinfo)
+
+
+def measure(case, timer, steps, warmup, world, device):
+    """warm-up -> pick the dominant operator from three fully timed (still warm-up) steps -> the timed region: EXACTLY `steps` steps
+    between a barrier + device sync on both sides, one HIP event per step boundary (median) and an event pair around the dominant
+    operator only -> (wall seconds [max over ranks], median ms, the dominant operator's live summary, last outputs, last losses)."""
+    for _ in range(warmup):
+        case.step()
+    # Which operator is the dominant one is measured, not assumed: three steps with every operator timed (still warm-up), and the
+    # largest carries the events of the timed region.  field_bwd and hashgrid_bwd_apply are within a few percent of each other at
+    # C2 -- a ranking taken AFTER the timed region (from the untimed pass) would quote an operator that was not timed live.
+    timer.records.clear()
+    timer.only, timer.enabled = None, True
+    for _ in range(3):
+        case.step()
+    torch.cuda.synchronize()
+    timer.enabled = False
+    pre = timer.summary()
+    pick = torch.tensor([float(pre.get(k, (0.0, 0))[0]) for k in ROOFLINE_OPS], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(pick, op=dist.ReduceOp.MAX)  # every rank times the same operator
+    timer.only = {ROOFLINE_OPS[int(torch.argmax(pick).item())]}
+    timer.records.clear()
+    timer.enabled = True
+    # Host hygiene of the timed region: a generation-2 pass of Python's cycle collector takes ~0.1 s in this process (torch + numpy +
+    # the oracle's modules are tens of thousands of tracked objects); BENCH_r03's breakdown pass caught one between an event pair
+    # (DESIGN 5).  Collect now and freeze the survivors, so the passes below only ever see young-generation collections.
+    gc.collect()
+    gc.freeze()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    outputs = loss_dict = None
+    for i in range(steps):
+        outputs, loss_dict = case.step()
+        marks[i + 1].record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]  # GPU-side step boundaries on the launch stream
+    tmax = torch.tensor([dt, float(np.median(per_step_ms))], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dom_live = timer.summary()
+    timer.records.clear()
+    return float(tmax[0].item()), float(tmax[1].item()), dom_live, outputs, loss_dict
+
+
+def breakdown(case, timer, steps):
+    """Untimed pass with an event pair around every operator -> {operator: (median ms, launches, mean, max)}."""
+    timer.records.clear()
+    timer.only, timer.enabled = None, True
+    for _ in range(steps):
+        case.step()
+    torch.cuda.synchronize()
+    timer.enabled = False
+    out = timer.summary()
+    timer.records.clear()
+    return out
+
+
+def roofline_tables(case, ksum, dom, world, config_name):
+    """Per-operator rooflines from the measured operator times: algorithmic work per launch -- hash gather / scatter 1024 B
+    per sample + the level-major feature rows (128 B) and positions (12 B); field MLPs 2 x MAC per sample (forward), backward = dX +
+    dW = 2 x forward; compositing and the optimizer by the bytes they must move once."""
+    cfg, pipe, N, R, B, Cn = case.cfg, case.pipe, case.N, case.R, case.B, case.Cn
+    kern = {k: round(v[0], 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][0])}
+    spec = cfg["pred_specular"]
+    mac = 3072 + 2 * (1728 + 4096) + 64 * Cn + 64 * (Cn + (1 if spec else 0)) + ((448 + 16 * B) if spec else 0) + Cn * B + 256
+    nstream = (3 * B if spec else B) + Cn
+    # (one GPU: the Adam step of the dense hash levels rides in the bucket reduce of hashgrid_bwd_apply -- 28 B per parameter of
+    # levels 5..15, the same bytes the separate adam_step would move -- so that operator's algorithmic bytes include them)
+    sink = getattr(pipe.model.field, "_grad_sink", None)
+    fused_adam_bytes = 28 * (16 - int(getattr(sink, "sparse_levels", 0) or 0)) * (1 << 19) * 2 if world == 1 else 0
+    alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12),
+                 "hashgrid_bwd_apply": N * (1024 + 128 + 12) + fused_adam_bytes,
+                 # (above 32 bands the compositing pass carries no value stream -- the band sums are formed inside the heads kernel and
+                 # the value half of its backward inside field_bwd, DESIGN 4.3: sigma, t0, t1 in, weights out + two floats per ray)
+                 "composite_fwd": (N * 16 + R * 8) if "field_heads_fwd" in ksum else N * (nstream + 4) * 4, "composite_bwd": N * (2 * B + 5) * 4,
+                 "adam_step": pipe.model.field.flat.numel() * 28}
+    # (wide-band models run the forward as mlp_base + heads with the per-ray band sums inside the heads kernel, and the backward
+    # with the compositing backward's value half inside field_bwd: ops.field_base_fwd / field_heads_fwd; field_bwd then includes it)
+    alg_flops = {"field_fwd": 2.0 * mac * N, "field_bwd": 4.0 * mac * N, "field_base_fwd": 2.0 * 3072 * N,
+                 "field_heads_fwd": 2.0 * (mac - 3072) * N}
+    # HBM traffic / MFMA-busy from the committed rocprofv3 --pmc passes of this same command -- only when they were taken on
+    # THIS build of the kernels (the summary records the source hash); counters cannot be read from inside the process
+    pmc, pmc_src = {}, None
+    for rel in (f"profiles/r04/pmc_summary_{config_name}.json", f"profiles/r03/pmc_summary_{config_name}.json"):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                js = json.load(f)
+            if js.get("csrc_sha") == csrc_hash() and js.get("config", "C2") == config_name:
+                pmc, pmc_src = js["kernels"], rel
+                break
+        except Exception:
+            pass
+    op_kernels = {"field_bwd": ("field_bwd_tf_kernel", "field_bwd_tfz0_kernel", "field_bwd_tfz1_kernel", "field_slab_fold", "field_reduce_tf", "field_mix_"),
+                  "field_fwd": ("field_fwd_kernel", "field_pack_all"), "field_base_fwd": ("field_fwd_kernel<false, true",),
+                  "field_heads_fwd": ("field_fwd_kernel", "field_heads_finish"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
+                  "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel", "hg_pairs_kernel", "hg_level_absmax"),
+                  "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel", "hg_pairs_kernel<true>", "hg_level_absmax"),
+                  "adam_step": ("adam_kernel",),
+                  "composite_fwd": ("composite_fwd_kernel",), "composite_bwd": ("composite_bwd_kernel",)}
+
+    def roof_of(op):
+        ms, launches = ksum[op][0], ksum[op][1]
+        extra = {"avg_ms": round(ms, 4), "launches": launches}
+        if len(ksum[op]) > 3:
+            extra.update(mean_ms=round(ksum[op][2], 4), max_ms=round(ksum[op][3], 4))
+        traffic = sum(v["hbm_traffic_bytes"] for k, v in pmc.items() if "hbm_traffic_bytes" in v and any(k.startswith(p_) for p_ in op_kernels.get(op, ()))) or None
+        if op in alg_bytes:
+            ach = alg_bytes[op] / (ms * 1e-3) / 1e9
+            return dict(kernel=op, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                        traffic=traffic, **extra)
+        if op in alg_flops:
+            ach = alg_flops[op] / (ms * 1e-3) / 1e12
+            # MFMA-busy share of the operator = of all its kernels (the reductions included), weighted by their cycles
+            mk = [v for k, v in pmc.items() if v.get("kernel_cycles_per_xcd") and any(k.startswith(p_) for p_ in op_kernels[op])]
+            busy = round(sum(v.get("mfma_util", 0.0) * v["kernel_cycles_per_xcd"] for v in mk) / sum(v["kernel_cycles_per_xcd"] for v in mk), 4) if mk else None
+            return dict(kernel=op, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4),
+                        traffic=traffic, mfma_busy_frac_pmc=busy, **extra)
+        return None
+
+    rooflines = [r for r in (roof_of(op) for op in kern) if r is not None]
+    roof = next((r for r in rooflines if r["kernel"] == dom), rooflines[0] if rooflines else None)
+    if roof is not None:
+        roof = dict(roof, pmc_source=pmc_src,
+                    note="dominant operator, timed with HIP events inside the timed region (avg_ms = median of those launches); achieved = "
+                         "algorithmic bytes or FLOPs (SURVEY 8d) / time; traffic / mfma_busy_frac_pmc only when profiles/*/pmc_summary.json was "
+                         "taken on this build")
+    return kern, roof, rooflines
+
+
+def other_config(name, device, timer, steps=20, warmup=10):
+    """The other single-GPU BASELINE shapes through the same measurement, on the driver's line: C3 = configs[2]
+    (scripts/cbox_dragon.sh:3-9, 128 bands, 8192 rays, 1 GPU), C4 = one GPU's 8192-ray shard of configs[3], C5 = configs[4]'s shard."""
+    case = Case(name, device, 1, 0, 0)
+    dt, median_ms, dom_live, outputs, loss_dict = measure(case, timer, steps, warmup, 1, device)
+    ksum = breakdown(case, timer, 5)
+    ksum.update(dom_live)
+    dom = next(iter(dom_live)) if dom_live else None
+    kern, roof, _ = roofline_tables(case, ksum, dom, 1, name)
+    out = dict(workload=case.cfg["workload"], rays=case.R, samples_per_ray=case.S, bands=case.B, endmembers=case.Cn,
+               ms_per_step=round(dt / steps * 1e3, 4), ms_per_step_median=round(median_ms, 4), rays_per_s=round(case.R * steps / dt, 1),
+               steps=steps, warmup=warmup, roofline=roof, kernels_ms=kern,
+               spectral_psnr_db_vs_uniform_random_gt=round(float(case.pipe.model.psnr(outputs["spectral"].detach(), case.b["gt_spectral"])), 3))
+    del case
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +539,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler-step", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-eval-image", action="store_true")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -277,176 +561,63 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from umhsnerf import ops, parallel
-    from umhsnerf._ns_compat import packed_ray_samples
-    from umhsnerf.umhs_model import UMHSConfig
-    from umhsnerf.umhs_pipeline import UMHSPipeline
 
-    cfg = CONFIGS[args.config]
-    R, S, B, Cn = cfg["R"], cfg["S"], cfg["B"], cfg["C"]
-    N = R * S
-    bands = list(np.linspace(400, 700, B))
-    mc = UMHSConfig(method=cfg["method"], pred_specular=cfg["pred_specular"], temperature=cfg["temperature"], per_band_outputs=True)
-    pipe = UMHSPipeline.from_packed_samples(mc, device, metadata={"wavelengths": bands, "num_classes": Cn}, world_size=world, local_rank=local, seed=42)
-    trained_like_init(pipe.model.field, seed=42)
-    if world > 1:
-        dist.broadcast(pipe.model.field.flat.data, src=0)
-    b = synthetic_batch(R, S, B, seed=42 + rank, device=device)  # every rank draws its own rays (weak scaling)
-    rs = packed_ray_samples(b["origins"], b["directions"], b["starts"], b["ends"])
-    pinfo = ops.pack_info(b["ray_indices"], R)
-    with torch.no_grad():
-        gt_rgb = pipe.model.converter(b["gt_spectral"])
-    batch = {"image": gt_rgb, "hs_image": b["gt_spectral"]}
+    case = Case(args.config, device, world, local, rank)
+    cfg, pipe, b = case.cfg, case.pipe, case.b
+    R, S, B, Cn = case.R, case.S, case.B, case.Cn
 
     timer = KernelTimer(ops)
-    OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "field_base_fwd", "field_heads_fwd", "accumulate_fwd", "composite_fwd", "tmid_minmax",
-           "ray_train_tail", "composite_bwd", "field_bwd",
-           "hashgrid_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "field_fwd_prepare", "field_bwd_prepare", "adam_step",
-           "adam_step_rows", "adam_step_rows_range")  # (one GPU: the dense hash levels' Adam step rides in hashgrid_bwd_apply)
     for name in OPS:
         timer.wrap(name)
     # Inside the timed region only the dominant operator carries HIP events (2 per step) plus one event per step boundary (for the
     # median): an event is a barrier packet on the queue, and a pair around every one of the ~12 operators costs ~12 % of the
     # step.  The full per-operator table comes from a separate, untimed pass over the same step.
-    def step():
-        return pipe.train_iteration(rs, b["ray_indices"], R, batch, packed_info=pinfo)
-
-    for _ in range(args.warmup):
-        step()
-    # Which operator is the dominant one is measured, not assumed: three steps with every operator timed (still warm-up), and the
-    # largest carries the events of the timed region.  field_bwd and hashgrid_bwd_apply are within a few percent of each other at
-    # C2 -- a ranking taken AFTER the timed region (from the untimed pass) would quote an operator that was not timed live.
-    timer.only, timer.enabled = None, True
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    timer.enabled = False
-    pre = timer.summary()
-    pick = torch.tensor([float(pre.get(k, (0.0, 0))[0]) for k in ROOFLINE_OPS], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(pick, op=dist.ReduceOp.MAX)  # every rank times the same operator
-    timer.only = {ROOFLINE_OPS[int(torch.argmax(pick).item())]}
-    timer.records.clear()
-    timer.enabled = True
     parallel.STATS.update(bytes=0, messages=0)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        outputs, loss_dict = step()
-        marks[i + 1].record()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    exchanged = dict(parallel.STATS)
-    per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]  # GPU-side step boundaries on the launch stream
-    tmax = torch.tensor([dt, float(np.median(per_step_ms))], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, median_ms = float(tmax[0].item()), float(tmax[1].item())
-    dom_live = timer.summary()
-    timer.records.clear()
-    timer.only, timer.enabled = None, True  # untimed breakdown pass (all ranks: the step contains the collectives)
-    for _ in range(min(args.steps, 10)):
-        step()
-    torch.cuda.synchronize()
-    timer.enabled = False
+    pauses = []
+
+    def gc_cb(phase, info, _t=[0.0]):  # every pass of Python's cycle collector during the measurement, with its length
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        else:
+            pauses.append((info.get("generation"), round((time.perf_counter() - _t[0]) * 1e3, 3)))
+
+    gc.callbacks.append(gc_cb)
+    dt, median_ms, dom_live, outputs, loss_dict = measure(case, timer, args.steps, args.warmup, world, device)
+    exchanged = {k: v for k, v in parallel.STATS.items()}
+    ksum_all = breakdown(case, timer, min(args.steps, 10))  # (all ranks: the step contains the collectives)
+    gc.callbacks.remove(gc_cb)
     dist_info = None
     if world > 1:  # how much of the step is exchange that did NOT hide under the backward: the same step with the collectives off
         parallel.EXCHANGE_DISABLED = True
         for _ in range(3):
-            step()
+            case.step()
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(min(args.steps, 20)):
-            step()
+            case.step()
         torch.cuda.synchronize()
         t_noex = torch.tensor([(time.perf_counter() - t1) / min(args.steps, 20)], device=device, dtype=torch.float64)
         parallel.EXCHANGE_DISABLED = False
         dist.all_reduce(t_noex, op=dist.ReduceOp.MAX)
         sink = pipe.model.field._grad_sink
+        # (the counters also saw the three dominant-operator steps of measure(): per step = / (steps + 3))
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": ndev,
-                     "mb_exchanged_per_step": round(exchanged["bytes"] / args.steps / 1e6, 2),
-                     "messages_per_step": round(exchanged["messages"] / args.steps, 2),
+                     "mb_exchanged_per_step": round(exchanged["bytes"] / (args.steps + 3 + args.warmup) / 1e6, 2),
+                     "messages_per_step": round(exchanged["messages"] / (args.steps + 3 + args.warmup), 2),
                      "level_groups": getattr(sink, "level_groups", None), "async_reduce": getattr(sink, "async_reduce", None),
                      "ms_per_step_without_exchange": round(float(t_noex.item()) * 1e3, 4),
                      "exposed_exchange_ms": round(dt / args.steps * 1e3 - float(t_noex.item()) * 1e3, 4)}
 
     if rank == 0:
-        ksum = timer.summary()
+        ksum = dict(ksum_all)
         ksum.update(dom_live)  # the dominant operator's figure is the one measured inside the timed region
         ms_step = dt / args.steps * 1e3
         psnr = float(pipe.model.psnr(outputs["spectral"].detach(), b["gt_spectral"]))
         loss_dict = {k: v.detach() for k, v in loss_dict.items()}
         print(f"[bench] gpu: {ms_step:.3f} ms/step (median {median_ms:.3f}), {R * world * args.steps / dt:.0f} rays/s", file=sys.stderr, flush=True)
-        kern = {k: round(v[0], 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][0])}
-        dom = next(iter(dom_live)) if dom_live else next(iter(kern))  # the operator that carried the events of the timed region
-        # algorithmic work per launch: hash gather / scatter 1024 B per sample + the level-major feature rows (128 B) and
-        # positions (12 B); field MLPs 2 x MAC per sample (forward), backward = dX + dW = 2 x forward; compositing and the optimizer
-        # by the bytes they must move once
-        spec = cfg["pred_specular"]
-        mac = 3072 + 2 * (1728 + 4096) + 64 * Cn + 64 * (Cn + (1 if spec else 0)) + ((448 + 16 * B) if spec else 0) + Cn * B + 256
-        nstream = (3 * B if spec else B) + Cn
-        # (one GPU: the Adam step of the dense hash levels rides in the bucket reduce of hashgrid_bwd_apply -- 28 B per parameter of
-        # levels 5..15, the same bytes the separate adam_step would move -- so that operator's algorithmic bytes include them)
-        sink = getattr(pipe.model.field, "_grad_sink", None)
-        fused_adam_bytes = 28 * (16 - int(getattr(sink, "sparse_levels", 0) or 0)) * (1 << 19) * 2 if world == 1 else 0
-        alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12),
-                     "hashgrid_bwd_apply": N * (1024 + 128 + 12) + fused_adam_bytes,
-                     # (above 32 bands the compositing pass carries no value stream -- the band sums are formed inside the heads kernel and
-                     # the value half of its backward inside field_bwd, DESIGN 4.3: sigma, t0, t1 in, weights out + two floats per ray)
-                     "composite_fwd": (N * 16 + R * 8) if "field_heads_fwd" in ksum else N * (nstream + 4) * 4, "composite_bwd": N * (2 * B + 5) * 4,
-                     "adam_step": pipe.model.field.flat.numel() * 28}
-        # (wide-band models run the forward as mlp_base + heads with the per-ray band sums inside the heads kernel, and the backward
-        # with the compositing backward's value half inside field_bwd: ops.field_base_fwd / field_heads_fwd; field_bwd then includes it)
-        alg_flops = {"field_fwd": 2.0 * mac * N, "field_bwd": 4.0 * mac * N, "field_base_fwd": 2.0 * 3072 * N,
-                     "field_heads_fwd": 2.0 * (mac - 3072) * N}
-        # HBM traffic / MFMA-busy from the committed rocprofv3 --pmc passes of this same command -- only when they were taken on
-        # THIS build of the kernels (the summary records the source hash); counters cannot be read from inside the process
-        pmc, pmc_src = {}, None
-        for rel in (f"profiles/r03/pmc_summary_{args.config}.json", "profiles/r02/pmc_summary.json", "profiles/r01/pmc_summary.json"):
-            try:
-                with open(os.path.join(ROOT, rel)) as f:
-                    js = json.load(f)
-                if js.get("csrc_sha") == csrc_hash() and js.get("config", "C2") == args.config:
-                    pmc, pmc_src = js["kernels"], rel
-                    break
-            except Exception:
-                pass
-        op_kernels = {"field_bwd": ("field_bwd_tf_kernel", "field_bwd_tfz0_kernel", "field_bwd_tfz1_kernel", "field_slab_fold", "field_reduce_tf", "field_mix_"),
-                      "field_fwd": ("field_fwd_kernel", "field_pack_all"), "field_base_fwd": ("field_fwd_kernel<false, true",),
-                      "field_heads_fwd": ("field_fwd_kernel", "field_heads_finish"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
-                      "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel"),
-                      "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel"), "adam_step": ("adam_kernel",),
-                      "composite_fwd": ("composite_fwd_kernel",), "composite_bwd": ("composite_bwd_kernel",)}
-
-        def roof_of(op):
-            ms, launches = ksum[op]
-            traffic = sum(v["hbm_traffic_bytes"] for k, v in pmc.items() if "hbm_traffic_bytes" in v and any(k.startswith(p_) for p_ in op_kernels.get(op, ()))) or None
-            if op in alg_bytes:
-                ach = alg_bytes[op] / (ms * 1e-3) / 1e9
-                return dict(kernel=op, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                            traffic=traffic, avg_ms=round(ms, 4), launches=launches)
-            if op in alg_flops:
-                ach = alg_flops[op] / (ms * 1e-3) / 1e12
-                # MFMA-busy share of the operator = of all its kernels (the reductions included), weighted by their cycles
-                mk = [v for k, v in pmc.items() if v.get("kernel_cycles_per_xcd") and any(k.startswith(p_) for p_ in op_kernels[op])]
-                busy = round(sum(v.get("mfma_util", 0.0) * v["kernel_cycles_per_xcd"] for v in mk) / sum(v["kernel_cycles_per_xcd"] for v in mk), 4) if mk else None
-                return dict(kernel=op, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4),
-                            traffic=traffic, avg_ms=round(ms, 4), launches=launches, mfma_busy_frac_pmc=busy)
-            return None
-
-        rooflines = [r for r in (roof_of(op) for op in kern) if r is not None]
-        roof = next((r for r in rooflines if r["kernel"] == dom), rooflines[0] if rooflines else None)
-        if roof is not None:
-            roof = dict(roof, pmc_source=pmc_src,
-                        note="dominant operator, timed with HIP events inside the timed region; achieved = algorithmic bytes or FLOPs (SURVEY 8d) "
-                             "/ time; traffic / mfma_busy_frac_pmc only when profiles/*/pmc_summary.json was taken on this build")
+        dom = next(iter(dom_live)) if dom_live else None  # the operator that carried the events of the timed region
+        kern, roof, rooflines = roofline_tables(case, ksum, dom, world, args.config)
         line = {
             "metric": f"train rays/sec (hotdog-shaped 31-band, C2)" if args.config == "C2" else f"train rays/sec ({args.config})",
             "value": round(R * world * args.steps / dt, 1), "unit": "rays/s",
@@ -462,14 +633,32 @@ def main():
             "sanity": {"loss": {k: round(float(v), 6) for k, v in loss_dict.items()},
                        "spectral_psnr_db_vs_uniform_random_gt": round(psnr, 3),
                        "note": "the synthetic ground truth is uniform noise: these only show the step is numerically alive, not image quality"},
-            "kernels_ms": kern, "roofline": roof, "rooflines": rooflines, "csrc_sha": csrc_hash(),
+            "kernels_ms": kern,
+            "kernels_ms_note": "median over the launches of an untimed pass with an event pair around every operator (the dominant one: inside "
+                               "the timed region); kernels_ms_max = the slowest launch of each",
+            "kernels_ms_max": {k: round(v[3], 4) for k, v in ksum.items()},
+            "host_gc_pauses_ms": [p for p in pauses if p[1] >= 1.0],
+            "roofline": roof, "rooflines": rooflines, "csrc_sha": csrc_hash(),
         }
         if dist_info is not None:
             line["dist"] = dist_info
-        if world == 1 and not args.no_sampler_step:
-            del pipe, rs, b, batch, outputs  # (the hot-path pipeline's buffers: the sampler-driven one builds its own model)
+        if world == 1:
+            del pipe, b, outputs, case  # (the hot-path pipeline's buffers: the passes below build their own models)
             torch.cuda.empty_cache()
-            line["sampler_step"] = sampler_step(cfg, device)
+        if world == 1 and not args.no_other_configs:
+            line["other_configs"] = {}
+            for name in ("C3", "C4", "C5", "C2"):
+                if name != args.config:
+                    line["other_configs"][name] = other_config(name, device, timer)
+                    print(f"[bench] {name}: {line['other_configs'][name]['ms_per_step']:.3f} ms/step", file=sys.stderr, flush=True)
+        if world == 1 and not (args.no_eval_image and args.no_sampler_step):
+            scene_pipe, scene_c2w = sampler_scene(cfg, device)
+            if not args.no_sampler_step:
+                line["sampler_step"] = sampler_step(cfg, device, scene_pipe)
+            if not args.no_eval_image:
+                line["eval_image"] = eval_image(cfg, device, scene_pipe, scene_c2w)
+            del scene_pipe
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, seed=42)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)

@@ -251,14 +251,16 @@ def spectral_renderer(spectral: Tensor, weights: Tensor, ray_indices: Optional[T
     return accumulate_along_rays(weights[..., 0], spectral, ray_indices, num_rays)
 
 
-def render_depth_expected(weights: Tensor, starts: Tensor, ends: Tensor, ray_indices: Tensor, num_rays: int) -> Tensor:
-    """nerfstudio ``DepthRenderer(method="expected")`` packed branch  [upstream-recalled] (``umhs_model.py:254-256``)."""
+def render_depth_expected(weights: Tensor, starts: Tensor, ends: Tensor, ray_indices: Tensor, num_rays: int, clip_range=None) -> Tensor:
+    """nerfstudio ``DepthRenderer(method="expected")`` packed branch  [upstream-recalled] (``umhs_model.py:254-256``).
+    ``clip_range`` = (min, max) of the WHOLE batch's sample midpoints when the caller hands in a ray chunk of it (tests only)."""
     eps = 1e-10
     steps = (starts + ends) / 2
     depth = accumulate_along_rays(weights[..., 0], steps, ray_indices, num_rays)
     acc = accumulate_along_rays(weights[..., 0], None, ray_indices, num_rays)
     depth = depth / (acc + eps)
-    return torch.clip(depth, steps.min(), steps.max())
+    lo, hi = (steps.min(), steps.max()) if clip_range is None else clip_range
+    return torch.clip(depth, lo, hi)
 
 
 # --------------------------------------------------------------------------- #
@@ -470,6 +472,7 @@ def model_outputs(
     colour_M: Tensor,
     use_gradient_scaling: bool = True,
     contraction: bool = True,
+    depth_clip_range=None,
 ) -> Dict[str, Tensor]:
     """``UMHSModel.get_outputs`` after the sampler, ``umhs_model.py:239-313`` (spectral methods; ``method="rgb"``: rgb / accumulation / depth)."""
     density, emb, _, _ = field_density(p, origins, directions, starts, ends, contraction)
@@ -480,7 +483,7 @@ def model_outputs(
     pinfo = pack_info(ray_indices, num_rays)
     weights = render_weight_from_density(starts[..., 0], ends[..., 0], fo["density"][..., 0], pinfo)[0][..., None]
     out = {
-        "depth": render_depth_expected(weights, starts, ends, ray_indices, num_rays),
+        "depth": render_depth_expected(weights, starts, ends, ray_indices, num_rays, depth_clip_range),
         "accumulation": accumulate_along_rays(weights[..., 0], None, ray_indices, num_rays),
         "weights": weights,
     }

@@ -124,3 +124,26 @@ def test_sampler_driven_render_runs():
     with torch.no_grad():
         out = m(RayBundle(origins=o.to(DEV), directions=dd.to(DEV)))
     assert out["rgb"].shape == (64, 3) and bool(torch.isfinite(out["rgb"]).all()) and float(out["rgb"].min()) >= 0.0
+
+
+def test_a_batch_without_surviving_samples_renders_the_background():
+    """with no sample left after the march the rgb method must give an all-background image and a legal (zero) backward,
+    not an argument error from the hash-grid entry point (empty tensors carry NULL data pointers)."""
+    from umhsnerf import ops
+    from umhsnerf._ns_compat import packed_ray_samples
+
+    _, m, _ = _pair(R=8, S=4)
+    z3, z1 = torch.zeros(0, 3, device=DEV), torch.zeros(0, 1, device=DEV)
+    rs = packed_ray_samples(z3, z3, z1, z1)
+    ri = torch.zeros(0, dtype=torch.int64, device=DEV)
+    m.train()
+    out = m.get_outputs_from_samples(rs, ri, 8)
+    assert out["rgb"].shape == (8, 3) and out["accumulation"].shape == (8, 1)
+    assert float(out["accumulation"].abs().max()) == 0.0 and float(out["rgb"].abs().max()) == 0.0
+    assert int(out["num_samples_per_ray"].sum()) == 0
+    out["rgb"].sum().backward()
+    assert m.field.flat.grad is None or float(m.field.flat.grad.abs().max()) == 0.0
+    # the C entry points themselves: an empty batch is a no-op, not an argument error
+    enc = ops.hashgrid_fwd(torch.zeros(0, 3, device=DEV), m.field.layout.view(m.field.flat.detach(), "mlp_base.encoder.hash_table"),
+                           m.field.scalings, m.field.layout.log2_hashmap_size, level_major=False)
+    assert enc.shape[0] == 0

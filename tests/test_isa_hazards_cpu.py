@@ -32,5 +32,8 @@ def test_no_inline_asm_mfma_reads_a_freshly_written_vgpr(built_library):
     assert all(os.path.exists(o) for o in objs), "run __graft_entry__.build() first"
     text = "".join(isa_hazards.disassemble(o) for o in objs)
     assert text.count("v_mfma_f32_16x16x16_bf16 a[") > 1000, "the dW products of the transpose-free backward were not found in the disassembly"
-    bad = isa_hazards.check(text)
+    stats = {}
+    bad = isa_hazards.check(text, stats)
     assert not bad, bad[:5]
+    # both operand files were seen and checked: the products on VGPR tiles and the carried ones whose tiles live in AGPRs
+    assert stats.get("v", 0) > 1000 and stats.get("a", 0) > 500, stats

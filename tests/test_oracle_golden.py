@@ -174,3 +174,21 @@ def test_c1_rgb_plumbing_forward_on_cpu():
     sd = p.reference_state_dict()
     assert sd["mlp_head.layers.0.weight"].shape == (64, 31) and sd["mlp_head.layers.2.weight"].shape == (3, 64)
     assert not any(k.startswith(("feature_mlp", "mlp_directional", "endmembers")) for k in sd)
+
+
+def test_the_chunked_oracle_step_of_the_full_size_tests_equals_one_call():
+    """tests/test_hip_fullsize.py runs the oracle in ray chunks at 8192 rays (it is separable per ray): same outputs, batch losses and
+    summed parameter gradients as one call over the whole batch -- checked here on the CPU at a size both forms finish in seconds."""
+    import test_hip_fullsize as F
+
+    R, S, B, C = 48, 12, 31, 6
+    p = F._bench_state(C, B, True)
+    b = T.synthetic_batch(R, S, B, seed=1)
+    M = T.colour_matrix(list(np.linspace(400, 700, B)))
+    one, many = F._oracle_step(p, b, R, 0.4, M), F._oracle_step_chunked(p, b, R, S, 0.4, M, chunk=16)
+    for k in ("spectral", "rgb", "depth", "accumulation", "abundances", "seg_probs", "spectral2", "specular"):
+        assert float((one[0][k].detach() - many[0][k]).abs().max()) <= 2e-7, k
+    for k in one[1]:
+        assert abs(float(one[1][k].detach()) - float(many[1][k])) <= 1e-6 * abs(float(one[1][k].detach())), k
+    for name, g1, g2 in zip(one[3], one[5], many[5]):
+        assert float((g1 - g2).abs().max()) <= 1e-6 * float(g1.abs().max()) + 1e-12, name

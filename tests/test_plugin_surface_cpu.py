@@ -301,6 +301,23 @@ def test_deposited_gradient_follows_the_trainers_loss_scale():
     with pytest.raises(RuntimeError, match="accumulation window"):
         (sum(ld.values()) / 3).backward()
 
+    # (a) a scale while the step's asynchronous all-reduces hold segments of the buffer must raise, not race with them;
+    class _Sink:
+        works = [object()]
+
+        def reducing(self):
+            return True
+
+    flat = torch.nn.Parameter(torch.zeros(4))
+    flat.grad = torch.ones(4)
+    st = {"accumulated": False, "sink": _Sink()}
+    with pytest.raises(RuntimeError, match="exchange of this step is in flight"):
+        (0.5 * _DepositedGrad.apply(torch.tensor(0.7), flat, st)).backward()
+    # (b) where the pipeline knows the scale is 1 (no / disabled grad scaler, no accumulation) the upstream gradient is not read at all
+    flat.grad = torch.ones(4)
+    _DepositedGrad.apply(torch.tensor(0.7), flat, {"accumulated": False, "unit_scale": True}).backward()
+    assert flat.grad.tolist() == [1.0] * 4
+
 
 def test_rgb_field_host_side_pieces_match_the_oracle():
     """umhs_field_rgb.py's torch pieces (no HIP call): SHEncoding(levels=4) on (d+1)/2 and trunc_exp's clamped gradient against the oracle's

@@ -4,8 +4,10 @@
 hipcc's hazard recognizer does not look inside inline asm.  The dW products of the transpose-free field backward are inline-asm MFMAs
 (accumulators pinned to AGPRs); gfx950 needs two wait states between a VALU write of a VGPR (v_perm, v_mov, v_accvgpr_read, a
 conversion ...) and an MFMA that reads it as its A or B operand, and for an inline-asm MFMA nobody inserts them.  This walks the
-disassembly and reports every MFMA with AGPR destination and VGPR operands whose operand registers were written by one of the two
-preceding instructions (s_nop k counts as k + 1).  Exit status 1 if any is found."""
+disassembly and reports every MFMA with AGPR destination whose A / B operand registers -- VGPRs, or AGPRs (the carried dW products
+take their operand tiles from AGPRs, `dwm_a`: a register-allocator copy `v_accvgpr_write` / `v_accvgpr_mov` into such an operand
+right in front of the MFMA is the same hazard) -- were written by one of the two preceding instructions (s_nop k counts as k + 1).
+Exit status 1 if any is found.  `check(text, stats)` also counts the MFMAs it looked at by operand file."""
 import os
 import re
 import shutil
@@ -34,7 +36,7 @@ def disassemble(obj):
         return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
 
 
-def check(text):
+def check(text, stats=None):
     bad, kernel, hist = [], "?", []
     for line in text.split("\n"):
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -47,7 +49,10 @@ def check(text):
         toks = [t.strip(",") for t in ins.split()]
         op = toks[0]
         if op.startswith("v_mfma") and len(toks) >= 4 and toks[1].startswith("a"):
-            srcs = {r for t in toks[2:4] for r in regs(t) if r[0] == "v"}
+            srcs = {r for t in toks[2:4] for r in regs(t)}
+            if stats is not None:
+                for f in {r[0] for r in srcs}:
+                    stats[f] = stats.get(f, 0) + 1
             states = 0
             for prev in reversed(hist[-4:]):
                 if states >= 2:

@@ -107,10 +107,11 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
 extern "C" int umhs_hashgrid_fwd(const float* pos01, const float* table, const float* scalings, int64_t n,
                                  int n_levels, int log2_T, float* enc, int64_t stride_n, int64_t stride_l,
                                  umhs_stream_t stream) {
-  if (n < 0 || !pos01 || !table || !scalings || !enc) return UMHS_ERR_ARG;
+  if (n < 0 || !table || !scalings) return UMHS_ERR_ARG;
   if (n_levels < 1 || n_levels > 32 || log2_T < 1 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (n == 0) return UMHS_OK;  // (an empty batch has no per-sample arrays: torch hands out NULL for them)
+  if (!pos01 || !enc) return UMHS_ERR_ARG;
   if (((uintptr_t)table & 15) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;  // (16-byte slot pairs are fetched with one load)
-  if (n == 0) return UMHS_OK;
   const float2* t2 = reinterpret_cast<const float2*>(table);
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_levels);
   hipLaunchKernelGGL(hashgrid_fwd_kernel, grid, dim3(256), 0, umhs_s(stream), pos01, t2, scalings, n, n_levels, log2_T, enc, stride_n, stride_l);
@@ -150,24 +151,38 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 // N = 262k.  Instead each level's contributions are radix-partitioned by the high bits of their hash
 // slot into buckets of 2^13 slots, every (level, bucket) tile is accumulated in LDS by one workgroup
 // and added to d_table with plain coalesced stores:
-//   count   : per (level, 1024-sample chunk) LDS histogram of bucket ids -> global counts
-//   scan    : exclusive scan of the (level, bucket) counts -> record offsets
-//   scatter : recompute the corners, reserve a contiguous run per (chunk, bucket), store {slot_low, w*g}
-//   reduce  : one workgroup per (level, bucket): stream its records into an LDS tile, flush
-// Two MI355X-specific choices (tools/mb_lds_atomics.hip, measured): LDS float atomics cost 3.1 cycles per
-// lane-op per CU but 64-bit INTEGER LDS atomics 1.35, so the tile is int64 fixed point (scale from the level's
-// max |value| and the bucket's record count: >= 46 bits below the level maximum) -- which also makes every
-// sum exact and order-independent, i.e. bitwise reproducible, unlike the reference's index_put_/atomics.
-// And consecutive samples of a ray mostly share a grid cell on the coarse/mid levels, so lanes with the
-// same cell are merged by a wave segmented scan before a record is emitted (2-30x fewer records there).
+//   count   : per (level, 512-sample run) LDS histogram of bucket ids -> per-workgroup counts
+//   scan    : exclusive prefix over the workgroups of a level (hg_wgscan) and over its buckets (hg_scan)
+//   scatter : recompute the corners, order the run's records by bucket in LDS, write them out
+//   reduce  : one workgroup per (level, bucket): stream its records into an LDS tile, flush (+ Adam)
+// Round 4 (in-kernel stamps, profiles/r04/hg_stamps_*.json): neither pass was bound where rounds 1-3 said.  The scatter pass spent
+// 40 % of its wave time writing records out and 47 % waiting on its few loads behind those stores (hashing + run merging: 3 %); the
+// reduce pass 42-55 % waiting for record loads and 39 % in the Adam stream, 7 % in LDS atomics (the LDS unit alone would do the whole
+// pass in 30 us: tools/mb_lds_atomics2.hip).  What cost the time was the SHAPE of the record stream: {uint16 slot, float2 value} in
+// two arrays = a 2-byte and an 8-byte access per record (MI355X_MICROARCH.md: short stores cost 12.5x, dwordx2 2.7x the dwordx4 time
+// per byte).  Records are now ONE 16-byte word each and there are half as many:
+//   * the two x-neighbours of a corner pair hash to slots s and s ^ (xf ^ xc), i.e. into the same bucket (xf ^ xc < 2^13 for every
+//     resolution below 8192), and their values are g*wyz*(1-ox) and g*wyz*ox: one PAIR record {g.x*wyz, g.y*wyz, ox, meta} serves
+//     both corners (meta = slot_low | k << 13, xf ^ xc = 2^(k+1) - 1) -- 4 records of 16 B per (sample, level) instead of 8 of 10 B,
+//     one dwordx4 store / load each, half the LDS placement work; the reduce pass forms the two corner values;
+//   * a run of samples that share a cell (coarse / mid levels of a real ray batch: merged by a wave segmented scan as before) emits
+//     its 8 corner sums as SINGLE records {v.x, v.y, 0, meta} (k = 15: no partner); so do the (x-integer) and the (partner in another
+//     bucket: resolutions >= 8192 only) cases.
+// Two MI355X-specific choices kept from round 1 (tools/mb_lds_atomics2.hip): LDS float atomics cost 81 ns per wave-instruction but
+// 64-bit INTEGER ones 7.5, so the tile is int64 fixed point (scale from the level's max |value| and the bucket's record count:
+// >= 46 bits below the level maximum) -- which also makes every sum exact and order-independent, i.e. bitwise reproducible,
+// unlike the reference's index_put_/atomics.
 // ---------------------------------------------------------------------------------------------
 #ifndef HB_BUCKET_BITS
 #define HB_BUCKET_BITS 13
 #endif
 #define HB_MAX_NB 128  // buckets per level the partition kernels can handle (two per lane of wave 0)
 #ifndef HB_SPT
-#define HB_SPT 2  // samples per thread -> 512 samples per workgroup (<= 4096 records staged in 44 KiB of LDS)
+#define HB_SPT 2  // samples per thread -> 512 samples per workgroup (<= 2048 pair records staged in 32 KiB of LDS)
 #endif
+#define HB_CAP_PER_SAMPLE 5  // record capacity per (sample, level): 4 pair records, or <= 4 per sample from merged runs; the fifth is
+                             // slack for pairs split over two buckets (resolutions >= 8192); a level that overflows gets NaN gradients
+#define HB_POISON 0xffffffffu
 
 // One Adam update (torch.optim.Adam, no weight decay / amsgrad); one expression for the stand-alone kernels and for the
 // epilogue of hg_reduce_kernel, so that the fused and the separate update give the same bits.
@@ -196,13 +211,13 @@ struct HbArgs {
   int log2_T, bucket_bits, nb, level0, nlev;  // level0: first level of the WORKSPACE range; nlev: its size
   int lev_off;                                 // this launch covers workspace levels [lev_off, lev_off + gridDim.y)
   int grad_mask;  // 1: samples whose gradient is exactly zero emit no records (both passes then need d_enc); 0: every sample does
-  uint32_t *counts, *offsets, *cursor;  // [nlev * nb]
-  uint32_t *wg_counts, *wg_prefix;      // [nlev][nwg][nb]: per-workgroup bucket histogram, and (hg_wgscan) its exclusive prefix over
-  int nwg;                              // the workgroups of the level = each workgroup's private, atomics-free place in every bucket
-  uint32_t* lmax;                       // [nlev] bits of the level's max |record value|
-  uint16_t* rec_idx;                    // [8 * n * nlev]
-  float2* rec_val;
-  int overwrite;                        // reduce: d_table slab = tile (zeros where untouched) instead of +=
+  uint32_t *counts, *offsets;       // [nlev * nb]: records per (level, bucket) and their exclusive prefix INSIDE the level
+  uint32_t *wg_counts, *wg_prefix;  // [nlev][nwg][nb]: per-workgroup bucket histogram, and (hg_wgscan) its exclusive prefix over
+  int nwg;                          // the workgroups of the level = each workgroup's private, atomics-free place in every bucket
+  uint32_t* lmax;                   // [nlev] bits of the level's max |record value|; HB_POISON: the level's records do not fit
+  uint4* recs;                      // [nlev][cap] 16-byte records
+  uint32_t cap;                     // record capacity per level
+  int overwrite;                    // reduce: d_table slab = tile (zeros where untouched) instead of +=
 };
 
 // DPP row_shr:D -- lane l receives the value of lane l-D of its 16-lane row (0 when l%16 < D).  Pure VALU: unlike
@@ -230,6 +245,71 @@ __device__ __forceinline__ void seg_scan_step(float2 (&val)[8], bool& f, int l16
   if (l16 >= D) f = f || pf;
 }
 
+// In-kernel phase stamps of the partitioned backward (tools/stamp_hg.py builds this file with -DUMHS_HG_STAMP into its own library;
+// no stamp executes in the product).  Every wave sums the cycles between consecutive stamps per phase and adds them to
+// g_hg_stamp[kernel][level][phase] once, at its end; [..][15] counts the waves.  HG_STAMP_DRAIN also waits for the wave's outstanding
+// vector-memory operations first, so that a phase that issues loads or stores is charged with their completion.
+#ifdef UMHS_HG_STAMP
+__device__ unsigned long long g_hg_stamp[2][16][16];
+#define HG_STAMP_DECL unsigned long long hgs_acc_[15] = {}, hgs_t_ = hg_now_(false)
+__device__ __forceinline__ unsigned long long hg_now_(bool drain) {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  if (drain) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  } else {
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define HG_STAMP(k_)                              \
+  do {                                            \
+    const unsigned long long n_ = hg_now_(false); \
+    hgs_acc_[k_] += n_ - hgs_t_, hgs_t_ = n_;     \
+  } while (0)
+#define HG_STAMP_DRAIN(k_)                       \
+  do {                                           \
+    const unsigned long long n_ = hg_now_(true); \
+    hgs_acc_[k_] += n_ - hgs_t_, hgs_t_ = n_;    \
+  } while (0)
+#define HG_STAMP_FLUSH(kern_, lev_)                                                                                     \
+  do {                                                                                                                  \
+    if ((threadIdx.x & 63) == 0) {                                                                                      \
+      _Pragma("unroll") for (int q_ = 0; q_ < 15; ++q_) if (hgs_acc_[q_]) atomicAdd(&g_hg_stamp[kern_][(lev_) & 15][q_], hgs_acc_[q_]); \
+      atomicAdd(&g_hg_stamp[kern_][(lev_) & 15][15], 1ull);                                                             \
+    }                                                                                                                   \
+  } while (0)
+extern "C" int umhs_debug_hg_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hg_stamp), sizeof(unsigned long long) * 2 * 16 * 16);
+}
+extern "C" int umhs_debug_hg_stamps_clear() {
+  static unsigned long long z[2 * 16 * 16] = {};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_hg_stamp), z, sizeof(z));
+}
+#else
+#define HG_STAMP_DECL \
+  do {                \
+  } while (0)
+#define HG_STAMP(k_) \
+  do {               \
+  } while (0)
+#define HG_STAMP_DRAIN(k_) \
+  do {                     \
+  } while (0)
+#define HG_STAMP_FLUSH(kern_, lev_) \
+  do {                              \
+  } while (0)
+#endif
+
+// x-pair p of a (sample, level): floor-x corner FI[p], ceil-x corner CI[p] of HashCorners' corner order; their common (y, z) weight
+__device__ constexpr int HB_FI[4] = {3, 2, 7, 6}, HB_CI[4] = {0, 1, 4, 5};
+
+// record meta word: [12:0] slot inside the bucket, [16:13] k (partner slot = slot ^ (2^(k+1) - 1); 15: no partner), [23:17] bucket
+__device__ __forceinline__ uint32_t hb_meta(uint32_t idx, uint32_t k, uint32_t bucket, uint32_t lowmask) {
+  return (idx & lowmask) | (k << 13) | (bucket << 17);
+}
+
 template <bool SCATTER>
 __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg) {  // wg: which run of 256*HB_SPT samples
   __shared__ uint32_t hist[HB_MAX_NB];
@@ -237,47 +317,74 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
   __shared__ uint32_t lbase[HB_MAX_NB + 1];
   __shared__ uint32_t wgmax;
   // scatter pass: records are first ordered by bucket in LDS, then written out with consecutive lanes on consecutive
-  // records (PMC: writing each record straight to its slot cost 288 MB of HBM writes for 146 MB of records)
-  constexpr int MAXREC = SCATTER ? 256 * HB_SPT * 8 : 1;
-  __shared__ float2 recV[MAXREC];
-  __shared__ uint16_t recI[MAXREC];
-  __shared__ uint8_t recB[MAXREC];
+  // records (PMC round 1: writing each record straight to its slot cost 288 MB of HBM writes for 146 MB of records)
+  constexpr int MAXREC = SCATTER ? 256 * HB_SPT * 4 : 1;
+  __shared__ uint4 stage[MAXREC];
   const int tid = threadIdx.x, lane = tid & 63, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
+  HG_STAMP_DECL;
+  if (SCATTER && a.lmax[lev] == HB_POISON) return;  // (uniform) the level's records do not fit its region: hg_reduce writes NaN
   if (tid < HB_MAX_NB) hist[tid] = 0;
   if (tid == 0) wgmax = 0;
   // scatter pass: the histogram pass left this workgroup's bucket counts and hg_wgscan its place in every bucket, so nothing is
-  // counted again and no global cursor is touched -- wave 0 fetches both here and turns them into LDS offsets after the hashing
-  uint32_t my_count[2] = {0, 0}, my_base[2] = {0, 0};  // buckets tid and tid + 64 (wave 0)
+  // counted again and no global cursor is touched -- wave 0 fetches both and turns them into LDS offsets before anything is hashed
   if (SCATTER && tid < 64) {
+    uint32_t carry = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int bk = tid + 64 * h;
+      uint32_t c = 0, mb = 0;
       if (bk < a.nb) {
         const size_t o = ((size_t)lev * a.nwg + wg) * a.nb + bk;
-        my_count[h] = a.wg_counts[o];
-        my_base[h] = a.offsets[lev * a.nb + bk] + a.wg_prefix[o];
+        c = a.wg_counts[o];
+        mb = a.offsets[lev * a.nb + bk] + a.wg_prefix[o];
       }
+      uint32_t incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+      }
+      lbase[bk] = carry + incl - c;
+      carry += __shfl(incl, 63, 64);
+      // this workgroup's slice of the bucket: bucket start + the records of the workgroups before it -- no cursor atomics
+      base[bk] = mb;
     }
+    if (tid == 0) lbase[HB_MAX_NB] = carry;
   }
   __syncthreads();
   const float s = a.scalings[l];
-  const uint32_t mask = (1u << a.log2_T) - 1u;
-  uint32_t slot[HB_SPT][8];
-  float2 val[HB_SPT][8];
-  bool emit[HB_SPT];
+  const uint32_t mask = (1u << a.log2_T) - 1u, lowmask = (1u << a.bucket_bits) - 1u;
+  const int bb = a.bucket_bits;
+  uint4* const __restrict__ out = a.recs + (size_t)lev * a.cap;
+  const bool staged = SCATTER && lbase[HB_MAX_NB] <= (uint32_t)MAXREC;  // (split pairs can exceed 4 per sample: then straight to memory)
+  if (SCATTER) HG_STAMP_DRAIN(0);
   // max |record value| of the level as raw bits: for non-negative floats the integer order is the float order, and an Inf / NaN
   // pattern (>= 0x7f800000) beats every finite one -- hg_reduce turns a level that saw one into NaN gradients instead of
   // an arbitrary fixed-point conversion (fmaxf would silently drop a NaN; the reference's index_add propagates it)
   uint32_t vmax = 0u;
+  auto emit = [&](const uint32_t idx, const uint32_t k, const float vx, const float vy, const float ox) {
+    const uint32_t b = idx >> bb;
+    if (!SCATTER) {
+      atomicAdd(&hist[b], 1u);
+      return;
+    }
+    vmax = max(vmax, max(__float_as_uint(fabsf(vx)), __float_as_uint(fabsf(vy))));
+    const uint32_t pos = lbase[b] + atomicAdd(&hist[b], 1u);
+    const uint4 r = make_uint4(__float_as_uint(vx), __float_as_uint(vy), __float_as_uint(ox), hb_meta(idx, k, b, lowmask));
+    if (staged)
+      stage[pos] = r;
+    else
+      out[base[b] + (pos - lbase[b])] = r;
+  };
 #pragma unroll
   for (int k = 0; k < HB_SPT; ++k) {
     const int64_t i = (int64_t)wg * (256 * HB_SPT) + k * 256 + tid;
     bool act = false;
-    float g0 = 0.0f, g1 = 0.0f;
+    float g0 = 0.0f, g1 = 0.0f, ox = 0.0f, oy = 0.0f, oz = 0.0f;
     uint32_t kx = 0xffffffffu, ky = 0, kz = 0, kf = 0x80000000u | (uint32_t)lane;  // unique per lane when inactive
-    float w[8];
+    uint32_t slot[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) w[c] = 0.0f, slot[k][c] = 0;
+    for (int c = 0; c < 8; ++c) slot[c] = 0;
     if (i < a.n) {
       if (SCATTER || a.grad_mask) {  // the histogram pass of a prepare/apply pair runs before any gradient exists
         const float* g = a.d_enc + i * a.sn + (int64_t)l * a.sl;
@@ -286,105 +393,111 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
       if (!a.grad_mask || g0 != 0.0f || g1 != 0.0f) {
         act = true;
         const float px = a.pos01[3 * i], py = a.pos01[3 * i + 1], pz = a.pos01[3 * i + 2];
+        if (SCATTER) HG_STAMP_DRAIN(1);
         HashCorners h = hash_corners(px, py, pz, s, mask, 0u);
-        const float ox = h.ox, oy = h.oy, oz = h.oz, rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
-        w[0] = ox * oy * oz, w[3] = rx * oy * oz, w[1] = ox * ry * oz, w[2] = rx * ry * oz;
-        w[4] = ox * oy * rz, w[7] = rx * oy * rz, w[5] = ox * ry * rz, w[6] = rx * ry * rz;
+        ox = h.ox, oy = h.oy, oz = h.oz;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) slot[k][c] = h.idx[c];
+        for (int c = 0; c < 8; ++c) slot[c] = h.idx[c];
         // cell identity: floor coordinates + "coordinate is an exact integer" flags (ceil == floor)
         kx = h.fx, ky = h.fy, kz = h.fz, kf = h.eqx | (h.eqy << 1) | (h.eqz << 2);
       }
     }
     // runs of equal cells are merged inside each 16-lane DPP row (all cross-lane ops executed by every lane)
+    if (SCATTER) HG_STAMP(2);
     const int l16 = lane & 15;
     const uint32_t px_ = row_shr_u<1>(kx), py_ = row_shr_u<1>(ky), pz_ = row_shr_u<1>(kz), pf_ = row_shr_u<1>(kf);
     const bool head = (l16 == 0) | (px_ != kx) | (py_ != ky) | (pz_ != kz) | (pf_ != kf);
     const int nhead = row_shl1((int)head);
-    emit[k] = act && (l16 == 15 || nhead);  // tail lane of a run of equal cells emits the run's sum
-    if (SCATTER) {
+    const bool tail = act && (l16 == 15 || nhead);  // tail lane of a run of equal cells emits for the run
+    const bool solo = head && tail;                 // a run of one sample: pair records
+    const float rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
+    float2 val[8];
+    // the 8 corner sums of a merged run: segmented inclusive scan over the row, (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv) --
+    // skipped (wave-uniform branch) when every lane of the wave starts its own run, i.e. nothing merges: always so on the fine levels
+    const bool merging = __builtin_amdgcn_ballot_w64(!head) != 0;
+    if (SCATTER && merging) {
+      float w[8];
+      w[0] = ox * oy * oz, w[3] = rx * oy * oz, w[1] = ox * ry * oz, w[2] = rx * ry * oz;
+      w[4] = ox * oy * rz, w[7] = rx * oy * rz, w[5] = ox * ry * rz, w[6] = rx * ry * rz;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) val[k][c] = make_float2(w[c] * g0, w[c] * g1);
-      // segmented inclusive scan over the row: (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv) -- skipped (wave-uniform branch) when
-      // every lane of the wave starts its own run, i.e. nothing merges: always so on the fine levels, and 64 DPP moves + adds saved
-      if (__builtin_amdgcn_ballot_w64(!head) != 0) {
-        bool f = head;
-        seg_scan_step<1>(val[k], f, l16), seg_scan_step<2>(val[k], f, l16);
-        seg_scan_step<4>(val[k], f, l16), seg_scan_step<8>(val[k], f, l16);
+      for (int c = 0; c < 8; ++c) val[c] = act ? make_float2(w[c] * g0, w[c] * g1) : make_float2(0.0f, 0.0f);
+      bool f = head;
+      seg_scan_step<1>(val, f, l16), seg_scan_step<2>(val, f, l16);
+      seg_scan_step<4>(val, f, l16), seg_scan_step<8>(val, f, l16);
+    }
+    if (SCATTER) HG_STAMP(3);
+    if (tail) {
+      if (solo) {
+        const float wyz[4] = {oy * oz, ry * oz, oy * rz, ry * rz};  // (y, z) weight of x-pair p: (c,c) (f,c) (c,f) (f,f)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const uint32_t iF = slot[HB_FI[p]], iC = slot[HB_CI[p]], pm = iF ^ iC;
+          const float gx = g0 * wyz[p], gy = g1 * wyz[p];
+          if ((pm >> bb) == 0) {  // both corners in one bucket (always below resolution 8192): one record, the reduce pass splits it
+            emit(iF, pm ? (uint32_t)(31 - __clz((int)pm)) : 15u, gx, gy, ox);  // (pm == 0: x is an integer, ox == 0, all weight on iF)
+          } else {
+            emit(iF, 15u, gx * rx, gy * rx, 0.0f);
+            emit(iC, 15u, gx * ox, gy * ox, 0.0f);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) emit(slot[c], 15u, SCATTER ? val[c].x : 0.0f, SCATTER ? val[c].y : 0.0f, 0.0f);
       }
     }
-    if (emit[k]) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (!SCATTER) atomicAdd(&hist[slot[k][c] >> a.bucket_bits], 1u);
-        if (SCATTER) vmax = max(vmax, max(__float_as_uint(fabsf(val[k][c].x)), __float_as_uint(fabsf(val[k][c].y))));
-      }
-    }
-  }
-  if (SCATTER) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
-    if (lane == 0 && vmax > 0u) atomicMax(&wgmax, vmax);
+    if (SCATTER) HG_STAMP(4);
   }
   if (!SCATTER) {
     __syncthreads();
     if (tid < a.nb) a.wg_counts[((size_t)lev * a.nwg + wg) * a.nb + tid] = hist[tid];
     return;
   }
-  if (tid < 64) {  // wave 0: local exclusive prefix of the bucket counts (two buckets per lane: 0-63, then 64-127)
-    uint32_t carry = 0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t c = my_count[h];
-      uint32_t incl = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-      }
-      lbase[tid + 64 * h] = carry + incl - c;
-      carry += __shfl(incl, 63, 64);
-      // this workgroup's slice of the bucket: bucket start + the records of the workgroups before it -- no cursor atomics (512
-      // workgroups x 64 buckets hammering 1024 counters made the returning atomic the longest step of the workgroup)
-      base[tid + 64 * h] = my_base[h];
-    }
-    if (tid == 0) lbase[HB_MAX_NB] = carry;
-  }
+  for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
+  if (lane == 0 && vmax > 0u) atomicMax(&wgmax, vmax);
+  HG_STAMP(5);
   __syncthreads();
+  HG_STAMP(6);
   if (tid == 0 && wgmax) atomicMax(&a.lmax[lev], wgmax);
-  const uint32_t lowmask = (1u << a.bucket_bits) - 1u;
-#pragma unroll
-  for (int k = 0; k < HB_SPT; ++k) {
-    if (emit[k]) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const uint32_t b = slot[k][c] >> a.bucket_bits;
-        const uint32_t pos = lbase[b] + atomicAdd(&hist[b], 1u);
-        recI[pos] = (uint16_t)(slot[k][c] & lowmask);
-        recV[pos] = val[k][c];
-        recB[pos] = (uint8_t)b;
-      }
+  if (staged) {
+    const uint32_t total = lbase[HB_MAX_NB];
+    for (uint32_t i = tid; i < total; i += 256) {
+      const uint4 r = stage[i];
+      const uint32_t b = (r.w >> 17) & 127u;
+      out[base[b] + (i - lbase[b])] = r;
     }
   }
-  __syncthreads();
-  const uint32_t total = lbase[HB_MAX_NB];
-  for (uint32_t i = tid; i < total; i += 256) {
-    const uint32_t b = recB[i];
-    const uint32_t g = base[b] + (i - lbase[b]);
-    a.rec_idx[g] = recI[i];
-    a.rec_val[g] = recV[i];
-  }
+  HG_STAMP_DRAIN(7);
+  HG_STAMP_FLUSH(0, l);
 }
 
 // Scatter pass: one workgroup per run of samples.  Histogram pass: gridDim.x workgroups per level walk the runs -- a caller that
 // hides the pass under other kernels (umhs_hashgrid_bwd_prepare on a side stream) launches few, so that it takes a small, steady
 // share of the CUs instead of flooding the dispatcher in front of the kernels it overlaps with.
+#ifndef HB_XCD_REMAP
+#define HB_XCD_REMAP 1
+#endif
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
   if (SCATTER) {
+#if HB_XCD_REMAP
+    // Workgroups go to the 8 XCDs round-robin by their linear index, and the runs wg, wg + 1 write ADJACENT record runs in every
+    // bucket -- short ones on the coarse levels, so most 128-byte lines of the record stream are shared by neighbouring workgroups.
+    // With neighbours on different XCDs each partial line is written back by its own L2 and merged at the memory side (a
+    // read-modify-write under ECC); XCD x therefore takes the CONTIGUOUS runs [x * per, (x + 1) * per): neighbours share an L2,
+    // their partial lines combine there.  (gridDim.x = 8 * per.)
+    const int per = (int)(gridDim.x >> 3), wg = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (wg >= a.nwg) return;
+    hg_partition_body<true>(a, wg);
+#else
+    if ((int)blockIdx.x >= a.nwg) return;
     hg_partition_body<true>(a, (int)blockIdx.x);
+#endif
   } else {
-    for (int wg = blockIdx.x; wg < a.nwg; wg += gridDim.x) hg_partition_body<false>(a, wg);
+    for (int wg = blockIdx.x; wg < a.nwg; wg += gridDim.x) {
+      hg_partition_body<false>(a, wg);
+      __syncthreads();  // (the histogram is zeroed again at the top of the next run)
+    }
   }
 }
 
@@ -417,118 +530,142 @@ __global__ __launch_bounds__(256) void hg_wgscan_kernel(HbArgs a) {
     pre[(size_t)w * a.nb] = run;
     run += col[(size_t)w * a.nb];
   }
-  if (tid == 0) {
-    a.counts[lev * a.nb + b] = total;
-    if (b == 0) a.lmax[lev] = 0u;
-  }
+  if (tid == 0) a.counts[lev * a.nb + b] = total;
 }
 
-__global__ void hg_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                               uint32_t* __restrict__ cursor, int m) {
-  // m <= 16 levels x 64 buckets: one wave does a chunked 64-lane scan
-  const int lane = threadIdx.x;
+// One wave per level: exclusive scan of the level's bucket counts (nb <= 128: two per lane) -> offsets inside the level's record
+// region; sets the level's max-|value| word to 0, or to HB_POISON when its records exceed the region.
+__global__ void hg_scan_kernel(HbArgs a) {
+  const int lane = threadIdx.x, lev = blockIdx.x;
   uint32_t carry = 0;
-  for (int base = 0; base < m; base += 64) {
-    const int i = base + lane;
-    uint32_t c = i < m ? counts[i] : 0u, incl = c;
+  for (int b0 = 0; b0 < a.nb; b0 += 64) {
+    const int b = b0 + lane;
+    const uint32_t c = b < a.nb ? a.counts[lev * a.nb + b] : 0u;
+    uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      uint32_t o = __shfl_up(incl, d, 64);
+      const uint32_t o = __shfl_up(incl, d, 64);
       if (lane >= d) incl += o;
     }
-    if (i < m) offsets[i] = cursor[i] = carry + incl - c;
+    if (b < a.nb) a.offsets[lev * a.nb + b] = carry + incl - c;
     carry += __shfl(incl, 63, 64);
   }
+  if (lane == 0) a.lmax[lev] = carry > a.cap ? HB_POISON : 0u;
 }
+
+__device__ __forceinline__ unsigned long long hb_fixed(const float v, const int k) { return (unsigned long long)__float2ll_rn(ldexpf(v, k)); }
 
 __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __restrict__ d_table) {
   extern __shared__ __attribute__((aligned(16))) long long tile[];  // [2 << bucket_bits] int64 fixed point
   const int tid = threadIdx.x, b = blockIdx.x, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
+  HG_STAMP_DECL;
   const uint32_t start = a.offsets[lev * a.nb + b], cnt = a.counts[lev * a.nb + b];
   const int nsl = 2 << a.bucket_bits;
   const size_t slab = 2 * (((size_t)l << a.log2_T) + ((size_t)b << a.bucket_bits));  // element offset of this (level, bucket)
   const bool adam = a.adam.p != nullptr && l >= a.adam.level_begin;
-  auto step4 = [&](int j, const float4& g) {  // Adam on 4 consecutive table entries whose final gradient is g
-    float4 pp = *reinterpret_cast<float4*>(a.adam.p + slab + j), mm = *reinterpret_cast<float4*>(a.adam.m + slab + j);
-    float4 vv = *reinterpret_cast<float4*>(a.adam.v + slab + j);
+  auto step4 = [&](const float4& g, float4& pp, float4& mm, float4& vv) {  // Adam on 4 consecutive table entries whose final gradient is g
     adam_update(pp.x, mm.x, vv.x, g.x, a.adam.lr_bc1, a.adam.b1, a.adam.b2, a.adam.eps, a.adam.sqrt_bc2);
     adam_update(pp.y, mm.y, vv.y, g.y, a.adam.lr_bc1, a.adam.b1, a.adam.b2, a.adam.eps, a.adam.sqrt_bc2);
     adam_update(pp.z, mm.z, vv.z, g.z, a.adam.lr_bc1, a.adam.b1, a.adam.b2, a.adam.eps, a.adam.sqrt_bc2);
     adam_update(pp.w, mm.w, vv.w, g.w, a.adam.lr_bc1, a.adam.b1, a.adam.b2, a.adam.eps, a.adam.sqrt_bc2);
-    *reinterpret_cast<float4*>(a.adam.p + slab + j) = pp;
-    *reinterpret_cast<float4*>(a.adam.m + slab + j) = mm;
-    *reinterpret_cast<float4*>(a.adam.v + slab + j) = vv;
   };
-  if (cnt == 0) {  // nothing lands in this slab (uniform over the workgroup)
-    if (a.overwrite) {
-      float* dst0 = d_table + slab;
-      for (int j = tid * 4; j < nsl; j += 4096) {
-        *reinterpret_cast<float4*>(dst0 + j) = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (adam) step4(j, make_float4(0.f, 0.f, 0.f, 0.f));  // zero gradient: the moments still decay and move the entry
+  // epilogue of every path: the slab's gradient (+ its Adam step) as float4 lanes; the optimizer operands of a thread's (up to)
+  // four chunks are requested before anything is computed -- three loads in flight per chunk, not three per thread
+  const uint32_t lmax_bits = a.lmax[lev];
+  // a non-finite gradient reached this level: the slabs its records land in are NaN, as after the reference's index_add; a level
+  // whose records did not fit its region (HB_POISON) is NaN everywhere
+  const bool nan_level = lmax_bits >= 0x7f800000u && (cnt != 0 || lmax_bits == HB_POISON);
+  const bool from_tile = cnt != 0 && !nan_level;
+  if (!from_tile && !a.overwrite && !nan_level) return;  // nothing lands in this slab and it is not ours to zero
+  int kfix = 0;
+  if (from_tile) {
+    for (int i = tid; i < nsl; i += 1024) tile[i] = 0;
+    // fixed-point scale 2^k:  |v| <= vmax < 2^e, at most cnt < 2^hb addends  =>  |sum| * 2^k < 2^62
+    int e;
+    (void)frexpf(__uint_as_float(lmax_bits), &e);
+    const int hb = 33 - __clz(cnt);  // cnt < 2^(32-clz) ; one spare bit
+    kfix = 62 - hb - e;
+    __syncthreads();
+    const uint4* __restrict__ rp = a.recs + (size_t)lev * a.cap + start;
+    typedef unsigned long long u64;
+    u64* ut = reinterpret_cast<u64*>(tile);
+    const uint32_t lowmask = (1u << a.bucket_bits) - 1u;
+    auto add = [&](const uint4& r) {
+      const float vx = __uint_as_float(r.x), vy = __uint_as_float(r.y), ox = __uint_as_float(r.z);
+      const uint32_t s = r.w & lowmask, kk = (r.w >> 13) & 15u;
+      const float rx = 1.0f - ox;
+      atomicAdd(&ut[2 * s], hb_fixed(vx * rx, kfix)), atomicAdd(&ut[2 * s + 1], hb_fixed(vy * rx, kfix));
+      if (kk != 15u) {
+        const uint32_t cs = s ^ (((2u << kk) - 1u) & lowmask);
+        atomicAdd(&ut[2 * cs], hb_fixed(vx * ox, kfix)), atomicAdd(&ut[2 * cs + 1], hb_fixed(vy * ox, kfix));
+      }
+    };
+    uint32_t i = tid;
+    HG_STAMP(0);
+    for (; i + 3072 < cnt; i += 4096) {  // 4 records in flight per thread
+      const uint4 r0 = rp[i], r1 = rp[i + 1024], r2 = rp[i + 2048], r3 = rp[i + 3072];
+      HG_STAMP_DRAIN(1);
+      add(r0), add(r1), add(r2), add(r3);
+      HG_STAMP(3);
+    }
+    for (; i < cnt; i += 1024) add(rp[i]);
+    HG_STAMP_DRAIN(3);
+    __syncthreads();
+    HG_STAMP(4);
+  }
+  float* const dst = d_table + slab;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  for (int j0 = tid * 4; j0 < nsl; j0 += 4 * 4096) {
+    float4 pp[4], mm[4], vv[4], dd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = min(j0 + c * 4096, nsl - 4);  // (chunks past the slab re-read its last float4 and are not stored)
+      if (adam) {
+        pp[c] = *reinterpret_cast<const float4*>(a.adam.p + slab + j), mm[c] = *reinterpret_cast<const float4*>(a.adam.m + slab + j);
+        vv[c] = *reinterpret_cast<const float4*>(a.adam.v + slab + j);
+      }
+      if (!a.overwrite) dd[c] = *reinterpret_cast<const float4*>(dst + j);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + c * 4096;
+      if (j < nsl) {
+        float4 d = a.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : dd[c];
+        if (nan_level) {
+          d = make_float4(qnan, qnan, qnan, qnan);
+        } else if (from_tile) {
+          d.x += (float)ldexp((double)tile[j], -kfix), d.y += (float)ldexp((double)tile[j + 1], -kfix);
+          d.z += (float)ldexp((double)tile[j + 2], -kfix), d.w += (float)ldexp((double)tile[j + 3], -kfix);
+        }
+        *reinterpret_cast<float4*>(dst + j) = d;
+        // The gradient of these entries is final here (one GPU, overwrite mode): update them in place of a separate pass -- the
+        // 67 MB gradient is not read back and the stand-alone Adam launch shrinks to the MLP tail + the sparse rows.  (A slab no
+        // record lands in still steps: with a zero gradient the moments decay and move the entry.)
+        if (adam) {
+          step4(d, pp[c], mm[c], vv[c]);
+          *reinterpret_cast<float4*>(a.adam.p + slab + j) = pp[c];
+          *reinterpret_cast<float4*>(a.adam.m + slab + j) = mm[c];
+          *reinterpret_cast<float4*>(a.adam.v + slab + j) = vv[c];
+        }
       }
     }
-    return;
   }
-  const uint32_t lmax_bits = a.lmax[lev];
-  if (lmax_bits >= 0x7f800000u) {  // a non-finite gradient reached this level: its gradient is NaN, as after the reference's index_add
-    float* dst0 = d_table + slab;
-    const float qnan = __uint_as_float(0x7fc00000u);
-    for (int j = tid * 4; j < nsl; j += 4096) {
-      *reinterpret_cast<float4*>(dst0 + j) = make_float4(qnan, qnan, qnan, qnan);
-      if (adam) step4(j, make_float4(qnan, qnan, qnan, qnan));
-    }
-    return;
-  }
-  for (int i = tid; i < nsl; i += 1024) tile[i] = 0;
-  // fixed-point scale 2^k:  |v| <= vmax < 2^e, at most cnt < 2^hb addends  =>  |sum| * 2^k < 2^62
-  int e;
-  (void)frexpf(__uint_as_float(lmax_bits), &e);
-  const int hb = 33 - __clz(cnt);  // cnt < 2^(32-clz) ; one spare bit
-  const int k = 62 - hb - e;
-  __syncthreads();
-  const uint16_t* __restrict__ ri = a.rec_idx + start;
-  const float2* __restrict__ rv = a.rec_val + start;
-  typedef unsigned long long u64;
-  u64* ut = reinterpret_cast<u64*>(tile);
-  uint32_t i = tid;
-  for (; i + 3072 < cnt; i += 4096) {  // 4 records in flight per thread
-    const uint32_t i0 = ri[i], i1 = ri[i + 1024], i2 = ri[i + 2048], i3 = ri[i + 3072];
-    const float2 v0 = rv[i], v1 = rv[i + 1024], v2 = rv[i + 2048], v3 = rv[i + 3072];
-    atomicAdd(&ut[2 * i0], (u64)__float2ll_rn(ldexpf(v0.x, k))), atomicAdd(&ut[2 * i0 + 1], (u64)__float2ll_rn(ldexpf(v0.y, k)));
-    atomicAdd(&ut[2 * i1], (u64)__float2ll_rn(ldexpf(v1.x, k))), atomicAdd(&ut[2 * i1 + 1], (u64)__float2ll_rn(ldexpf(v1.y, k)));
-    atomicAdd(&ut[2 * i2], (u64)__float2ll_rn(ldexpf(v2.x, k))), atomicAdd(&ut[2 * i2 + 1], (u64)__float2ll_rn(ldexpf(v2.y, k)));
-    atomicAdd(&ut[2 * i3], (u64)__float2ll_rn(ldexpf(v3.x, k))), atomicAdd(&ut[2 * i3 + 1], (u64)__float2ll_rn(ldexpf(v3.y, k)));
-  }
-  for (; i < cnt; i += 1024) {
-    const uint32_t i0 = ri[i];
-    const float2 v0 = rv[i];
-    atomicAdd(&ut[2 * i0], (u64)__float2ll_rn(ldexpf(v0.x, k))), atomicAdd(&ut[2 * i0 + 1], (u64)__float2ll_rn(ldexpf(v0.y, k)));
-  }
-  __syncthreads();
-  float* dst = d_table + slab;
-  for (int j = tid * 4; j < nsl; j += 4096) {
-    float4 d = a.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(dst + j);
-    d.x += (float)ldexp((double)tile[j], -k), d.y += (float)ldexp((double)tile[j + 1], -k);
-    d.z += (float)ldexp((double)tile[j + 2], -k), d.w += (float)ldexp((double)tile[j + 3], -k);
-    *reinterpret_cast<float4*>(dst + j) = d;
-    // The gradient of these entries is final here (one GPU, overwrite mode): update them in place of a separate pass -- the 67 MB
-    // gradient is not read back and the stand-alone Adam launch shrinks to the MLP tail + the sparse rows.  Measured: the reduce
-    // pass grows by 39 us, the Adam launch shrinks by 46 (with one 128 KiB workgroup per CU the rounds stay in step, so the
-    // epilogues of the whole grid stream at once rather than hiding under their neighbours' LDS atomics; requesting the operands
-    // before the accumulation was slower still: +59 us).
-    if (adam) step4(j, d);
-  }
+  HG_STAMP_DRAIN(5);
+  HG_STAMP_FLUSH(1, l);
 }
 
 static inline int hb_bucket_bits(int log2_T) { return log2_T < HB_BUCKET_BITS ? log2_T : HB_BUCKET_BITS; }
+
+static inline size_t hb_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_T) {
   if (n <= 0 || n_levels < 1 || log2_T < 2) return 0;
   const int nb = 1 << (log2_T - hb_bucket_bits(log2_T));
   if (nb > HB_MAX_NB) return 0;  // larger tables: only the atomic path is available
-  const size_t m = (size_t)n_levels * nb, cap = (size_t)8 * n * n_levels;
+  if ((size_t)n * HB_CAP_PER_SAMPLE >= ((size_t)1 << 32)) return 0;  // record indices inside a level are 32-bit
+  const size_t m = (size_t)n_levels * nb, cap = (size_t)n * HB_CAP_PER_SAMPLE;
   const size_t nwg = (size_t)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
-  return (3 * m + 64) * 4 + 256 + 2 * ((size_t)n_levels * nwg * nb * 4 + 256) + cap * 2 + 256 + cap * 8 + 256;
+  return 256 + hb_align((2 * m + 64) * 4) + 2 * hb_align((size_t)n_levels * nwg * nb * 4) + hb_align((size_t)n_levels * cap * 16);
 }
 
 static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t n, int ws_begin, int ws_levels, int log2_T,
@@ -540,7 +677,8 @@ extern "C" int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t
                                  const float* scalings, int64_t n, int level_begin, int n_levels, int log2_T,
                                  float* d_table, int overwrite, void* workspace, size_t workspace_bytes,
                                  umhs_stream_t stream) {
-  if (n < 0 || !pos01 || !d_enc || !scalings || !d_table || level_begin < 0) return UMHS_ERR_ARG;
+  if (n < 0 || !scalings || !d_table || level_begin < 0) return UMHS_ERR_ARG;
+  if (n > 0 && (!pos01 || !d_enc)) return UMHS_ERR_ARG;  // (an empty batch has no per-sample arrays)
   if (overwrite && (!workspace || n == 0)) {  // only the partitioned path writes every slot itself
     if (hipMemsetAsync(d_table + (((size_t)level_begin << log2_T) * 2), 0, ((size_t)n_levels << log2_T) * 8, umhs_s(stream)) !=
         hipSuccess)
@@ -571,23 +709,21 @@ static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t
   const size_t need = umhs_hashgrid_bwd_workspace_bytes(n, ws_levels, log2_T);
   if (need == 0) return UMHS_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < need) return UMHS_ERR_WORKSPACE;
-  if ((size_t)8 * n * ws_levels >= ((size_t)1 << 32)) return UMHS_ERR_UNSUPPORTED;
   a->pos01 = pos01, a->d_enc = nullptr, a->sn = 0, a->sl = 0, a->scalings = scalings, a->n = n;
   a->log2_T = log2_T, a->bucket_bits = hb_bucket_bits(log2_T), a->nb = 1 << (log2_T - a->bucket_bits), a->level0 = ws_begin;
   a->nlev = ws_levels, a->lev_off = 0, a->overwrite = 0, a->grad_mask = 0;
   a->adam = HbAdam{};
-  const size_t m = (size_t)ws_levels * a->nb, cap = (size_t)8 * n * ws_levels;
+  const size_t m = (size_t)ws_levels * a->nb;
+  a->cap = (uint32_t)((size_t)n * HB_CAP_PER_SAMPLE);
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
-  a->counts = reinterpret_cast<uint32_t*>(p), a->lmax = a->counts + m, a->offsets = a->lmax + 64, a->cursor = a->offsets + m;
-  p = (p + (3 * m + 64) * 4 + 255) & ~(uintptr_t)255;
+  a->counts = reinterpret_cast<uint32_t*>(p), a->offsets = a->counts + m, a->lmax = a->offsets + m;
+  p += hb_align((2 * m + 64) * 4);
   a->nwg = (int)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
   a->wg_counts = reinterpret_cast<uint32_t*>(p);
-  p = (p + (size_t)ws_levels * a->nwg * a->nb * 4 + 255) & ~(uintptr_t)255;
+  p += hb_align((size_t)ws_levels * a->nwg * a->nb * 4);
   a->wg_prefix = reinterpret_cast<uint32_t*>(p);
-  p = (p + (size_t)ws_levels * a->nwg * a->nb * 4 + 255) & ~(uintptr_t)255;
-  a->rec_idx = reinterpret_cast<uint16_t*>(p);
-  p = (p + cap * 2 + 255) & ~(uintptr_t)255;
-  a->rec_val = reinterpret_cast<float2*>(p);
+  p += hb_align((size_t)ws_levels * a->nwg * a->nb * 4);
+  a->recs = reinterpret_cast<uint4*>(p);
   return UMHS_OK;
 }
 
@@ -596,19 +732,18 @@ static int hb_run_prepare(const HbArgs& a, int n_levels, int count_wgs, umhs_str
   // The histogram pass reads the gradient only in the one-call form (grad_mask): a prepare half built from hb_args() has
   // d_enc == nullptr, and a pass that dereferenced it anyway is the nil-address GPU fault recorded in DESIGN.md section 9.
   if (a.grad_mask && !a.d_enc) return UMHS_ERR_ARG;
-  const size_t m = (size_t)a.nlev * a.nb;
+  if (n_levels != a.nlev) return UMHS_ERR_ARG;  // (the scans walk the whole workspace range)
   dim3 pgrid((unsigned)(count_wgs > 0 && count_wgs < a.nwg ? count_wgs : a.nwg), (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<false>, pgrid, dim3(256), 0, umhs_s(stream), a);
   hipLaunchKernelGGL(hg_wgscan_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(256), 0, umhs_s(stream), a);
-  hipLaunchKernelGGL(hg_scan_kernel, dim3(1), dim3(64), 0, umhs_s(stream), (const uint32_t*)a.counts, a.offsets, a.cursor,
-                     (int)m);
+  hipLaunchKernelGGL(hg_scan_kernel, dim3((unsigned)n_levels), dim3(64), 0, umhs_s(stream), a);
   UMHS_CHECK_LAUNCH();
   return UMHS_OK;
 }
 
 static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stream_t stream) {  // scatter + bucket reduce
   if (!a.d_enc || !d_table || !a.pos01 || !a.scalings) return UMHS_ERR_ARG;  // every pointer the two kernels dereference
-  dim3 pgrid((unsigned)((a.n + 256 * HB_SPT - 1) / (256 * HB_SPT)), (unsigned)n_levels);
+  dim3 pgrid((unsigned)(((a.nwg + 7) / 8) * 8), (unsigned)n_levels);  // (a multiple of 8: hg_partition_kernel's XCD mapping)
   hipLaunchKernelGGL(hg_partition_kernel<true>, pgrid, dim3(256), 0, umhs_s(stream), a);
   const size_t lds = (size_t)(2 << a.bucket_bits) * 8;
   {  // raise the dynamic-LDS limit once per device, not per call (the driver call is a bubble in front of the launch)
@@ -632,9 +767,10 @@ static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stre
 // form; the one-call umhs_hashgrid_bwd skips samples whose gradient is exactly zero.)
 extern "C" int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalings, int64_t n, int level_begin, int n_levels,
                                          int log2_T, void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
-  if (n < 0 || !pos01 || !scalings || level_begin < 0) return UMHS_ERR_ARG;
+  if (n < 0 || !scalings || level_begin < 0) return UMHS_ERR_ARG;
   if (n_levels < 1 || level_begin + n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
   if (n == 0) return UMHS_OK;
+  if (!pos01) return UMHS_ERR_ARG;
   HbArgs a;
   int rc = hb_args(&a, pos01, scalings, n, level_begin, n_levels, log2_T, workspace, workspace_bytes);
   if (rc) return rc;
@@ -648,7 +784,8 @@ extern "C" int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalin
 static int hb_apply(const float* pos01, const float* d_enc, int64_t stride_n, int64_t stride_l, const float* scalings, int64_t n,
                     int level_begin, int n_levels, int ws_level_begin, int ws_n_levels, int log2_T, float* d_table, int overwrite,
                     const HbAdam* adam, void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
-  if (n < 0 || !pos01 || !d_enc || !scalings || !d_table || level_begin < 0) return UMHS_ERR_ARG;
+  if (n < 0 || !scalings || !d_table || level_begin < 0) return UMHS_ERR_ARG;
+  if (n > 0 && (!pos01 || !d_enc)) return UMHS_ERR_ARG;
   if (n_levels < 1 || level_begin < ws_level_begin || level_begin + n_levels > ws_level_begin + ws_n_levels ||
       ws_level_begin + ws_n_levels > 32 || log2_T < 2 || log2_T > 24)
     return UMHS_ERR_UNSUPPORTED;

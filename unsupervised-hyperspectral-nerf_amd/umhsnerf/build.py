@@ -26,8 +26,24 @@ def _headers():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "umhs_hip.h")]
 
 
-def _obj_stale(src: str, obj: str) -> bool:
+def _cmd_stamp(cmd) -> str:
+    import hashlib
+
+    # (paths reduced to their last component: the same tree under another root -- a gpurun snapshot -- is the same build)
+    return hashlib.sha256("\0".join(("-I" + os.path.basename(c[2:])) if c.startswith("-I") else os.path.basename(c) if os.sep in c else c
+                                     for c in cmd).encode()).hexdigest()
+
+
+def _obj_stale(src: str, obj: str, cmd) -> bool:
+    """An object is stale when a source / header is newer, or when it was compiled with another command line (flags, defines, unit
+    split: `<obj>.cmd` holds the hash of the command that produced it -- an A/B of compiler flags must never link a mixed build)."""
     if not os.path.exists(obj):
+        return True
+    try:
+        with open(obj + ".cmd") as f:
+            if f.read().strip() != _cmd_stamp(cmd):
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(obj)
     return any(os.path.getmtime(d) > t for d in [src, *_headers()])
@@ -36,6 +52,15 @@ def _obj_stale(src: str, obj: str) -> bool:
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    for src in SOURCES:  # an object compiled with another command line (or never stamped) makes the library stale too
+        for suffix, defines in UNITS.get(src, (("", []),)):
+            obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
+            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *defines, f"-I{INCLUDE}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
+            if os.path.exists(obj) and not os.path.exists(obj + ".cmd"):
+                continue  # (objects that travelled without their stamp -- a GPU box's copy -- are judged by their mtimes alone)
+            if _obj_stale(os.path.join(CSRC, src), obj, cmd):
+                return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
@@ -51,15 +76,19 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
         for suffix, defines in UNITS.get(src, (("", []),)):
             obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
             objs.append(obj)
-            if not force and not _obj_stale(os.path.join(CSRC, src), obj):
-                continue
             cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *defines, f"-I{INCLUDE}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
+            if not force and not _obj_stale(os.path.join(CSRC, src), obj, cmd):
+                continue
+            if os.path.exists(obj + ".cmd"):
+                os.remove(obj + ".cmd")
             if verbose:
                 print(" ".join(cmd), flush=True)
             running.append((cmd, subprocess.Popen(cmd)))
     for cmd, proc in running:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
+        with open(cmd[-1] + ".cmd", "w") as f:
+            f.write(_cmd_stamp(cmd))
         if verbose:
             print(f"[build] {os.path.basename(cmd[-1])}: done {time.time() - t0:.0f} s after the start", flush=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]

@@ -356,6 +356,13 @@ class UMHSModel(ModelBase):
         per ray, as the reference does for every other output.  Background: "random" leaves the colour unblended here (it is blended
         in the loss, ``blend_background_for_loss_computation``), "white" / "black" add ``bg (1 - accumulation)``, as RGBRenderer does."""
         c, fr = self.config, ray_samples.frustums
+        if fr.origins.numel() == 0:  # no sample survived the march: every ray shows the background (and the step has a zero gradient)
+            R, dev_ = packed_info.shape[0], packed_info.device
+            zero = (self.field.flat[:1] * 0.0).sum() if torch.is_grad_enabled() else torch.zeros((), device=dev_)  # keeps loss.backward() legal
+            acc = torch.zeros(R, 1, device=dev_) + zero
+            rgb = torch.zeros(R, 3, device=dev_) + zero + (1.0 if self.background_color == "white" else 0.0)
+            return {"accumulation": acc, "depth": torch.zeros(R, 1, device=dev_), "rgb": rgb, "num_samples_per_ray": packed_info[:, 1],
+                    "weights": torch.zeros(0, 1, device=dev_)}
         fo = self.field(ray_samples)
         weights, accumulation, depth, rgb = ops.CompositeFn.apply(fo[FieldHeadNames.DENSITY], fr.starts, fr.ends, packed_info,
                                                                   bool(c.use_gradient_scaling), fo[FieldHeadNames.RGB])

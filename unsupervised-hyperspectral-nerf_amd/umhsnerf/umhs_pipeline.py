@@ -40,7 +40,9 @@ class _DepositedGrad(torch.autograd.Function):
     the PLAIN sum of the losses, so an upstream gradient g != 1 -- a GradScaler's loss scale, a division by the accumulation steps --
     multiplies the step's contribution to ``param.grad`` by g (once per step: every loss of the step must arrive with the same g; a
     trainer that weights the losses differently needs the autograd path, UMHS_DIRECT_STEP=0, and gets an error here, not a silently
-    wrong step).  Reading g costs one host sync per loss in trainer-driven mode; UMHS_TRUST_UNIT_LOSS_SCALE=1 skips it."""
+    wrong step).  Reading g is one host sync per loss, so it is skipped where g is known to be 1: a pipeline whose trainer handed it
+    no grad scaler or a disabled one (the shipped TrainerConfig: mixed_precision False) and that does no gradient accumulation
+    (``step_state["unit_scale"]``), and under UMHS_TRUST_UNIT_LOSS_SCALE=1."""
 
     @staticmethod
     def forward(ctx, value, flat, step_state):
@@ -49,7 +51,7 @@ class _DepositedGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if os.environ.get("UMHS_TRUST_UNIT_LOSS_SCALE", "0") == "1":
+        if ctx.step_state.get("unit_scale") or os.environ.get("UMHS_TRUST_UNIT_LOSS_SCALE", "0") == "1":
             return None, None, None
         st, gv = ctx.step_state, float(g)
         if "g" not in st:
@@ -58,6 +60,12 @@ class _DepositedGrad(torch.autograd.Function):
                 if st.get("accumulated"):  # earlier micro-steps of the window are in the same buffer: their share must not be rescaled
                     raise RuntimeError(f"loss scaled by {gv:g} inside a gradient-accumulation window: the deposited gradient cannot be "
                                        "rescaled per micro-step (run with UMHS_DIRECT_STEP=0)")
+                sink = st.get("sink")
+                if sink is not None and (sink.reducing() or sink.works):
+                    # the backward has already handed segments of this buffer to asynchronous all-reduces: an in-place multiply
+                    # would race with the transfers and leave the ranks with differently scaled sums
+                    raise RuntimeError(f"loss scaled by {gv:g} while the gradient exchange of this step is in flight: a loss scale on "
+                                       "more than one rank needs the autograd path (UMHS_DIRECT_STEP=0)")
                 ctx.flat.grad.mul_(gv)
         elif st["g"] != gv:
             raise RuntimeError(f"the trainer weights this step's losses differently ({st['g']:g} vs {gv:g}): the launch-sequence step has "
@@ -86,6 +94,7 @@ class UMHSPipeline(PipelineBase):
             scene_box=datamanager.train_dataset.scene_box, num_train_data=len(datamanager.train_dataset),
             metadata=datamanager.train_dataset.metadata, grad_scaler=grad_scaler, num_classes=config.num_classes,
             wavelengths=datamanager.train_dataparser_outputs.metadata.get("wavelengths", None))
+        self.grad_scaler = grad_scaler  # (None or disabled: the trainer's backward() arrives unscaled, see _deposit)
         self._init_common(model.to(device), datamanager, device, world_size, local_rank, trainer_driven=True,
                           gradient_accumulation_steps=config.gradient_accumulation_steps)
 
@@ -99,6 +108,7 @@ class UMHSPipeline(PipelineBase):
         self.config = UMHSPipelineConfig(model=config, num_classes=int((metadata or {}).get("num_classes", 5)),
                                          gradient_accumulation_steps=gradient_accumulation_steps)
         self.test_mode = "val"
+        self.grad_scaler = None
         if datamanager is not None:
             metadata = {**(datamanager.metadata or {}), **(metadata or {})}
             scene_box = scene_box if scene_box is not None else getattr(datamanager, "scene_box", None)
@@ -145,7 +155,12 @@ class UMHSPipeline(PipelineBase):
     def _deposit(self, loss_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Trainer-driven mode: the trainer will call ``.backward()`` on the summed losses -- the gradient is in ``param.grad`` already."""
         flat = self._model.field.flat
-        step_state = {"accumulated": self._model.field._spec().grad_sink.accumulating}
+        sink = self._model.field._spec().grad_sink
+        scaler = getattr(self, "grad_scaler", None)
+        scaler_on = scaler is not None and (scaler.is_enabled() if hasattr(scaler, "is_enabled") else True)
+        # no scaler (or a disabled one) and no accumulation window: the trainer's backward() arrives with g = 1 -- nothing to read back
+        unit = (not scaler_on) and self.gradient_accumulation_steps == 1 and os.environ.get("UMHS_CHECK_LOSS_SCALE", "0") != "1"
+        step_state = {"accumulated": sink.accumulating, "sink": sink, "unit_scale": unit}
         return {k: _DepositedGrad.apply(v, flat, step_state) for k, v in loss_dict.items()}
 
     def train_iteration(self, ray_samples: RaySamples, ray_indices, num_rays: int, batch: Dict, packed_info=None, background=None):
