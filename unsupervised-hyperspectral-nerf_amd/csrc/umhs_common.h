@@ -60,11 +60,13 @@ __device__ __forceinline__ HashCorners hash_corners(float px, float py, float pz
   asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
   float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
   uint32_t xf = (uint32_t)(int)fx, yf = (uint32_t)(int)fy * HASH_P1, zf = (uint32_t)(int)fz * HASH_P2;
-  uint32_t xc = (uint32_t)(int)ceilf(sx), yc = (uint32_t)(int)ceilf(sy) * HASH_P1,
-           zc = (uint32_t)(int)ceilf(sz) * HASH_P2;
+  // ceil = floor + 1 unless the coordinate is an integer: the hashed ceil products are the floor products + the prime (the same
+  // bits as (uint32_t)(int)ceilf(.) * P mod 2^32, without two more quarter-rate v_mul_lo_u32)
+  const bool ex = fx == sx, ey = fy == sy, ez = fz == sz;
+  uint32_t xc = ex ? xf : xf + 1u, yc = ey ? yf : yf + HASH_P1, zc = ez ? zf : zf + HASH_P2;
   HashCorners h;
   h.fx = xf, h.fy = (uint32_t)(int)fy, h.fz = (uint32_t)(int)fz;
-  h.eqx = xc == xf, h.eqy = yc == yf, h.eqz = zc == zf;
+  h.eqx = ex, h.eqy = ey, h.eqz = ez;
   h.ox = sx - fx, h.oy = sy - fy, h.oz = sz - fz;
   // corner order of nerfstudio HashEncoding.pytorch_fwd: 0 ccc, 1 cfc, 2 ffc, 3 fcc, 4 ccf, 5 cff, 6 fff, 7 fcf
   h.idx[0] = ((xc ^ yc ^ zc) & mask) + base;

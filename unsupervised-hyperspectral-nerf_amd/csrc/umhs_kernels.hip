@@ -182,7 +182,15 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 #endif
 #define HB_CAP_PER_SAMPLE 5  // record capacity per (sample, level): 4 pair records, or <= 4 per sample from merged runs; the fifth is
                              // slack for pairs split over two buckets (resolutions >= 8192); a level that overflows gets NaN gradients
+#ifndef HB_MERGE_MIN
+#define HB_MERGE_MIN 16  // lanes of a wave that must continue a run of equal cells for the wave to merge runs
+#endif
 #define HB_POISON 0xffffffffu
+// One word per scatter workgroup and level for the level's max |value|, reduced by the readers.  Rounds 1-3 (and the first round-4
+// builds) did `atomicMax(&lmax[level])` once per workgroup run: 8192 device-scope atomics on 16 words of ONE cache line serialise at
+// the memory side at ~12 ns each = 100 us -- the whole scatter pass, whatever else it did (ablations of tools/alt_kernels.py:
+// 98 us with every store, LDS placement and the write-out removed, 16 us once the maximum stayed zero).
+#define HB_LMAX_PARTS 64
 
 // One Adam update (torch.optim.Adam, no weight decay / amsgrad); one expression for the stand-alone kernels and for the
 // epilogue of hg_reduce_kernel, so that the fused and the separate update give the same bits.
@@ -214,7 +222,8 @@ struct HbArgs {
   uint32_t *counts, *offsets;       // [nlev * nb]: records per (level, bucket) and their exclusive prefix INSIDE the level
   uint32_t *wg_counts, *wg_prefix;  // [nlev][nwg][nb]: per-workgroup bucket histogram, and (hg_wgscan) its exclusive prefix over
   int nwg;                          // the workgroups of the level = each workgroup's private, atomics-free place in every bucket
-  uint32_t* lmax;                   // [nlev] bits of the level's max |record value|; HB_POISON: the level's records do not fit
+  uint32_t* lmax;                   // [nlev][HB_LMAX_PARTS] bits of the max |record value| seen by each scatter workgroup of the level
+                                    // ([..][0] = HB_POISON, set by hg_scan: the level's records do not fit its region)
   uint4* recs;                      // [nlev][cap] 16-byte records
   uint32_t cap;                     // record capacity per level
   int overwrite;                    // reduce: d_table slab = tile (zeros where untouched) instead of +=
@@ -232,6 +241,24 @@ __device__ __forceinline__ uint32_t row_shr_u(uint32_t v) {
 }
 __device__ __forceinline__ int row_shl1(int v) {  // lane l <- lane l+1 of its row (0 at the row end)
   return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true);
+}
+// 64-lane inclusive prefix sum on the VALU alone (gfx9 DPP: four shifts inside the 16-lane rows, then row_bcast:15 into rows 1 and 3
+// and row_bcast:31 into the upper half): the scatter pass is bound by VALU + LDS issue, and a __shfl_up scan is six ds_bpermute
+// round trips through the LDS unit per 64 values.
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
+  v += row_shr_u<1>(v);
+  v += row_shr_u<2>(v);
+  v += row_shr_u<4>(v);
+  v += row_shr_u<8>(v);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// maximum over the 64 lanes, uniform result (row-wise DPP, then the four row results through readlane)
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+  v = max(v, row_shr_u<1>(v)), v = max(v, row_shr_u<2>(v)), v = max(v, row_shr_u<4>(v)), v = max(v, row_shr_u<8>(v));  // lane 15 of a row: its max (values >= 0)
+  return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 15), (uint32_t)__builtin_amdgcn_readlane((int)v, 31)),
+             max((uint32_t)__builtin_amdgcn_readlane((int)v, 47), (uint32_t)__builtin_amdgcn_readlane((int)v, 63)));
 }
 template <int D>
 __device__ __forceinline__ void seg_scan_step(float2 (&val)[8], bool& f, int l16) {
@@ -305,76 +332,104 @@ extern "C" int umhs_debug_hg_stamps_clear() {
 // x-pair p of a (sample, level): floor-x corner FI[p], ceil-x corner CI[p] of HashCorners' corner order; their common (y, z) weight
 __device__ constexpr int HB_FI[4] = {3, 2, 7, 6}, HB_CI[4] = {0, 1, 4, 5};
 
-// record meta word: [12:0] slot inside the bucket, [16:13] k (partner slot = slot ^ (2^(k+1) - 1); 15: no partner), [23:17] bucket
-__device__ __forceinline__ uint32_t hb_meta(uint32_t idx, uint32_t k, uint32_t bucket, uint32_t lowmask) {
-  return (idx & lowmask) | (k << 13) | (bucket << 17);
+// record meta word: [23:0] slot index inside the level (its bits above bucket_bits = the bucket), [27:24] k: the partner slot is
+// slot ^ (2^(k+1) - 1); 15: no partner
+
+// Everything a workgroup reads from memory for one run of 256 * HB_SPT samples.  Requested in ONE batch (hb_load), a whole run ahead
+// of its use by the scatter pass's persistent workgroups: the stamps of round 4 showed the pass as a chain of dependent memory
+// latencies per workgroup (level flag -> bucket counts / prefix -> barrier -> gradient -> position: 47 % of a wave's time at 12-16
+// waves per CU) behind the CU's own queue of record stores, not as bandwidth.  Lanes past the end load the last sample
+// (unconditional loads stay batched; a load under a per-lane condition compiles to a branch + s_waitcnt vmcnt(0)).
+struct HbIn {
+  float g[HB_SPT][2], p[HB_SPT][3];
+  uint32_t c[2], mb[2];  // wave 0: this workgroup's record count in buckets lane / lane + 64 and where its slice of them starts
+};
+
+template <bool SCATTER>
+__device__ __forceinline__ void hb_load(const HbArgs& a, const int wg, const int lev, const int l, HbIn& in) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < HB_SPT; ++k) {
+    const int64_t i = (int64_t)wg * (256 * HB_SPT) + k * 256 + tid, ii = i < a.n ? i : a.n - 1;
+    in.g[k][0] = in.g[k][1] = 0.0f;
+    if (SCATTER || a.grad_mask) {  // the histogram pass of a prepare/apply pair runs before any gradient exists
+      const float* g = a.d_enc + ii * a.sn + (int64_t)l * a.sl;
+      if (((a.sn | a.sl) & 1) == 0 && (((uintptr_t)a.d_enc) & 7) == 0) {
+        const float2 g2 = *reinterpret_cast<const float2*>(g);
+        in.g[k][0] = g2.x, in.g[k][1] = g2.y;
+      } else {
+        in.g[k][0] = g[0], in.g[k][1] = g[1];
+      }
+    }
+    in.p[k][0] = a.pos01[3 * ii], in.p[k][1] = a.pos01[3 * ii + 1], in.p[k][2] = a.pos01[3 * ii + 2];
+  }
+  in.c[0] = in.c[1] = in.mb[0] = in.mb[1] = 0u;
+  if (SCATTER && tid < 64) {  // the histogram pass left this workgroup's bucket counts and hg_wgscan its place in every bucket
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int bk = tid + 64 * h;
+      if (bk < a.nb) {
+        const size_t o = ((size_t)lev * a.nwg + wg) * a.nb + bk;
+        in.c[h] = a.wg_counts[o];
+        in.mb[h] = a.offsets[lev * a.nb + bk] + a.wg_prefix[o];
+      }
+    }
+  }
 }
 
 template <bool SCATTER>
-__device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg) {  // wg: which run of 256*HB_SPT samples
-  __shared__ uint32_t hist[HB_MAX_NB];
-  __shared__ uint32_t base[HB_MAX_NB];
-  __shared__ uint32_t lbase[HB_MAX_NB + 1];
-  __shared__ uint32_t wgmax;
+__device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg, const int lev, const int l, const float s, const HbIn& in,
+                                                  uint32_t& wgmax) {
+  // cursor[b]: histogram pass: records of bucket b; scatter pass: where the next record of bucket b goes in the LDS staging array
+  // (starts at the run's first place, so a returning atomic add IS the place).  delta[b]: (global place) - (staged place) of bucket b.
+  __shared__ uint32_t cursor[HB_MAX_NB];
+  __shared__ uint32_t delta[HB_MAX_NB];
+  __shared__ uint32_t ltotal;
   // scatter pass: records are first ordered by bucket in LDS, then written out with consecutive lanes on consecutive
-  // records (PMC round 1: writing each record straight to its slot cost 288 MB of HBM writes for 146 MB of records)
+  // records (tools/mb_scatter_store.hip: 5.7 TB/s in this shape, 3.2 TB/s with every lane storing its own record where it belongs)
   constexpr int MAXREC = SCATTER ? 256 * HB_SPT * 4 : 1;
   __shared__ uint4 stage[MAXREC];
-  const int tid = threadIdx.x, lane = tid & 63, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
+  const int tid = threadIdx.x, lane = tid & 63;
   HG_STAMP_DECL;
-  if (SCATTER && a.lmax[lev] == HB_POISON) return;  // (uniform) the level's records do not fit its region: hg_reduce writes NaN
-  if (tid < HB_MAX_NB) hist[tid] = 0;
-  if (tid == 0) wgmax = 0;
-  // scatter pass: the histogram pass left this workgroup's bucket counts and hg_wgscan its place in every bucket, so nothing is
-  // counted again and no global cursor is touched -- wave 0 fetches both and turns them into LDS offsets before anything is hashed
+  if (!SCATTER && tid < HB_MAX_NB) cursor[tid] = 0;
+  // scatter pass: nothing is counted again and no global cursor is touched -- wave 0 turns the workgroup's bucket counts into LDS offsets
   if (SCATTER && tid < 64) {
     uint32_t carry = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int bk = tid + 64 * h;
-      uint32_t c = 0, mb = 0;
-      if (bk < a.nb) {
-        const size_t o = ((size_t)lev * a.nwg + wg) * a.nb + bk;
-        c = a.wg_counts[o];
-        mb = a.offsets[lev * a.nb + bk] + a.wg_prefix[o];
-      }
-      uint32_t incl = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-      }
-      lbase[bk] = carry + incl - c;
-      carry += __shfl(incl, 63, 64);
+      const uint32_t c = in.c[h], mb = in.mb[h];
+      const uint32_t incl = wave_scan_incl_dpp(c);
+      const uint32_t first = carry + incl - c;
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       // this workgroup's slice of the bucket: bucket start + the records of the workgroups before it -- no cursor atomics
-      base[bk] = mb;
+      cursor[bk] = first, delta[bk] = mb - first;
     }
-    if (tid == 0) lbase[HB_MAX_NB] = carry;
+    if (tid == 0) ltotal = carry;
   }
   __syncthreads();
-  const float s = a.scalings[l];
-  const uint32_t mask = (1u << a.log2_T) - 1u, lowmask = (1u << a.bucket_bits) - 1u;
+  const uint32_t mask = (1u << a.log2_T) - 1u;
   const int bb = a.bucket_bits;
   uint4* const __restrict__ out = a.recs + (size_t)lev * a.cap;
-  const bool staged = SCATTER && lbase[HB_MAX_NB] <= (uint32_t)MAXREC;  // (split pairs can exceed 4 per sample: then straight to memory)
+  const bool staged = SCATTER && ltotal <= (uint32_t)MAXREC;  // (pairs split over two buckets can exceed 4 per sample: then straight to memory)
   if (SCATTER) HG_STAMP_DRAIN(0);
   // max |record value| of the level as raw bits: for non-negative floats the integer order is the float order, and an Inf / NaN
   // pattern (>= 0x7f800000) beats every finite one -- hg_reduce turns a level that saw one into NaN gradients instead of
   // an arbitrary fixed-point conversion (fmaxf would silently drop a NaN; the reference's index_add propagates it)
   uint32_t vmax = 0u;
-  auto emit = [&](const uint32_t idx, const uint32_t k, const float vx, const float vy, const float ox) {
-    const uint32_t b = idx >> bb;
-    if (!SCATTER) {
-      atomicAdd(&hist[b], 1u);
-      return;
-    }
-    vmax = max(vmax, max(__float_as_uint(fabsf(vx)), __float_as_uint(fabsf(vy))));
-    const uint32_t pos = lbase[b] + atomicAdd(&hist[b], 1u);
-    const uint4 r = make_uint4(__float_as_uint(vx), __float_as_uint(vy), __float_as_uint(ox), hb_meta(idx, k, b, lowmask));
+  auto emit = [&](const uint32_t meta, const float vx, const float vy, const float ox) {  // meta = slot index | k << 24
+    const uint32_t b = __builtin_amdgcn_ubfe(meta, (uint32_t)bb, (uint32_t)(24 - bb));
+#ifdef HB_ABL_NOPLACE  // (ablation builds of tools/alt_kernels.py only: never defined in the product)
+    asm volatile("" ::"v"(vx), "v"(vy), "v"(ox), "v"(b));
+    return;
+#endif
+    const uint32_t pos = atomicAdd(&cursor[b], 1u);
+    if (!SCATTER) return;
+    const uint4 r = make_uint4(__float_as_uint(vx), __float_as_uint(vy), __float_as_uint(ox), meta);
     if (staged)
       stage[pos] = r;
     else
-      out[base[b] + (pos - lbase[b])] = r;
+      out[delta[b] + pos] = r;
   };
 #pragma unroll
   for (int k = 0; k < HB_SPT; ++k) {
@@ -385,16 +440,17 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
     uint32_t slot[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) slot[c] = 0;
+    if (SCATTER) HG_STAMP_DRAIN(1);
+#ifdef HB_ABL_NOHASH
+    asm volatile("" ::"v"(in.g[k][0]), "v"(in.g[k][1]), "v"(in.p[k][0]), "v"(in.p[k][1]), "v"(in.p[k][2]));
+    if (false) {
+#else
     if (i < a.n) {
-      if (SCATTER || a.grad_mask) {  // the histogram pass of a prepare/apply pair runs before any gradient exists
-        const float* g = a.d_enc + i * a.sn + (int64_t)l * a.sl;
-        g0 = g[0], g1 = g[1];
-      }
+#endif
+      g0 = in.g[k][0], g1 = in.g[k][1];
       if (!a.grad_mask || g0 != 0.0f || g1 != 0.0f) {
         act = true;
-        const float px = a.pos01[3 * i], py = a.pos01[3 * i + 1], pz = a.pos01[3 * i + 2];
-        if (SCATTER) HG_STAMP_DRAIN(1);
-        HashCorners h = hash_corners(px, py, pz, s, mask, 0u);
+        HashCorners h = hash_corners(in.p[k][0], in.p[k][1], in.p[k][2], s, mask, 0u);
         ox = h.ox, oy = h.oy, oz = h.oz;
 #pragma unroll
         for (int c = 0; c < 8; ++c) slot[c] = h.idx[c];
@@ -406,15 +462,23 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
     if (SCATTER) HG_STAMP(2);
     const int l16 = lane & 15;
     const uint32_t px_ = row_shr_u<1>(kx), py_ = row_shr_u<1>(ky), pz_ = row_shr_u<1>(kz), pf_ = row_shr_u<1>(kf);
-    const bool head = (l16 == 0) | (px_ != kx) | (py_ != ky) | (pz_ != kz) | (pf_ != kf);
-    const int nhead = row_shl1((int)head);
+    bool head = (l16 == 0) | (px_ != kx) | (py_ != ky) | (pz_ != kz) | (pf_ != kf);
+    // Merging is a wave-wide decision (the scan below is ~450 VALU instructions per sample for all 64 lanes): it is taken where it
+    // removes records in earnest -- at least a quarter of the wave's samples continue a run -- and otherwise every sample stays a
+    // run of its own.  (Both passes see the same positions, hence take the same decision.)
+#ifdef HB_ABL_NODPP
+    head = true;
+    const bool merging = false;
+#else
+    const bool merging = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!head)) >= HB_MERGE_MIN;
+#endif
+    if (!merging) head = true;
+    const int nhead = merging ? row_shl1((int)head) : 1;
     const bool tail = act && (l16 == 15 || nhead);  // tail lane of a run of equal cells emits for the run
     const bool solo = head && tail;                 // a run of one sample: pair records
     const float rx = 1.0f - ox, ry = 1.0f - oy, rz = 1.0f - oz;
     float2 val[8];
-    // the 8 corner sums of a merged run: segmented inclusive scan over the row, (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv) --
-    // skipped (wave-uniform branch) when every lane of the wave starts its own run, i.e. nothing merges: always so on the fine levels
-    const bool merging = __builtin_amdgcn_ballot_w64(!head) != 0;
+    // the 8 corner sums of a merged run: segmented inclusive scan over the row, (f, v) (+) (pf, pv) = (f | pf, f ? v : v + pv)
     if (SCATTER && merging) {
       float w[8];
       w[0] = ox * oy * oz, w[3] = rx * oy * oz, w[1] = ox * ry * oz, w[2] = rx * ry * oz;
@@ -426,76 +490,136 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg)
       seg_scan_step<4>(val, f, l16), seg_scan_step<8>(val, f, l16);
     }
     if (SCATTER) HG_STAMP(3);
+#ifdef HB_ABL_NOEMIT
+    asm volatile("" ::"v"(slot[0]), "v"(slot[1]), "v"(slot[2]), "v"(slot[3]), "v"(slot[4]), "v"(slot[5]), "v"(slot[6]), "v"(slot[7]), "v"(ox), "v"(oy), "v"(oz), "v"(g0), "v"(g1));
+    if (false) {
+#else
     if (tail) {
+#endif
+      const uint32_t single = 15u << 24;
       if (solo) {
+        // the x-neighbours of all four pairs differ by the same pattern (xf ^ xc) & mask = 2^(k+1) - 1; |g wyz| <= |g|: one maximum per sample
+        const uint32_t pm = slot[HB_FI[0]] ^ slot[HB_CI[0]];
         const float wyz[4] = {oy * oz, ry * oz, oy * rz, ry * rz};  // (y, z) weight of x-pair p: (c,c) (f,c) (c,f) (f,f)
+        if (SCATTER) vmax = max(vmax, max(__float_as_uint(fabsf(g0)), __float_as_uint(fabsf(g1))));
+        if ((pm >> bb) == 0) {  // both corners in one bucket (always below resolution 8192): one record, the reduce pass splits it
+          const uint32_t km = (pm ? (uint32_t)(31 - __clz((int)pm)) : 15u) << 24;  // (pm == 0: x is an integer, ox == 0, all weight on the floor slot)
+          // (the four places first, then the four records: four returning LDS atomics in flight instead of one round trip per record)
+          uint32_t meta[4], pos[4], bk[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const uint32_t iF = slot[HB_FI[p]], iC = slot[HB_CI[p]], pm = iF ^ iC;
-          const float gx = g0 * wyz[p], gy = g1 * wyz[p];
-          if ((pm >> bb) == 0) {  // both corners in one bucket (always below resolution 8192): one record, the reduce pass splits it
-            emit(iF, pm ? (uint32_t)(31 - __clz((int)pm)) : 15u, gx, gy, ox);  // (pm == 0: x is an integer, ox == 0, all weight on iF)
-          } else {
-            emit(iF, 15u, gx * rx, gy * rx, 0.0f);
-            emit(iC, 15u, gx * ox, gy * ox, 0.0f);
+          for (int p = 0; p < 4; ++p) {
+            meta[p] = slot[HB_FI[p]] | km;
+            bk[p] = __builtin_amdgcn_ubfe(meta[p], (uint32_t)bb, (uint32_t)(24 - bb));
+#ifdef HB_ABL_NOPLACE
+            pos[p] = bk[p];
+#else
+            pos[p] = atomicAdd(&cursor[bk[p]], 1u);
+#endif
+          }
+          if (SCATTER) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const uint4 r = make_uint4(__float_as_uint(g0 * wyz[p]), __float_as_uint(g1 * wyz[p]), __float_as_uint(ox), meta[p]);
+#ifdef HB_ABL_NOPLACE
+              asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "v"(pos[p]));
+#else
+              if (staged)
+                stage[pos[p]] = r;
+              else
+                out[delta[bk[p]] + pos[p]] = r;
+#endif
+            }
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float gx = g0 * wyz[p], gy = g1 * wyz[p];
+            emit(slot[HB_FI[p]] | single, gx * rx, gy * rx, 0.0f);
+            emit(slot[HB_CI[p]] | single, gx * ox, gy * ox, 0.0f);
           }
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) emit(slot[c], 15u, SCATTER ? val[c].x : 0.0f, SCATTER ? val[c].y : 0.0f, 0.0f);
+        for (int c = 0; c < 8; ++c) {
+          if (SCATTER) vmax = max(vmax, max(__float_as_uint(fabsf(val[c].x)), __float_as_uint(fabsf(val[c].y))));
+          emit(slot[c] | single, SCATTER ? val[c].x : 0.0f, SCATTER ? val[c].y : 0.0f, 0.0f);
+        }
       }
     }
     if (SCATTER) HG_STAMP(4);
   }
   if (!SCATTER) {
     __syncthreads();
-    if (tid < a.nb) a.wg_counts[((size_t)lev * a.nwg + wg) * a.nb + tid] = hist[tid];
+    if (tid < a.nb) a.wg_counts[((size_t)lev * a.nwg + wg) * a.nb + tid] = cursor[tid];
     return;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
-  if (lane == 0 && vmax > 0u) atomicMax(&wgmax, vmax);
+  vmax = wave_max_u32_dpp(vmax);
+  if (lane == 0 && vmax > 0u) atomicMax(&wgmax, vmax);  // (LDS; the kernel writes the workgroup's maximum out once, after its last run)
   HG_STAMP(5);
   __syncthreads();
   HG_STAMP(6);
-  if (tid == 0 && wgmax) atomicMax(&a.lmax[lev], wgmax);
   if (staged) {
-    const uint32_t total = lbase[HB_MAX_NB];
+    // byte offsets inside the level's record region fit 32 bits (umhs_hashgrid_bwd_workspace_bytes): scalar base + 32-bit offset stores
+    char* const ob = reinterpret_cast<char*>(out);
+#ifdef HB_ABL_NOWRITEOUT
+    const uint32_t total = 0;
+#else
+    const uint32_t total = ltotal;
+#endif
     for (uint32_t i = tid; i < total; i += 256) {
       const uint4 r = stage[i];
-      const uint32_t b = (r.w >> 17) & 127u;
-      out[base[b] + (i - lbase[b])] = r;
+      const uint32_t b = __builtin_amdgcn_ubfe(r.w, (uint32_t)bb, (uint32_t)(24 - bb));
+#ifdef HB_ABL_NOSTORE
+      asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(delta[b] + i));
+#else
+      *reinterpret_cast<uint4*>(ob + (size_t)((delta[b] + i) << 4)) = r;
+#endif
     }
   }
   HG_STAMP_DRAIN(7);
   HG_STAMP_FLUSH(0, l);
 }
 
-// Scatter pass: one workgroup per run of samples.  Histogram pass: gridDim.x workgroups per level walk the runs -- a caller that
-// hides the pass under other kernels (umhs_hashgrid_bwd_prepare on a side stream) launches few, so that it takes a small, steady
-// share of the CUs instead of flooding the dispatcher in front of the kernels it overlaps with.
-#ifndef HB_XCD_REMAP
-#define HB_XCD_REMAP 1
-#endif
+// Scatter pass: PERSISTENT workgroups, gridDim.x (a multiple of 8) per level; each walks its runs of samples with the next run's
+// inputs in flight (hb_load above).  Which runs: workgroups go to the 8 XCDs round-robin by their linear index, and the runs wg,
+// wg + 1 write ADJACENT record runs in every bucket (short ones on the coarse levels: most 128-byte lines of the record stream are
+// shared by neighbouring runs) -- XCD x takes the CONTIGUOUS runs [x * per, (x + 1) * per) and its workgroups interleave inside
+// that range, so that neighbouring runs are written through the same L2 at about the same time and their partial lines combine
+// there (tools/mb_scatter_store.hip: 16-byte pieces 3.3 vs 1.3 TB/s, 32-byte 5.7 vs 2.7).
+// Histogram pass: gridDim.x workgroups per level walk the runs -- a caller that hides the pass under other kernels
+// (umhs_hashgrid_bwd_prepare on a side stream) launches few, so that it takes a small, steady share of the CUs instead of flooding
+// the dispatcher in front of the kernels it overlaps with.
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void hg_partition_kernel(HbArgs a) {
+  const int lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
+  const float s = a.scalings[l];
+  __shared__ uint32_t wgmax;
+  HbIn cur;
+  if (threadIdx.x == 0) wgmax = 0;  // (ordered before its first use by the barrier inside the body)
   if (SCATTER) {
-#if HB_XCD_REMAP
-    // Workgroups go to the 8 XCDs round-robin by their linear index, and the runs wg, wg + 1 write ADJACENT record runs in every
-    // bucket -- short ones on the coarse levels, so most 128-byte lines of the record stream are shared by neighbouring workgroups.
-    // With neighbours on different XCDs each partial line is written back by its own L2 and merged at the memory side (a
-    // read-modify-write under ECC); XCD x therefore takes the CONTIGUOUS runs [x * per, (x + 1) * per): neighbours share an L2,
-    // their partial lines combine there.  (gridDim.x = 8 * per.)
-    const int per = (int)(gridDim.x >> 3), wg = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-    if (wg >= a.nwg) return;
-    hg_partition_body<true>(a, wg);
-#else
-    if ((int)blockIdx.x >= a.nwg) return;
-    hg_partition_body<true>(a, (int)blockIdx.x);
-#endif
+    const int per = (a.nwg + 7) >> 3, q = (int)(gridDim.x >> 3);  // runs per XCD, workgroups per XCD (and level)
+    const int x = (int)(blockIdx.x & 7u), end = min(a.nwg, (x + 1) * per);
+    int wg = x * per + (int)(blockIdx.x >> 3);
+    const uint32_t lmax0 = a.lmax[(size_t)lev * HB_LMAX_PARTS];
+    if (wg >= end) return;
+    hb_load<true>(a, wg, lev, l, cur);
+    if (lmax0 == HB_POISON) return;  // (uniform) the level's records do not fit its region: hg_reduce writes NaN
+    while (true) {
+      const int nxt = wg + q;
+      HbIn nx;
+      if (nxt < end) hb_load<true>(a, nxt, lev, l, nx);  // (uniform branch)
+      hg_partition_body<true>(a, wg, lev, l, s, cur, wgmax);
+      if (nxt >= end) break;
+      cur = nx, wg = nxt;
+      __syncthreads();  // the write-out of this run has read the staged records before the next run's placement overwrites them
+    }
+    __syncthreads();
+    // a plain store into the workgroup's own word (hg_scan zeroed them): no atomic, nothing shared
+    if (threadIdx.x == 0 && wgmax) a.lmax[(size_t)lev * HB_LMAX_PARTS + (blockIdx.x % HB_LMAX_PARTS)] = wgmax;
   } else {
     for (int wg = blockIdx.x; wg < a.nwg; wg += gridDim.x) {
-      hg_partition_body<false>(a, wg);
+      hb_load<false>(a, wg, lev, l, cur);
+      hg_partition_body<false>(a, wg, lev, l, s, cur, wgmax);
       __syncthreads();  // (the histogram is zeroed again at the top of the next run)
     }
   }
@@ -550,7 +674,7 @@ __global__ void hg_scan_kernel(HbArgs a) {
     if (b < a.nb) a.offsets[lev * a.nb + b] = carry + incl - c;
     carry += __shfl(incl, 63, 64);
   }
-  if (lane == 0) a.lmax[lev] = carry > a.cap ? HB_POISON : 0u;
+  a.lmax[(size_t)lev * HB_LMAX_PARTS + lane] = (lane == 0 && carry > a.cap) ? HB_POISON : 0u;  // (64 lanes = HB_LMAX_PARTS words)
 }
 
 __device__ __forceinline__ unsigned long long hb_fixed(const float v, const int k) { return (unsigned long long)__float2ll_rn(ldexpf(v, k)); }
@@ -571,7 +695,8 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
   };
   // epilogue of every path: the slab's gradient (+ its Adam step) as float4 lanes; the optimizer operands of a thread's (up to)
   // four chunks are requested before anything is computed -- three loads in flight per chunk, not three per thread
-  const uint32_t lmax_bits = a.lmax[lev];
+  // the level's max |value| = max over its scatter workgroups' words (one word per lane, L2 hits; every wave computes it for itself)
+  const uint32_t lmax_bits = wave_max_u32_dpp(a.lmax[(size_t)lev * HB_LMAX_PARTS + (tid & 63)]);
   // a non-finite gradient reached this level: the slabs its records land in are NaN, as after the reference's index_add; a level
   // whose records did not fit its region (HB_POISON) is NaN everywhere
   const bool nan_level = lmax_bits >= 0x7f800000u && (cnt != 0 || lmax_bits == HB_POISON);
@@ -592,7 +717,7 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
     const uint32_t lowmask = (1u << a.bucket_bits) - 1u;
     auto add = [&](const uint4& r) {
       const float vx = __uint_as_float(r.x), vy = __uint_as_float(r.y), ox = __uint_as_float(r.z);
-      const uint32_t s = r.w & lowmask, kk = (r.w >> 13) & 15u;
+      const uint32_t s = r.w & lowmask, kk = (r.w >> 24) & 15u;
       const float rx = 1.0f - ox;
       atomicAdd(&ut[2 * s], hb_fixed(vx * rx, kfix)), atomicAdd(&ut[2 * s + 1], hb_fixed(vy * rx, kfix));
       if (kk != 15u) {
@@ -602,13 +727,21 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
     };
     uint32_t i = tid;
     HG_STAMP(0);
-    for (; i + 3072 < cnt; i += 4096) {  // 4 records in flight per thread
-      const uint4 r0 = rp[i], r1 = rp[i + 1024], r2 = rp[i + 2048], r3 = rp[i + 3072];
+    // 4 records per thread and batch, the NEXT batch requested before this one is accumulated (every record slot past the end
+    // re-reads the bucket's last record and is dropped: unconditional loads stay batched)
+    const uint32_t last = cnt - 1;
+    uint4 r0 = rp[min(i, last)], r1 = rp[min(i + 1024, last)], r2 = rp[min(i + 2048, last)], r3 = rp[min(i + 3072, last)];
+    for (; i < cnt; i += 4096) {
+      const uint32_t j = i + 4096;
       HG_STAMP_DRAIN(1);
-      add(r0), add(r1), add(r2), add(r3);
+      const uint4 n0 = rp[min(j, last)], n1 = rp[min(j + 1024, last)], n2 = rp[min(j + 2048, last)], n3 = rp[min(j + 3072, last)];
+      add(r0);
+      if (i + 1024 < cnt) add(r1);
+      if (i + 2048 < cnt) add(r2);
+      if (i + 3072 < cnt) add(r3);
+      r0 = n0, r1 = n1, r2 = n2, r3 = n3;
       HG_STAMP(3);
     }
-    for (; i < cnt; i += 1024) add(rp[i]);
     HG_STAMP_DRAIN(3);
     __syncthreads();
     HG_STAMP(4);
@@ -654,18 +787,33 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
   HG_STAMP_FLUSH(1, l);
 }
 
+static inline int hb_scatter_wgs() {  // workgroups per level of the scatter pass (a multiple of 8); UMHS_HB_WGS: measurement knob
+  static const int v = [] {
+    const char* e = getenv("UMHS_HB_WGS");
+    int w = e ? atoi(e) : 64;
+    w = (w + 7) / 8 * 8;
+    return w < 8 ? 8 : w;
+  }();
+  return v;
+}
+
 static inline int hb_bucket_bits(int log2_T) { return log2_T < HB_BUCKET_BITS ? log2_T : HB_BUCKET_BITS; }
 
 static inline size_t hb_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// records per level: HB_CAP_PER_SAMPLE per sample, a multiple of 8 (the level regions start on 128-byte lines)
+static inline size_t hb_cap(int64_t n, size_t nwg, int nb) {
+  (void)nwg, (void)nb;
+  return ((size_t)n * HB_CAP_PER_SAMPLE + 7) & ~(size_t)7;
+}
 
 extern "C" size_t umhs_hashgrid_bwd_workspace_bytes(int64_t n, int n_levels, int log2_T) {
   if (n <= 0 || n_levels < 1 || log2_T < 2) return 0;
   const int nb = 1 << (log2_T - hb_bucket_bits(log2_T));
   if (nb > HB_MAX_NB) return 0;  // larger tables: only the atomic path is available
-  if ((size_t)n * HB_CAP_PER_SAMPLE >= ((size_t)1 << 32)) return 0;  // record indices inside a level are 32-bit
-  const size_t m = (size_t)n_levels * nb, cap = (size_t)n * HB_CAP_PER_SAMPLE;
   const size_t nwg = (size_t)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
-  return 256 + hb_align((2 * m + 64) * 4) + 2 * hb_align((size_t)n_levels * nwg * nb * 4) + hb_align((size_t)n_levels * cap * 16);
+  const size_t m = (size_t)n_levels * nb, cap = hb_cap(n, nwg, nb);
+  if (cap >= ((size_t)1 << 28)) return 0;  // byte offsets inside a level's record region are 32-bit (53 M samples per call)
+  return 256 + hb_align((2 * m + (size_t)n_levels * HB_LMAX_PARTS) * 4) + 2 * hb_align((size_t)n_levels * nwg * nb * 4) + hb_align((size_t)n_levels * cap * 16);
 }
 
 static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t n, int ws_begin, int ws_levels, int log2_T,
@@ -714,11 +862,11 @@ static int hb_args(HbArgs* a, const float* pos01, const float* scalings, int64_t
   a->nlev = ws_levels, a->lev_off = 0, a->overwrite = 0, a->grad_mask = 0;
   a->adam = HbAdam{};
   const size_t m = (size_t)ws_levels * a->nb;
-  a->cap = (uint32_t)((size_t)n * HB_CAP_PER_SAMPLE);
+  a->nwg = (int)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
+  a->cap = (uint32_t)hb_cap(n, (size_t)a->nwg, a->nb);
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
   a->counts = reinterpret_cast<uint32_t*>(p), a->offsets = a->counts + m, a->lmax = a->offsets + m;
-  p += hb_align((2 * m + 64) * 4);
-  a->nwg = (int)((n + 256 * HB_SPT - 1) / (256 * HB_SPT));
+  p += hb_align((2 * m + (size_t)ws_levels * HB_LMAX_PARTS) * 4);
   a->wg_counts = reinterpret_cast<uint32_t*>(p);
   p += hb_align((size_t)ws_levels * a->nwg * a->nb * 4);
   a->wg_prefix = reinterpret_cast<uint32_t*>(p);
@@ -743,7 +891,11 @@ static int hb_run_prepare(const HbArgs& a, int n_levels, int count_wgs, umhs_str
 
 static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stream_t stream) {  // scatter + bucket reduce
   if (!a.d_enc || !d_table || !a.pos01 || !a.scalings) return UMHS_ERR_ARG;  // every pointer the two kernels dereference
-  dim3 pgrid((unsigned)(((a.nwg + 7) / 8) * 8), (unsigned)n_levels);  // (a multiple of 8: hg_partition_kernel's XCD mapping)
+  // persistent workgroups: 8 per XCD and level = 64 per level (16 levels x 64 = the 1024 workgroups 256 CUs hold at four each)
+  int per_level = hb_scatter_wgs();
+  if (per_level > HB_LMAX_PARTS) per_level = HB_LMAX_PARTS;  // (one max-|value| word per workgroup and level)
+  if (per_level > ((a.nwg + 7) / 8) * 8) per_level = ((a.nwg + 7) / 8) * 8;
+  dim3 pgrid((unsigned)per_level, (unsigned)n_levels);
   hipLaunchKernelGGL(hg_partition_kernel<true>, pgrid, dim3(256), 0, umhs_s(stream), a);
   const size_t lds = (size_t)(2 << a.bucket_bits) * 8;
   {  // raise the dynamic-LDS limit once per device, not per call (the driver call is a bubble in front of the launch)
