@@ -425,7 +425,9 @@ def measure(case, timer, steps, warmup, world, device):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dom_live = timer.summary()
     timer.records.clear()
-    return float(tmax[0].item()), float(tmax[1].item()), dom_live, outputs, loss_dict
+    if np.max(per_step_ms) > 3 * np.median(per_step_ms):  # a stall inside the timed region: say where (stderr; the line carries max + median)
+        print(f"[bench] {case.name}: slow step(s) in the timed region, ms per step = {[round(t, 3) for t in per_step_ms]}", file=sys.stderr, flush=True)
+    return float(tmax[0].item()), float(tmax[1].item()), dom_live, outputs, loss_dict, float(np.max(per_step_ms))
 
 
 def breakdown(case, timer, steps):
@@ -517,13 +519,14 @@ def other_config(name, device, timer, steps=20, warmup=10):
     """The other single-GPU BASELINE shapes through the same measurement, on the driver's line: C3 = configs[2]
     (scripts/cbox_dragon.sh:3-9, 128 bands, 8192 rays, 1 GPU), C4 = one GPU's 8192-ray shard of configs[3], C5 = configs[4]'s shard."""
     case = Case(name, device, 1, 0, 0)
-    dt, median_ms, dom_live, outputs, loss_dict = measure(case, timer, steps, warmup, 1, device)
+    dt, median_ms, dom_live, outputs, loss_dict, worst_ms = measure(case, timer, steps, warmup, 1, device)
     ksum = breakdown(case, timer, 5)
     ksum.update(dom_live)
     dom = next(iter(dom_live)) if dom_live else None
     kern, roof, _ = roofline_tables(case, ksum, dom, 1, name)
     out = dict(workload=case.cfg["workload"], rays=case.R, samples_per_ray=case.S, bands=case.B, endmembers=case.Cn,
-               ms_per_step=round(dt / steps * 1e3, 4), ms_per_step_median=round(median_ms, 4), rays_per_s=round(case.R * steps / dt, 1),
+               ms_per_step=round(dt / steps * 1e3, 4), ms_per_step_median=round(median_ms, 4), ms_per_step_max=round(worst_ms, 4),
+               rays_per_s=round(case.R * steps / dt, 1),
                steps=steps, warmup=warmup, roofline=roof, kernels_ms=kern,
                spectral_psnr_db_vs_uniform_random_gt=round(float(case.pipe.model.psnr(outputs["spectral"].detach(), case.b["gt_spectral"])), 3))
     del case
@@ -578,11 +581,11 @@ def main():
     def gc_cb(phase, info, _t=[0.0]):  # every pass of Python's cycle collector during the measurement, with its length
         if phase == "start":
             _t[0] = time.perf_counter()
-        else:
-            pauses.append((info.get("generation"), round((time.perf_counter() - _t[0]) * 1e3, 3)))
+        else:  # (frozen = after measure()'s own deliberate collect + freeze, i.e. inside the timed region or the breakdown pass)
+            pauses.append({"generation": info.get("generation"), "ms": round((time.perf_counter() - _t[0]) * 1e3, 3), "frozen": gc.get_freeze_count() > 0})
 
     gc.callbacks.append(gc_cb)
-    dt, median_ms, dom_live, outputs, loss_dict = measure(case, timer, args.steps, args.warmup, world, device)
+    dt, median_ms, dom_live, outputs, loss_dict, worst_ms = measure(case, timer, args.steps, args.warmup, world, device)
     exchanged = {k: v for k, v in parallel.STATS.items()}
     ksum_all = breakdown(case, timer, min(args.steps, 10))  # (all ranks: the step contains the collectives)
     gc.callbacks.remove(gc_cb)
@@ -622,7 +625,7 @@ def main():
             "metric": f"train rays/sec (hotdog-shaped 31-band, C2)" if args.config == "C2" else f"train rays/sec ({args.config})",
             "value": round(R * world * args.steps / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "ms_per_step_median": round(median_ms, 4),
+            "ms_per_step_median": round(median_ms, 4), "ms_per_step_max": round(worst_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "arithmetic": "fp32 storage and accumulation; MLP chains (forward, recompute, dX) as three-piece bf16 products on the bf16 MFMA "
                           "(24 significant bits, fp32 accumulate); dW operands as two bf16 pieces x three products (2^-16 per product, "
@@ -637,7 +640,7 @@ def main():
             "kernels_ms_note": "median over the launches of an untimed pass with an event pair around every operator (the dominant one: inside "
                                "the timed region); kernels_ms_max = the slowest launch of each",
             "kernels_ms_max": {k: round(v[3], 4) for k, v in ksum.items()},
-            "host_gc_pauses_ms": [p for p in pauses if p[1] >= 1.0],
+            "host_gc_pauses": [p for p in pauses if p["ms"] >= 1.0],
             "roofline": roof, "rooflines": rooflines, "csrc_sha": csrc_hash(),
         }
         if dist_info is not None:

@@ -3,7 +3,7 @@
 -DUMHS_HG_STAMP into tools/_alt/libumhs_hgstamp.so (CPU box: `python tools/stamp_hg.py build`), then on the GPU box runs the apply
 half on the bench batch's positions (C2 / C5 sample counts) and prints, per level group, the cycles EVERY wave spent between
 consecutive stamps (s_memtime pinned by scheduling barriers; "drain" stamps wait for the wave's vector-memory operations first).
-The stamped build forbids the overlaps the product has: read its SHARES.  `--json path` also writes the table."""
+The stamped build forbids the overlaps the product has: read its SHARES.  `--json DIR` also writes DIR/hg_stamps_<case>.json."""
 import ctypes, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "unsupervised-hyperspectral-nerf_amd")
@@ -32,7 +32,7 @@ lib = _hip.lib()
 lib.umhs_debug_hg_stamps.argtypes = [ctypes.c_void_p]
 import bench
 dev = torch.device("cuda", 0)
-PH = {0: ["prologue: zero hist, fetch counts/prefix, bucket prefix (wave 0), barrier", "input loads (gradient, position) until arrived", "hash + cell key",
+PH = {0: ["prologue: bucket prefix of the run (wave 0, DPP scan), barrier", "inputs (prefetched a run ahead) until arrived", "hash + cell key",
           "DPP run merge (8 corner sums when the wave merges)", "records + LDS placement (1 atomic + 1 b128 write per record)", "wave max", "barrier",
           "record write-out (1 b128 LDS read + 1 dwordx4 store per record) until stored"],
       1: ["prologue: counts, tile zero, barrier", "record loads (dwordx4) until arrived", "-", "corner values + fixed-point conversion + LDS 64-bit atomics until done",
@@ -79,8 +79,11 @@ for name in os.environ.get("CASES", "C2,C5").split(","):
                 ent["phases"][label] = {"cycles_per_wave": round(c / waves, 1), "share": round(c / max(tot, 1), 4)}
                 print(f"    {label:72s} {c / waves:9.0f}  {100.0 * c / max(tot, 1):5.1f} %")
             res[name][kname][gname] = ent
-if "--json" in sys.argv:
-    path = sys.argv[sys.argv.index("--json") + 1]
-    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    with open(path, "w") as f:
-        json.dump(res, f, indent=1)
+if "--json" in sys.argv:  # --json DIR: one file per case, DIR/hg_stamps_<case>.json
+    d = sys.argv[sys.argv.index("--json") + 1]
+    os.makedirs(d, exist_ok=True)
+    for name, r in res.items():
+        with open(os.path.join(d, f"hg_stamps_{name}.json"), "w") as f:
+            json.dump({"case": name, "csrc_sha": bench.csrc_hash(), "note": "cycles per wave and run of 512 samples (scatter) / per wave (reduce) between "
+                       "s_memtime stamps of the -DUMHS_HG_STAMP build, mean over the waves of the level group; 'until ...' phases drain the wave's "
+                       "vector-memory operations first.  The stamped build forbids the product's overlaps: read shares, not lengths.", **r}, f, indent=1)

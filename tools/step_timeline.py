@@ -2,7 +2,7 @@
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("adam_kernel", "adam_rows_range_kernel"))]  # the last launch of a step
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 a, b = idx[k], idx[k + 1]
 t0 = int(rows[a]["End_Timestamp"])
