@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 8
+#define UMHS_ABI_VERSION 9
 
 enum {
   UMHS_OK = 0,
@@ -219,6 +219,28 @@ int umhs_field_bwd_composited(const umhs_field_cfg* cfg, const umhs_field_params
 /* builds the transposed packs + forward image ahead of time (parameters only): then pass packs_ready = 1, same workspace */
 int umhs_field_bwd_prepare(const umhs_field_cfg* cfg, const umhs_field_params* params, void* workspace,
                            size_t workspace_bytes, umhs_stream_t stream);
+
+/* ---- method="rgb" (the reference's default method, umhs_field.py:280-294 = nerfstudio NerfactoField; BASELINE configs[0]) ---------- */
+/* The two MLPs of the rgb field as gfx950 kernels (exact fp32 MFMA), replacing the torch.nn.functional.linear calls of rounds 1-3.     */
+/*   base: hash features enc [N,32] (sample-major) -> 64 ReLU -> 16: density = trunc_exp(out0) * selector (selector NULL: 1),           */
+/*         emb = out1..15 [N,15] (NULL: not written), sigma_raw = out0 [N] (NULL: not written)        -- mlp_base, umhs_field.py:51,320-327 */
+/*   head: [SHEncoding(levels=4)((directions + 1) / 2) | emb15] -> 64 ReLU -> 64 ReLU -> 3, Sigmoid -> rgb [N,3]   -- NerfactoField.mlp_head */
+/* Weights in torch.nn.Linear layout ([out][in] row-major, bias [out]).  The backward entries recompute the forward, write the input     */
+/* gradient (d_enc [N,32] / d_emb [N,15]) and the parameter gradients (accumulate != 0: += ), bitwise reproducibly; workspace:           */
+/* umhs_rgb_mlp_bwd_workspace_bytes(head, n), 16-byte aligned.  n == 0: no-op.                                                          */
+size_t umhs_rgb_mlp_bwd_workspace_bytes(int head, int64_t n);
+int umhs_rgb_base_fwd(const float* enc, const float* selector, const float* w0, const float* b0, const float* w1, const float* b1,
+                      int64_t n, float* density, float* emb, float* sigma_raw, umhs_stream_t stream);
+int umhs_rgb_head_fwd(const float* directions, const float* emb, const float* w0, const float* b0, const float* w1, const float* b1,
+                      const float* w2, const float* b2, int64_t n, float* rgb, umhs_stream_t stream);
+int umhs_rgb_base_bwd(const float* enc, const float* selector, const float* w0, const float* b0, const float* w1, const float* b1,
+                      const float* d_density, const float* d_emb, int64_t n, float* d_enc, float* d_w0, float* d_b0, float* d_w1,
+                      float* d_b1, int accumulate, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
+int umhs_rgb_head_bwd(const float* directions, const float* emb, const float* w0, const float* b0, const float* w1, const float* b1,
+                      const float* w2, const float* b2, const float* d_rgb, int64_t n, float* d_emb, float* d_w0, float* d_b0,
+                      float* d_w1, float* d_b1, float* d_w2, float* d_b2, int accumulate, void* workspace, size_t workspace_bytes,
+                      umhs_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------ */
 /* R11: packed transmittance/weights.  Replaces nerfacc.pack_info + render_weight_from_density, */

@@ -147,3 +147,62 @@ def test_a_batch_without_surviving_samples_renders_the_background():
     enc = ops.hashgrid_fwd(torch.zeros(0, 3, device=DEV), m.field.layout.view(m.field.flat.detach(), "mlp_base.encoder.hash_table"),
                            m.field.scalings, m.field.layout.log2_hashmap_size, level_major=False)
     assert enc.shape[0] == 0
+
+
+def test_the_rgb_mlp_kernels_alone_against_the_oracle_with_clamped_trunc_exp():
+    """csrc/umhs_rgb.hip by itself (no library GEMM in the rgb field): mlp_base with trunc_exp (incl. pre-activations
+    beyond +-15, where the backward clamps) and the SH + mlp_head + sigmoid kernel, outputs and every gradient against the oracle's
+    autograd on the same numbers; tail tiles (N not a multiple of 16 or 64), bitwise run-to-run reproducibility of the gradients."""
+    from umhsnerf import ops
+
+    g = torch.Generator().manual_seed(5)
+    N = 1000 + 13
+    enc = (torch.rand(N, 32, generator=g) - 0.5)
+    sel = (torch.rand(N, generator=g) > 0.1).float()
+    w0, b0 = torch.randn(64, 32, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1
+    w1, b1 = torch.randn(16, 64, generator=g) * 0.3, torch.randn(16, generator=g) * 0.1
+    b1[0] = 2.0
+    w1[0] *= 14.0  # sigma_raw spreads beyond +-15 on part of the samples (|z| up to ~45)
+    d_density, d_emb = torch.randn(N, generator=g), torch.randn(N, 15, generator=g)
+
+    def ref(enc_, w0_, b0_, w1_, b1_):
+        h = T.mlp_forward(enc_, [w0_, w1_], [b0_, b1_])
+        return T.trunc_exp(h[:, 0]) * sel, h[:, 1:]
+
+    leaves = [t.clone().requires_grad_() for t in (enc, w0, b0, w1, b1)]
+    dens_r, emb_r = ref(*leaves)
+    assert float((T.mlp_forward(enc, [w0, w1], [b0, b1])[:, 0].abs() > 15).float().mean()) > 0.02
+    grads_r = torch.autograd.grad([dens_r, emb_r], leaves, [d_density, d_emb])
+    dl = [t.to(DEV).requires_grad_() for t in (enc, w0, b0, w1, b1)]
+    dens, emb = ops.RgbBaseFn.apply(dl[0], sel.to(DEV), *dl[1:])
+    assert_close("rgb base density", dens, dens_r.detach(), 1e-4)  # (exp of pre-activations up to ~40: 1e-6 of the argument is 4e-5 of the value)
+    assert_close("rgb base emb", emb, emb_r.detach(), 2e-5)
+    grads = torch.autograd.grad([dens, emb], dl, [d_density.to(DEV), d_emb.to(DEV)])
+    for name, a, b in zip(("d_enc", "d_w0", "d_b0", "d_w1", "d_b1"), grads, grads_r):
+        assert_close(f"rgb base {name}", a, b, 5e-5)
+    again = torch.autograd.grad(ops.RgbBaseFn.apply(dl[0], sel.to(DEV), *dl[1:]), dl, [d_density.to(DEV), d_emb.to(DEV)])
+    assert all(torch.equal(a, b) for a, b in zip(grads, again)), "the slab reduce sums in a fixed order"
+    # trunc_exp's backward below -15 on its own (an unclamped exp(x) would give gradients e^-25 instead of e^-15 there)
+    raw = T.mlp_forward(enc, [w0, w1], [b0, b1])[:, 0]
+    low = ((raw < -16) & (sel > 0)).float()
+    assert float(low.sum()) >= 5
+    g_low_r = torch.autograd.grad(ref(*leaves)[0], leaves[0], d_density * low)[0]
+    g_low = torch.autograd.grad(ops.RgbBaseFn.apply(dl[0], sel.to(DEV), *dl[1:])[0], dl[0], (d_density * low).to(DEV))[0]
+    assert_close("rgb base d_enc through the clamp", g_low, g_low_r, 5e-5)
+    assert float(g_low_r.abs().max()) > 1e-9
+
+    dirs = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    embs = torch.randn(N, 15, generator=g) * 0.5
+    hw = [torch.randn(64, 31, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1, torch.randn(64, 64, generator=g) * 0.2,
+          torch.randn(64, generator=g) * 0.1, torch.randn(3, 64, generator=g) * 0.3, torch.randn(3, generator=g) * 0.1]
+    d_rgb = torch.randn(N, 3, generator=g)
+    hl = [t.clone().requires_grad_() for t in [embs] + hw]
+    x = torch.cat([T.sh_encoding_deg4((dirs + 1.0) / 2.0), hl[0]], dim=-1)
+    rgb_r = torch.sigmoid(T.mlp_forward(x, [hl[1], hl[3], hl[5]], [hl[2], hl[4], hl[6]]))
+    gr = torch.autograd.grad(rgb_r, hl, d_rgb)
+    hd = [t.to(DEV).requires_grad_() for t in [embs] + hw]
+    rgb = ops.RgbHeadFn.apply(dirs.to(DEV), *hd)
+    assert_elementwise("rgb head", rgb, rgb_r.detach(), rtol=2e-5, atol=1e-6)
+    gh = torch.autograd.grad(rgb, hd, d_rgb.to(DEV))
+    for name, a, b in zip(("d_emb", "d_w0", "d_b0", "d_w1", "d_b1", "d_w2", "d_b2"), gh, gr):
+        assert_close(f"rgb head {name}", a, b, 5e-5)

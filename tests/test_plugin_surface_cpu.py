@@ -320,23 +320,16 @@ def test_deposited_gradient_follows_the_trainers_loss_scale():
 
 
 def test_rgb_field_host_side_pieces_match_the_oracle():
-    """umhs_field_rgb.py's torch pieces (no HIP call): SHEncoding(levels=4) on (d+1)/2 and trunc_exp's clamped gradient against the oracle's
-    restatement, and the flat layout's segments (16-byte aligned, the reference's key names for method="rgb")."""
+    """umhs_field_rgb.py without a HIP call: the flat layout's segments (16-byte aligned, the reference's key names for method="rgb"),
+    and -- since round 4 -- that the module holds no torch arithmetic of its own any more (SH, trunc_exp and the MLPs are
+    csrc/umhs_rgb.hip, compared with the oracle on the GPU by tests/test_hip_rgb_method.py)."""
+    import inspect
+
     from oracle import torch_ref as T
     from umhsnerf import umhs_field_rgb as F
 
-    g = torch.Generator().manual_seed(0)
-    d = torch.nn.functional.normalize(torch.randn(257, 3, generator=g), dim=-1)
-    dn = (d + 1.0) / 2.0
-    torch.testing.assert_close(F.sh_components_deg4(dn), T.sh_encoding_deg4(dn), rtol=0, atol=1e-7)
-    x = torch.tensor([-20.0, -3.0, 0.0, 3.0, 14.9, 15.0, 20.0], requires_grad=True)
-    y = F._TruncExp.apply(x)
-    y.backward(torch.ones_like(y))
-    xr = x.detach().clone().requires_grad_()
-    yr = T.trunc_exp(xr)
-    yr.backward(torch.ones_like(yr))
-    assert torch.equal(y.detach(), yr.detach()) and torch.equal(x.grad, xr.grad)
-    assert float(x.grad[-1]) == float(torch.exp(torch.tensor(15.0))) and float(x.grad[0]) == float(torch.exp(torch.tensor(-15.0)))
+    src = inspect.getsource(F)
+    assert "functional.linear" not in src.split('"""', 2)[2] and not hasattr(F, "_TruncExp") and not hasattr(F, "sh_components_deg4")
     L = F.RGBLayout(10)
     assert list(L.entries)[0] == "mlp_base.encoder.hash_table" and L.entries["mlp_head.layers.0.weight"][1] == (64, 31)
     assert all(off % 4 == 0 for off, _ in L.entries.values()) and L.total % 4 == 0

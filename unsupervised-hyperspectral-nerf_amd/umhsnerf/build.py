@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libumhs_hip.so")
-SOURCES = ("umhs_kernels.hip", "umhs_field.hip", "umhs_sampler.hip", "umhs_data.hip", "umhs_metrics.hip")
+SOURCES = ("umhs_kernels.hip", "umhs_field.hip", "umhs_sampler.hip", "umhs_data.hip", "umhs_metrics.hip", "umhs_rgb.hip")
 # umhs_field.hip compiles as four translation units side by side (its header comment): object suffix -> extra defines
 UNITS = {"umhs_field.hip": (("_p0", ["-DUMHS_FIELD_TU=1", "-Wno-unused-function"]), ("_p1", ["-DUMHS_FIELD_TU=2", "-Wno-unused-function"]),
                             ("_p0f", ["-DUMHS_FIELD_TU=3", "-Wno-unused-function"]), ("", ["-DUMHS_FIELD_TU=0"]))}

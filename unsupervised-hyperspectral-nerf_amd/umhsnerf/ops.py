@@ -705,6 +705,84 @@ def adam_step_rows_range(p, g, m, v, rows, begin: int, end: int, step: int, lr: 
 
 
 # --------------------------------------------------------------------------------------------- #
+# method="rgb": the two MLPs of NerfactoField as HIP kernels (csrc/umhs_rgb.hip)
+# --------------------------------------------------------------------------------------------- #
+def rgb_base_fwd(enc, sel, w0, b0, w1, b1, want_emb: bool = True, want_raw: bool = False):
+    """mlp_base of the rgb field: enc [N,32] (sample-major) -> (density [N] = trunc_exp(out0) * sel, emb [N,15] | None, sigma_raw [N] | None)."""
+    n = enc.shape[0]
+    new = lambda *shp: torch.empty(shp, device=enc.device, dtype=torch.float32)
+    density, emb, raw = new(n), (new(n, 15) if want_emb else None), (new(n) if want_raw else None)
+    _hip.check(_hip.lib().umhs_rgb_base_fwd(ptr(enc), ptr(sel), ptr(w0), ptr(b0), ptr(w1), ptr(b1), n, ptr(density), ptr(emb), ptr(raw),
+                                            _hip.stream()), "umhs_rgb_base_fwd")
+    return density, emb, raw
+
+
+def rgb_head_fwd(dirs, emb, w0, b0, w1, b1, w2, b2):
+    """NerfactoField.mlp_head: [SH16((d + 1) / 2) | emb15] -> 64 -> 64 -> 3, sigmoid -> rgb [N,3]."""
+    n = dirs.shape[0]
+    rgb = torch.empty((n, 3), device=dirs.device, dtype=torch.float32)
+    _hip.check(_hip.lib().umhs_rgb_head_fwd(ptr(dirs), ptr(emb), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), n, ptr(rgb),
+                                            _hip.stream()), "umhs_rgb_head_fwd")
+    return rgb
+
+
+class RgbBaseFn(torch.autograd.Function):
+    """(enc [N,32], sel [N], w0, b0, w1, b1) -> (density [N], emb [N,15]); backward recomputes the forward inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, enc, sel, w0, b0, w1, b1):
+        enc, sel = enc.contiguous(), sel.contiguous()
+        w = [t.detach().contiguous() for t in (w0, b0, w1, b1)]
+        density, emb, _ = rgb_base_fwd(enc, sel, *w)
+        ctx.save_for_backward(enc, sel, *w)
+        return density, emb
+
+    @staticmethod
+    def backward(ctx, d_density, d_emb):
+        enc, sel, w0, b0, w1, b1 = ctx.saved_tensors
+        n = enc.shape[0]
+        d_enc = torch.empty_like(enc)
+        g = [torch.empty_like(t) for t in (w0, b0, w1, b1)]
+        if n == 0:
+            return (d_enc, None, *[t.zero_() for t in g])
+        dd = d_density.contiguous().float() if d_density is not None else None
+        de = d_emb.contiguous().float() if d_emb is not None else None
+        if dd is None and de is None:
+            dd = torch.zeros(n, device=enc.device)
+        ws = _scratch(enc.device, "rgb_mlp_bwd", _hip.lib().umhs_rgb_mlp_bwd_workspace_bytes(0, n))
+        _hip.check(_hip.lib().umhs_rgb_base_bwd(ptr(enc), ptr(sel), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(dd), ptr(de), n, ptr(d_enc),
+                                                ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), 0, ptr(ws), ws.numel(), _hip.stream()),
+                   "umhs_rgb_base_bwd")
+        return (d_enc, None, *g)
+
+
+class RgbHeadFn(torch.autograd.Function):
+    """(directions [N,3], emb [N,15], w0, b0, w1, b1, w2, b2) -> rgb [N,3]."""
+
+    @staticmethod
+    def forward(ctx, dirs, emb, w0, b0, w1, b1, w2, b2):
+        dirs, emb = dirs.contiguous(), emb.contiguous()
+        w = [t.detach().contiguous() for t in (w0, b0, w1, b1, w2, b2)]
+        rgb = rgb_head_fwd(dirs, emb, *w)
+        ctx.save_for_backward(dirs, emb, *w)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        dirs, emb, w0, b0, w1, b1, w2, b2 = ctx.saved_tensors
+        n = dirs.shape[0]
+        d_emb = torch.empty_like(emb)
+        g = [torch.empty_like(t) for t in (w0, b0, w1, b1, w2, b2)]
+        if n == 0:
+            return (None, d_emb, *[t.zero_() for t in g])
+        dr = d_rgb.contiguous().float()
+        ws = _scratch(dirs.device, "rgb_mlp_bwd", _hip.lib().umhs_rgb_mlp_bwd_workspace_bytes(1, n))
+        _hip.check(_hip.lib().umhs_rgb_head_bwd(ptr(dirs), ptr(emb), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dr), n,
+                                                ptr(d_emb), *[ptr(t) for t in g], 0, ptr(ws), ws.numel(), _hip.stream()), "umhs_rgb_head_bwd")
+        return (None, d_emb, *g)
+
+
+# --------------------------------------------------------------------------------------------- #
 # autograd glue
 # --------------------------------------------------------------------------------------------- #
 class FieldFn(torch.autograd.Function):

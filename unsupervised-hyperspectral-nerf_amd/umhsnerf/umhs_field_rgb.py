@@ -5,11 +5,11 @@
 [upstream-recalled: nerfstudio 1.1.5 ``NerfactoField.__init__``; the appearance embedding has width 0 with the reference's default
 ``use_appearance_embedding=True``, umhs_model.py:181].  None of the spectral heads exists.
 
-This is NOT the hot path (SURVEY section 8 scopes the spectral methods), so it is built from what is there: positions / contraction,
-the hash-grid gather and its atomics-free backward, the sampler, the per-ray compositing and the fused Adam step are the HIP
-operators of the spectral path; the two small MLPs (32 -> 64 -> 16 and 31 -> 64 -> 64 -> 3) are five plain library GEMMs
-(``torch.nn.functional.linear`` = rocBLAS / hipBLASLt) under autograd.  No CPU fallback: every tensor lives on the GPU and the HIP
-library is required exactly as for the spectral methods.
+This is NOT the hot path (SURVEY section 8 scopes the spectral methods).  Positions / contraction, the hash-grid gather and its
+atomics-free backward, the sampler, the per-ray compositing and the fused Adam step are the HIP operators of the spectral path; the
+two small MLPs (32 -> 64 -> 16 with trunc_exp, and SH16 | emb15 -> 64 -> 64 -> 3 with the sigmoid) are the fp32-MFMA kernels of
+``csrc/umhs_rgb.hip`` (``ops.RgbBaseFn`` / ``ops.RgbHeadFn``): since round 4 no library GEMM and no torch elementwise kernel is left
+in this field.  No CPU fallback: the HIP library is required exactly as for the spectral methods.
 
 Parameters live in one flat fp32 buffer under the reference's state-dict key names, as in :class:`UMHSField`.
 """
@@ -25,20 +25,6 @@ from torch import Tensor, nn
 
 from . import ops
 from ._ns_compat import FieldHeadNames, RaySamples
-
-
-class _TruncExp(torch.autograd.Function):
-    """nerfstudio ``trunc_exp`` (umhs_field.py:17,327): exp forward, gradient g * exp(clamp(x, -15, 15))."""
-
-    @staticmethod
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.exp(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return g * torch.exp(x.clamp(-15, 15))
 
 
 class HashEncodeFn(torch.autograd.Function):
@@ -57,21 +43,6 @@ class HashEncodeFn(torch.autograd.Function):
         d_table = torch.zeros(ctx.table_shape, device=d_enc.device, dtype=torch.float32)
         ops.hashgrid_bwd(pos01, d_enc.contiguous().float(), scalings, ctx.log2_T, d_table, level_major=False)
         return d_table, None, None, None
-
-
-def sh_components_deg4(d: Tensor) -> Tensor:
-    """Real spherical harmonics up to degree 3 (16 components) of ``d`` [N,3] -- nerfstudio's ``SHEncoding(levels=4)`` torch path,
-    applied by the reference to ``(direction + 1) / 2`` WITHOUT mapping back to [-1, 1] (umhs_field.py:160-162)."""
-    x, y, z = d[..., 0], d[..., 1], d[..., 2]
-    xx, yy, zz = x * x, y * y, z * z
-    return torch.stack([
-        torch.full_like(x, 0.28209479177387814),
-        0.4886025119029199 * y, 0.4886025119029199 * z, 0.4886025119029199 * x,
-        1.0925484305920792 * x * y, 1.0925484305920792 * y * z, 0.9461746957575601 * zz - 0.31539156525251999,
-        1.0925484305920792 * x * z, 0.5462742152960396 * (xx - yy),
-        0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * x * y * z, 0.4570457994644658 * y * (5 * zz - 1),
-        0.3731763325901154 * z * (5 * zz - 3), 0.4570457994644658 * x * (5 * zz - 1), 1.445305721320277 * z * (xx - yy),
-        0.5900435899266435 * x * (xx - 3 * yy)], dim=-1)
 
 
 class RGBLayout:
@@ -163,20 +134,20 @@ class UMHSRGBField(nn.Module):
     def _geom(self):
         return SimpleNamespace(aabb=self._aabb_host, contraction=self.spatial_distortion is not None)
 
-    def _mlp(self, x: Tensor, prefix: str, n_layers: int) -> Tensor:
+    def _weights(self, prefix: str, n_layers: int, flat: Optional[Tensor] = None):
+        flat = self.flat if flat is None else flat
+        out = []
         for i in range(n_layers):
-            x = torch.nn.functional.linear(x, self.layout.view(self.flat, f"{prefix}.layers.{i}.weight"),
-                                           self.layout.view(self.flat, f"{prefix}.layers.{i}.bias"))
-            if i + 1 < n_layers:
-                x = torch.relu(x)
-        return x
+            out += [self.layout.view(flat, f"{prefix}.layers.{i}.weight"), self.layout.view(flat, f"{prefix}.layers.{i}.bias")]
+        return out
 
     def _density_from_pos01(self, pos01: Tensor, sel: Tensor) -> Tuple[Tensor, Tensor]:
+        """mlp_base: hash-grid gather (HashEncodeFn) -> 64 -> 16 with trunc_exp on output 0 and the selector product, all in
+        ``umhs_rgb_base_fwd`` / ``_bwd`` (average_init_density = 1, umhs_field.py:57)."""
         table = self.layout.view(self.flat, "mlp_base.encoder.hash_table")
         enc = HashEncodeFn.apply(table, pos01, self.scalings, self.layout.log2_hashmap_size)
-        h = self._mlp(enc, "mlp_base.mlp", 2)
-        density = _TruncExp.apply(h[:, :1]) * sel[:, None]  # average_init_density = 1 (umhs_field.py:57)
-        return density, h[:, 1:]
+        density, emb = ops.RgbBaseFn.apply(enc, sel, *self._weights("mlp_base.mlp", 2))
+        return density[:, None], emb
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
         fr = ray_samples.frustums
@@ -193,9 +164,9 @@ class UMHSRGBField(nn.Module):
             raise AttributeError("Camera indices are not provided.")
         dirs = ray_samples.frustums.directions
         shp = dirs.shape[:-1]
-        d = sh_components_deg4((dirs.reshape(-1, 3).float() + 1.0) / 2.0)  # get_normalized_directions, then the SH encoding
-        h = torch.cat([d, density_embedding.reshape(-1, self.geo_feat_dim)], dim=-1)
-        rgb = torch.sigmoid(self._mlp(h, "mlp_head", 3)).view(*shp, 3)
+        # get_normalized_directions + SHEncoding(levels=4) + cat + mlp_head + Sigmoid: one kernel (umhs_rgb_head_fwd)
+        rgb = ops.RgbHeadFn.apply(dirs.reshape(-1, 3).float(), density_embedding.reshape(-1, self.geo_feat_dim).float(),
+                                  *self._weights("mlp_head", 3)).view(*shp, 3)
         return {FieldHeadNames.RGB: rgb}
 
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[Any, Tensor]:
@@ -210,5 +181,8 @@ class UMHSRGBField(nn.Module):
         with torch.no_grad():
             p = positions.reshape(-1, 3).float().contiguous()
             _, pos01, sel = ops.positions_fwd(None, None, None, None, self._geom(), world_pos_in=p)
-            density, _ = self._density_from_pos01(pos01, sel)
+            flat = self.flat.detach()
+            enc = ops.hashgrid_fwd(pos01, self.layout.view(flat, "mlp_base.encoder.hash_table"), self.scalings, self.layout.log2_hashmap_size,
+                                   level_major=False)
+            density, _, _ = ops.rgb_base_fwd(enc, sel, *self._weights("mlp_base.mlp", 2, flat), want_emb=False)
         return density.view(*shp, 1)
