@@ -327,8 +327,14 @@ def sampler_step(cfg, device, pipe, steps=40, warm=300):
                               frac=round(ach / HBM_PEAK_GBS, 4), ms_per_step=round(t, 4)))
 
     if n_cand:
-        # march: 16 B parked + 16 B read back + 16 B packed per candidate (t0, t1, ray index); a latency chain per ray, not a stream
-        roof("march (walk + compaction)", ("march_begin", "march_finish"), n_cand * 48)
+        # march: one dependent chain of ~150 instructions per voxel per ray -- bound by the LATENCY of its longest ray, not by bytes
+        # and not by occupancy (rays per wave 16 / 8 / 4 / 2: sample() 1.44 / 1.45 / 1.46 / 1.77 ms); it runs one step
+        # ahead on its own stream.  Reported as what it is: voxels walked per second, no peak to divide by.
+        t_m = sum(per_step.get(o, 0.0) for o in ("march_begin", "march_finish"))
+        if t_m > 0:
+            roofs.append(dict(kernel="march (walk + compaction)", operators=["march_begin", "march_finish"], bound="latency (longest ray's chain)",
+                              achieved=round(n_cand / (t_m * 1e-3) / 1e6, 1), unit="M candidates/s", peak=None, frac=None, ms_per_step=round(t_m, 4),
+                              note="hidden: issued one step ahead on its own stream"))
         # density query of every candidate: 1024 B of table rows + 128 B of features + 12 B position + 4 B sigma
         roof("density query of the candidates", ("sample_midpoints", "positions_fwd", "hashgrid_fwd", "field_fwd"), n_cand * (1024 + 128 + 12 + 4))
         roof("visibility + compaction", ("visibility_mask", "compact_samples", "enc_gather"), n_cand * 13 + n_surv * (48 + 128))

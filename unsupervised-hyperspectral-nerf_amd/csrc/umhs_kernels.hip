@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
   if (i >= n) return;
   const float px = pos01[3 * i], py = pos01[3 * i + 1], pz = pos01[3 * i + 2];
   const int l = (int)blockIdx.y;
-  const HashCorners h = hash_corners(px, py, pz, scalings[l], (1u << log2_T) - 1u, (uint32_t)l << log2_T);
+  HashCorners h = hash_corners(px, py, pz, scalings[l], (1u << log2_T) - 1u, (uint32_t)l << log2_T);
+#ifdef HF_ABL_SAMEADDR  // (ablation builds of tools/alt_kernels.py only): every lane gathers the level's first slots -> what is left is not the gather
+#pragma unroll
+  for (int c = 0; c < 8; ++c) h.idx[c] = ((uint32_t)l << log2_T) + (h.idx[c] & 7u);
+#endif
   float2 f[8];
   hash_gather8(table, h, f);
   const float2 r = hash_trilerp(f, h.ox, h.oy, h.oz);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const float* __restri
 // builds) did `atomicMax(&lmax[level])` once per workgroup run: 8192 device-scope atomics on 16 words of ONE cache line serialise at
 // the memory side at ~12 ns each = 100 us -- the whole scatter pass, whatever else it did (ablations of tools/alt_kernels.py:
 // 98 us with every store, LDS placement and the write-out removed, 16 us once the maximum stayed zero).
-#define HB_LMAX_PARTS 64
+#define HB_LMAX_PARTS 128
 
 // One Adam update (torch.optim.Adam, no weight decay / amsgrad); one expression for the stand-alone kernels and for the
 // epilogue of hg_reduce_kernel, so that the fused and the separate update give the same bits.
@@ -674,7 +678,7 @@ __global__ void hg_scan_kernel(HbArgs a) {
     if (b < a.nb) a.offsets[lev * a.nb + b] = carry + incl - c;
     carry += __shfl(incl, 63, 64);
   }
-  a.lmax[(size_t)lev * HB_LMAX_PARTS + lane] = (lane == 0 && carry > a.cap) ? HB_POISON : 0u;  // (64 lanes = HB_LMAX_PARTS words)
+  for (int j = lane; j < HB_LMAX_PARTS; j += 64) a.lmax[(size_t)lev * HB_LMAX_PARTS + j] = (j == 0 && carry > a.cap) ? HB_POISON : 0u;
 }
 
 __device__ __forceinline__ unsigned long long hb_fixed(const float v, const int k) { return (unsigned long long)__float2ll_rn(ldexpf(v, k)); }
@@ -696,7 +700,8 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
   // epilogue of every path: the slab's gradient (+ its Adam step) as float4 lanes; the optimizer operands of a thread's (up to)
   // four chunks are requested before anything is computed -- three loads in flight per chunk, not three per thread
   // the level's max |value| = max over its scatter workgroups' words (one word per lane, L2 hits; every wave computes it for itself)
-  const uint32_t lmax_bits = wave_max_u32_dpp(a.lmax[(size_t)lev * HB_LMAX_PARTS + (tid & 63)]);
+  const uint32_t lmax_bits =
+      wave_max_u32_dpp(max(a.lmax[(size_t)lev * HB_LMAX_PARTS + (tid & 63)], a.lmax[(size_t)lev * HB_LMAX_PARTS + 64 + (tid & 63)]));
   // a non-finite gradient reached this level: the slabs its records land in are NaN, as after the reference's index_add; a level
   // whose records did not fit its region (HB_POISON) is NaN everywhere
   const bool nan_level = lmax_bits >= 0x7f800000u && (cnt != 0 || lmax_bits == HB_POISON);
@@ -787,14 +792,14 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
   HG_STAMP_FLUSH(1, l);
 }
 
-static inline int hb_scatter_wgs() {  // workgroups per level of the scatter pass (a multiple of 8); UMHS_HB_WGS: measurement knob
-  static const int v = [] {
+static inline int hb_scatter_wgs(int n_levels) {  // workgroups per level of the scatter pass (a multiple of 8); UMHS_HB_WGS: measurement knob
+  static const int forced = [] {
     const char* e = getenv("UMHS_HB_WGS");
-    int w = e ? atoi(e) : 64;
-    w = (w + 7) / 8 * 8;
-    return w < 8 ? 8 : w;
+    return e ? atoi(e) : 0;
   }();
-  return v;
+  int w = forced > 0 ? forced : 1024 / (n_levels > 0 ? n_levels : 1);
+  w = (w + 7) / 8 * 8;
+  return w < 8 ? 8 : w;
 }
 
 static inline int hb_bucket_bits(int log2_T) { return log2_T < HB_BUCKET_BITS ? log2_T : HB_BUCKET_BITS; }
@@ -891,8 +896,9 @@ static int hb_run_prepare(const HbArgs& a, int n_levels, int count_wgs, umhs_str
 
 static int hb_run_apply(const HbArgs& a, int n_levels, float* d_table, umhs_stream_t stream) {  // scatter + bucket reduce
   if (!a.d_enc || !d_table || !a.pos01 || !a.scalings) return UMHS_ERR_ARG;  // every pointer the two kernels dereference
-  // persistent workgroups: 8 per XCD and level = 64 per level (16 levels x 64 = the 1024 workgroups 256 CUs hold at four each)
-  int per_level = hb_scatter_wgs();
+  // persistent workgroups: the 1024 that 256 CUs hold at four each, spread over the levels of this launch (16 levels: 64 per level =
+  // 8 per XCD; a level group of 8 -- the multi-GPU exchange applies the levels in groups -- 128 per level)
+  int per_level = hb_scatter_wgs(n_levels);
   if (per_level > HB_LMAX_PARTS) per_level = HB_LMAX_PARTS;  // (one max-|value| word per workgroup and level)
   if (per_level > ((a.nwg + 7) / 8) * 8) per_level = ((a.nwg + 7) / 8) * 8;
   dim3 pgrid((unsigned)per_level, (unsigned)n_levels);
