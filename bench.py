@@ -646,7 +646,9 @@ def main():
             "kernels_ms_note": "median over the launches of an untimed pass with an event pair around every operator (the dominant one: inside "
                                "the timed region); kernels_ms_max = the slowest launch of each",
             "kernels_ms_max": {k: round(v[3], 4) for k, v in ksum.items()},
-            "host_gc_pauses": [p for p in pauses if p["ms"] >= 1.0],
+            # (collector passes INSIDE the timed region / breakdown pass, i.e. after measure()'s own deliberate collect + freeze; none expected)
+            "host_gc_pauses": [p for p in pauses if p["ms"] >= 1.0 and p["frozen"]],
+            "host_gc_collect_before_timed_region_ms": max([p["ms"] for p in pauses if not p["frozen"]] or [0.0]),
             "roofline": roof, "rooflines": rooflines, "csrc_sha": csrc_hash(),
         }
         if dist_info is not None:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun_out/ (scratch; remove the pmcb_* / prof_* directories of earlier runs first: pmc_summarize.py reads every csv it finds)
 # -> profiles/<round>/ (tracked): kernel stats of the bench commands, the bench lines, the PMC csv + summary per configuration
-rd=${1:-r03}
+rd=${1:-r04}
 mkdir -p profiles/$rd
 for c in C2 C3 C5; do
   f=$(ls -t $(find gpurun_out/prof_$c -name "*kernel_stats.csv") 2>/dev/null | head -1)   # newest run

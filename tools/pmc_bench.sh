@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
 run() { cfg=$1; tag=$2; shift 2
-  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmcb_${cfg}_$tag -- python $R/bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline --no-sampler-step > $R/gpurun_out/pmcb_${cfg}_$tag.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmcb_${cfg}_$tag -- python $R/bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline --no-sampler-step --no-other-configs --no-eval-image > $R/gpurun_out/pmcb_${cfg}_$tag.log 2>&1
   rc=$?; echo "pmc $cfg $tag rc=$rc"; return $rc; }
 for cfg in ${@:-C2}; do
   run $cfg fetch FETCH_SIZE &&

@@ -13,11 +13,11 @@ fi
 timeout -k 10 400 python bench.py 2>gpurun_out/bench_C2.err | tail -1 > gpurun_out/bench_C2.json || exit 1
 cut -c1-200 gpurun_out/bench_C2.json
 for c in C3 C5; do
-  timeout -k 10 300 python bench.py --config $c --no-cpu-baseline 2>gpurun_out/bench_$c.err | tail -1 > gpurun_out/bench_$c.json || exit 1
+  timeout -k 10 300 python bench.py --config $c --no-cpu-baseline --no-other-configs --no-sampler-step --no-eval-image 2>gpurun_out/bench_$c.err | tail -1 > gpurun_out/bench_$c.json || exit 1
   cut -c1-160 gpurun_out/bench_$c.json
 done
 for c in C2 C3 C5; do
   OUT=$R/gpurun_out/prof_$c
-  (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python $R/bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-sampler-step > $R/gpurun_out/prof_$c.log 2>&1) || exit 1
+  (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python $R/bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-sampler-step --no-other-configs --no-eval-image > $R/gpurun_out/prof_$c.log 2>&1) || exit 1
   echo "kernel-trace $c done"
 done

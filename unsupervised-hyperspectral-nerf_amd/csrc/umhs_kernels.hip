@@ -1569,9 +1569,11 @@ extern "C" int umhs_tmid_minmax(const float* t_starts, const float* t_ends, int6
     UMHS_CHECK_LAUNCH();
     return UMHS_OK;
   }
-  // (two same-line device atomics per workgroup serialise at ~12 ns each at the memory side: 32 workgroups, not 256)
-  int64_t blocks = (n + 8191) / 8192;
-  if (blocks > 32) blocks = 32;
+  // (one atomic pair per workgroup: 512 same-line device atomics serialise at ~12 ns each = ~6 us behind the kernel's 2 MB read, on the
+  // side stream.  Fewer, longer workgroups were tried in round 4 -- 32 x 8192 elements: 63 us at C2 and 1 ms on an eval image's 18 M
+  // candidates, a serial chain of loads per thread -- and reverted.)
+  int64_t blocks = (n + 2047) / 2048;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(tmid_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, umhs_s(stream), t_starts, t_ends, n,
                      reinterpret_cast<uint32_t*>(minmax2));
   UMHS_CHECK_LAUNCH();
