@@ -681,10 +681,22 @@ __global__ void hg_scan_kernel(HbArgs a) {
   for (int j = lane; j < HB_LMAX_PARTS; j += 64) a.lmax[(size_t)lev * HB_LMAX_PARTS + j] = (j == 0 && carry > a.cap) ? HB_POISON : 0u;
 }
 
-__device__ __forceinline__ unsigned long long hb_fixed(const float v, const int k) { return (unsigned long long)__float2ll_rn(ldexpf(v, k)); }
+// x = value * 2^(k - 32) -> floor(value * 2^k) as a 64-bit two's complement integer: hi = floor(x) (signed), lo = (x - floor(x)) * 2^32
+// (exact: the remainder of a float has at most 24 bits).  Six VALU instructions; __float2ll_rn(ldexpf(v, k)) compiles to fourteen, and
+// the record phase of the reduce pass -- four conversions per record -- was bound by exactly that plus the LDS atomics (round 4:
+// records stream at 3.2 TB/s, the Adam epilogue at the HBM rate).  Rounds down instead of to nearest: <= 2^-46 of the level maximum
+// per addend, the same for every order of the addends.
+__device__ __forceinline__ unsigned long long hb_fixed(const float x) {
+  const float fl = floorf(x);
+  const int hi = (int)fl;
+  const uint32_t lo = (uint32_t)((x - fl) * 4294967296.0f);
+  return ((unsigned long long)(uint32_t)hi << 32) | lo;
+}
 
 __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __restrict__ d_table) {
   extern __shared__ __attribute__((aligned(16))) long long tile[];  // [2 << bucket_bits] int64 fixed point
+  // (levels in dispatch order.  Last level first -- the records the scatter pass wrote last are the likeliest to sit in the 256 MiB
+  // Infinity Cache -- was measured in round 4: 211-220 vs 186-204 us at C2, 361-382 vs 325-347 us at C5.  Dropped.)
   const int tid = threadIdx.x, b = blockIdx.x, lev = a.lev_off + blockIdx.y, l = a.level0 + lev;
   HG_STAMP_DECL;
   const uint32_t start = a.offsets[lev * a.nb + b], cnt = a.counts[lev * a.nb + b];
@@ -714,38 +726,64 @@ __global__ __launch_bounds__(1024) void hg_reduce_kernel(HbArgs a, float* __rest
     int e;
     (void)frexpf(__uint_as_float(lmax_bits), &e);
     const int hb = 33 - __clz(cnt);  // cnt < 2^(32-clz) ; one spare bit
-    kfix = 62 - hb - e;
+    kfix = min(62 - hb - e, 150);  // (2^(kfix - 32) must be a finite float: levels whose largest |value| is below 2^-60)
     __syncthreads();
     const uint4* __restrict__ rp = a.recs + (size_t)lev * a.cap + start;
     typedef unsigned long long u64;
     u64* ut = reinterpret_cast<u64*>(tile);
     const uint32_t lowmask = (1u << a.bucket_bits) - 1u;
+    const float fscale = ldexpf(1.0f, kfix - 32);
     auto add = [&](const uint4& r) {
+#ifdef HR_ABL_NOADD  // (ablation builds of tools/alt_kernels.py only)
+      asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w));
+      return;
+#endif
       const float vx = __uint_as_float(r.x), vy = __uint_as_float(r.y), ox = __uint_as_float(r.z);
       const uint32_t s = r.w & lowmask, kk = (r.w >> 24) & 15u;
-      const float rx = 1.0f - ox;
-      atomicAdd(&ut[2 * s], hb_fixed(vx * rx, kfix)), atomicAdd(&ut[2 * s + 1], hb_fixed(vy * rx, kfix));
+      const float rx = (1.0f - ox) * fscale, oxs = ox * fscale;  // the weights carry the fixed-point scale 2^(kfix - 32)
+#ifdef HR_ABL_NOATOMIC
+      asm volatile("" ::"v"(hb_fixed(vx * rx)), "v"(hb_fixed(vy * rx)), "v"(hb_fixed(vx * oxs)), "v"(hb_fixed(vy * oxs)), "v"(s), "v"(kk));
+      return;
+#endif
+      atomicAdd(&ut[2 * s], hb_fixed(vx * rx)), atomicAdd(&ut[2 * s + 1], hb_fixed(vy * rx));
       if (kk != 15u) {
         const uint32_t cs = s ^ (((2u << kk) - 1u) & lowmask);
-        atomicAdd(&ut[2 * cs], hb_fixed(vx * ox, kfix)), atomicAdd(&ut[2 * cs + 1], hb_fixed(vy * ox, kfix));
+        atomicAdd(&ut[2 * cs], hb_fixed(vx * oxs)), atomicAdd(&ut[2 * cs + 1], hb_fixed(vy * oxs));
       }
     };
     uint32_t i = tid;
     HG_STAMP(0);
     // 4 records per thread and batch, the NEXT batch requested before this one is accumulated (every record slot past the end
-    // re-reads the bucket's last record and is dropped: unconditional loads stay batched)
+    // re-reads the bucket's last record and is dropped: unconditional loads stay batched).  Two register sets in turn, no copies:
+    // with `r = n` moves at the loop's end hipcc waits for vmcnt(0) at its top -- in front of the next requests -- and nothing overlaps.
     const uint32_t last = cnt - 1;
-    uint4 r0 = rp[min(i, last)], r1 = rp[min(i + 1024, last)], r2 = rp[min(i + 2048, last)], r3 = rp[min(i + 3072, last)];
-    for (; i < cnt; i += 4096) {
-      const uint32_t j = i + 4096;
-      HG_STAMP_DRAIN(1);
-      const uint4 n0 = rp[min(j, last)], n1 = rp[min(j + 1024, last)], n2 = rp[min(j + 2048, last)], n3 = rp[min(j + 3072, last)];
-      add(r0);
-      if (i + 1024 < cnt) add(r1);
-      if (i + 2048 < cnt) add(r2);
-      if (i + 3072 < cnt) add(r3);
-      r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-      HG_STAMP(3);
+    auto load4 = [&](uint4 (&r)[4], const uint32_t at) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = rp[min(at + 1024u * u, last)];
+    };
+    auto add4 = [&](const uint4 (&r)[4], const uint32_t at) {
+      add(r[0]);
+#pragma unroll
+      for (int u = 1; u < 4; ++u)
+        if (at + 1024u * u < cnt) add(r[u]);
+    };
+    uint4 ra[4], rb[4];
+    if (i < cnt) {
+      load4(ra, i);
+      while (true) {
+        HG_STAMP_DRAIN(1);
+        load4(rb, i + 4096u);
+        add4(ra, i);
+        HG_STAMP(3);
+        i += 4096u;
+        if (i >= cnt) break;
+        HG_STAMP_DRAIN(1);
+        load4(ra, i + 4096u);
+        add4(rb, i);
+        HG_STAMP(3);
+        i += 4096u;
+        if (i >= cnt) break;
+      }
     }
     HG_STAMP_DRAIN(3);
     __syncthreads();
