@@ -328,7 +328,7 @@ def sampler_step(cfg, device, pipe, steps=40, warm=300):
 
     if n_cand:
         # march: one dependent chain of ~150 instructions per voxel per ray -- bound by the LATENCY of its longest ray, not by bytes
-        # and not by occupancy (rays per wave 16 / 8 / 4 / 2: sample() 1.44 / 1.45 / 1.46 / 1.77 ms, DESIGN 11.5); it runs one step
+        # and not by occupancy (rays per wave 16 / 8 / 4 / 2: sample() 1.44 / 1.45 / 1.46 / 1.77 ms, DESIGN 5); it runs one step
         # ahead on its own stream.  Reported as what it is: voxels walked per second, no peak to divide by.
         t_m = sum(per_step.get(o, 0.0) for o in ("march_begin", "march_finish"))
         if t_m > 0:

@@ -490,7 +490,7 @@ def model_outputs(
     if p.method == "rgb":
         # umhs_model.py:265-267.  The reference omits ray_indices / num_rays here, so nerfstudio's RGBRenderer sums over ALL packed
         # samples of the batch (one colour for every ray) -- a defect, not a behaviour to restate: per-ray compositing, as for every
-        # other output (DESIGN.md section 10.9).  background_color="random": no blend in the forward  [upstream-recalled].
+        # other output (DESIGN.md section 7).  background_color="random": no blend in the forward  [upstream-recalled].
         out["rgb"] = accumulate_along_rays(weights[..., 0], fo["rgb"], ray_indices, num_rays)
         out["num_samples_per_ray"] = pinfo[:, 1]
         return out

@@ -2,7 +2,7 @@
 """What would a hipGraph of the synthetic training step buy?  Captures ONE `UMHSPipeline.train_iteration` (C2 shape by default) with
 torch.cuda.graph (= hipGraph on ROCm) and replays it next to the eager loop.  TIMING ONLY: Adam's step-dependent scalars (bias
 corrections, decayed learning rate) are launch arguments and stay frozen at the captured step, so the replayed updates are not a valid
-training run -- a product version would first have to move them into a device buffer (DESIGN 10.4).  GPU box:
+training run -- a product version would first have to move them into a device buffer (DESIGN 5).  GPU box:
     python tools/graph_step.py [C2|C3|C5]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
