@@ -166,6 +166,47 @@ def test_hashgrid_bwd_partition_reproducible_and_keeps_small_gradients():
     assert float(got[~touched].abs().max()) == 0.0
 
 
+def test_hashgrid_bwd_pairs_that_straddle_two_buckets_and_the_overflow_guard():
+    """Round 4's record format pairs the two x-neighbour corners of a sample in ONE record, which needs both slots in one bucket of
+    2^13 slots: always so below resolution 8192.  Above it (any scale is legal at the C ABI) a floor coordinate = 8191 mod 8192 puts
+    the pair in two buckets: it is emitted as two singles, the workgroup may exceed its LDS staging (then it writes straight to
+    memory), and a level whose records exceed its region (5 per sample) comes back as NaN -- loudly -- never silently wrong."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N, log2_T = 4096, 19
+    sc = T.hash_scalings().clone()
+    sc[12:] = torch.tensor([9000.0, 17000.0, 33000.0, 40000.0])  # four levels above 8192
+    x = torch.rand(N, 3, generator=g) * 0.98 + 0.01
+    # every fourth sample: x chosen so that floor(x * scale_13) = 8191 (mod 8192) at level 13 -> its four x-pairs straddle two buckets there
+    pick = torch.arange(0, N, 4)
+    x[pick, 0] = (8191.0 + 0.25 + 0.5 * torch.rand(pick.numel(), generator=g)) / float(sc[13])
+    table = torch.zeros(16 << log2_T, 2, requires_grad=True)
+    cot = torch.rand(N, 32, generator=g)
+    (gref,) = torch.autograd.grad((T.hash_encode(x, table, sc, log2_T) * cot).sum(), table)
+    fl = torch.floor(x[:, 0] * sc[13]).long()
+    assert int(((fl % 8192) == 8191).sum()) >= N // 4 - 8
+    d_enc = cot.view(N, 16, 2).permute(1, 0, 2).contiguous()
+    outs = []
+    for _ in range(2):
+        d_table = torch.zeros(16 << log2_T, 2, device=DEV)
+        ops.hashgrid_bwd(x.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, True, method="partition")
+        outs.append(d_table.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert_close("d_table with straddling pairs", outs[0], gref, 2e-5)
+    # ALL samples straddling at level 13: 8 records per sample > the region's 5 -> that level (only) is NaN, every other level is right
+    x2 = x.clone()
+    x2[:, 0] = (8191.0 + 0.25 + 0.5 * torch.rand(N, generator=g)) / float(sc[13])
+    (gref2,) = torch.autograd.grad((T.hash_encode(x2, table, sc, log2_T) * cot).sum(), table)
+    d_table = torch.zeros(16 << log2_T, 2, device=DEV)
+    ops.hashgrid_bwd(x2.to(DEV), d_enc.to(DEV), sc.to(DEV), log2_T, d_table, True, method="partition", overwrite=True)
+    got = d_table.cpu()
+    Tn = 1 << log2_T
+    assert bool(torch.isnan(got[13 * Tn:14 * Tn]).all()), "an overflowing level must be NaN"
+    keep = torch.ones(16 * Tn, dtype=torch.bool)
+    keep[13 * Tn:14 * Tn] = False
+    assert_close("the other levels", got[keep], gref2[keep], 2e-5)
+
+
 def test_hashgrid_bwd_skewed_all_samples_in_one_cell():
     """Worst case for the bucket partition: every contribution of the coarse levels lands in 8 slots."""
     ops = _ops()
