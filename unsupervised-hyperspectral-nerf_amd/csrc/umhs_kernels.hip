@@ -1133,7 +1133,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     const int nvalid = min(64, cnt - base);
     for (int s = 0; s < st.n;) {
       // two streams of <= 32 values share the wave (lanes 0-31 / 32-63): at the reference's 21-31 bands a single stream would leave
-      // half the lanes idle, and this loop is latency-bound -- the number of row-load rounds is what it costs
+      // half the lanes idle, and this loop is latency-bound -- the number of row-load rounds is what it costs.  (Round 4 tried rows as
+      // float4 pieces, 64 / ceil(K / 4) rows per load instruction -- 8 instead of 64 load instructions per chunk at 31 bands, partial
+      // sums joined by xor-shuffles: 25.6 vs 20.5 us at C2, 189 vs 159 us with 128-band streams.  4-byte-aligned dwordx4 rows and the
+      // 12 extra shuffles cost more than the load rounds they save.  Reverted.)
       const bool pair = s + 1 < st.n && st.k[s] <= 32 && st.k[s + 1] <= 32;
       const int half = pair ? (lane >> 5) : 0;
       const int K = half ? st.k[s + 1] : st.k[s];
