@@ -658,10 +658,19 @@ def ray_train_tail(s, m, E, accumulation, depth, tminmax, colors, gt_spec, gt_rg
     R, B = s.shape
     Cn = E.shape[0]
     dev = s.device
-    new_ = lambda *shp: torch.empty(shp, device=dev, dtype=torch.float32)
-    rgb, dclip, probs, raw, pred = new_(R, 3), new_(R, 1), new_(R, Cn), new_(R), new_(R, 3)
-    losses, d_spec = new_(2), new_(R, B)
-    d_acc = new_(R) if rgb_loss else None
+    # ONE allocation for the nine outputs, carved into 16-byte-aligned views (fresh every call: callers keep what they get).  Nine
+    # torch.empty calls were ~40 us of host time between a profiler's event pair around this operator -- more than the kernel's 19 us,
+    # so whenever the GPU ran dry the "operator time" was the host's (BENCH_r03's kernels_ms row).
+    sizes = [R * 3, R, R * Cn, R, R * 3, 2, R * B, R if rgb_loss else 0]
+    offs, total = [], 0
+    for n_ in sizes:
+        offs.append(total)
+        total += (n_ + 3) & ~3
+    buf = torch.empty(total, device=dev, dtype=torch.float32)
+    view = lambda i, *shp: buf[offs[i]:offs[i] + sizes[i]].view(*shp)
+    rgb, dclip, probs, raw, pred = view(0, R, 3), view(1, R, 1), view(2, R, Cn), view(3, R), view(4, R, 3)
+    losses, d_spec = view(5, 2), view(6, R, B)
+    d_acc = view(7, R) if rgb_loss else None
     sc = _tail_scratch.get(dev.index or 0)
     if sc is None:
         sc = _tail_scratch[dev.index or 0] = torch.zeros(_hip.lib().umhs_ray_train_tail_scratch_bytes(), dtype=torch.uint8, device=dev)
