@@ -387,6 +387,12 @@ def measure(case, timer, steps, warmup, world, device):
     """warm-up -> pick the dominant operator from three fully timed (still warm-up) steps -> the timed region: EXACTLY `steps` steps
     between a barrier + device sync on both sides, one HIP event per step boundary (median) and an event pair around the dominant
     operator only -> (wall seconds [max over ranks], median ms, the dominant operator's live summary, last outputs, last losses)."""
+    # Host hygiene first: a generation-2 pass of Python's cycle collector takes ~0.1 s in this process (torch + numpy + the oracle's
+    # modules are tens of thousands of tracked objects); BENCH_r03's breakdown pass caught one between an event pair (DESIGN 5).
+    # Collect now and freeze the survivors, so the passes below only ever see young-generation collections.  It happens HERE, in front
+    # of the warm-up: 0.1 s of idle GPU right before the timed region cost its first step 0.9 ms and the next ten a lower clock.
+    gc.collect()
+    gc.freeze()
     for _ in range(warmup):
         case.step()
     # Which operator is the dominant one is measured, not assumed: three steps with every operator timed (still warm-up), and the
@@ -405,11 +411,11 @@ def measure(case, timer, steps, warmup, world, device):
     timer.only = {ROOFLINE_OPS[int(torch.argmax(pick).item())]}
     timer.records.clear()
     timer.enabled = True
-    # Host hygiene of the timed region: a generation-2 pass of Python's cycle collector takes ~0.1 s in this process (torch + numpy +
-    # the oracle's modules are tens of thousands of tracked objects); BENCH_r03's breakdown pass caught one between an event pair
-    # (DESIGN 5).  Collect now and freeze the survivors, so the passes below only ever see young-generation collections.
-    gc.collect()
-    gc.freeze()
+    # untimed: the launch queue refills and the clocks settle after the fully timed steps above (their host syncs drained it); the
+    # step times of a timed region that starts cold fall from 0.73 to 0.69 ms over its first thirty steps
+    for _ in range(max(20, warmup)):
+        case.step()
+    timer.records.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -610,10 +616,11 @@ def main():
         parallel.EXCHANGE_DISABLED = False
         dist.all_reduce(t_noex, op=dist.ReduceOp.MAX)
         sink = pipe.model.field._grad_sink
-        # (the counters also saw the three dominant-operator steps of measure(): per step = / (steps + 3))
+        # (the counters saw every step of measure(): warm-up, the three dominant-operator steps, the re-warm steps, the timed ones)
+        n_exchanging_steps = args.warmup + 3 + max(20, args.warmup) + args.steps
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": ndev,
-                     "mb_exchanged_per_step": round(exchanged["bytes"] / (args.steps + 3 + args.warmup) / 1e6, 2),
-                     "messages_per_step": round(exchanged["messages"] / (args.steps + 3 + args.warmup), 2),
+                     "mb_exchanged_per_step": round(exchanged["bytes"] / n_exchanging_steps / 1e6, 2),
+                     "messages_per_step": round(exchanged["messages"] / n_exchanging_steps, 2),
                      "level_groups": getattr(sink, "level_groups", None), "async_reduce": getattr(sink, "async_reduce", None),
                      "ms_per_step_without_exchange": round(float(t_noex.item()) * 1e3, 4),
                      "exposed_exchange_ms": round(dt / args.steps * 1e3 - float(t_noex.item()) * 1e3, 4)}
