@@ -346,7 +346,7 @@ def sampler_step(cfg, device, pipe, steps=40, warm=300):
                      "for the candidates' density query AND for the survivors' forward)")
 
 
-OPS = ("positions_fwd", "hashgrid_fwd", "field_fwd", "field_base_fwd", "field_heads_fwd", "accumulate_fwd", "composite_fwd", "tmid_minmax",
+OPS = ("positions_fwd", "hashgrid_fwd", "hashgrid_fwd_count", "hashgrid_bwd_prepare_counted", "field_fwd", "field_base_fwd", "field_heads_fwd", "accumulate_fwd", "composite_fwd", "tmid_minmax",
        "ray_train_tail", "composite_bwd", "field_bwd",
        "hashgrid_bwd", "hashgrid_bwd_prepare", "hashgrid_bwd_apply", "field_fwd_prepare", "field_bwd_prepare", "adam_step",
        "adam_step_rows", "adam_step_rows_range")  # (one GPU: the dense hash levels' Adam step rides in hashgrid_bwd_apply)

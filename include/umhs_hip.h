@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 9
+#define UMHS_ABI_VERSION 10
 
 enum {
   UMHS_OK = 0,
@@ -85,6 +85,17 @@ int umhs_hashgrid_bwd(const float* pos01, const float* d_enc, int64_t stride_n, 
                       float* d_table, int overwrite, void* workspace, size_t workspace_bytes, umhs_stream_t stream);
 /* The partitioned backward in two halves.  prepare: bucket histogram + scan, from the positions alone (may run on a side   */
 /* stream while the forward pass is in flight).  apply: scatter + per-bucket reduction of levels [level_begin, +n_levels),  */
+
+/* umhs_hashgrid_fwd for the workspace's level range [0, n_levels) AND the histogram pass of umhs_hashgrid_bwd_prepare for the same   */
+/* positions, in one launch (the gather has hashed every (sample, level) anyway and leaves the vector ALU idle);                     */
+/* umhs_hashgrid_bwd_prepare_counted then runs only the two small scans.  Together they equal umhs_hashgrid_fwd +                    */
+/* umhs_hashgrid_bwd_prepare(level_begin 0) bit for bit.  workspace: umhs_hashgrid_bwd_workspace_bytes(n, n_levels, log2_T).          */
+int umhs_hashgrid_fwd_count(const float* pos01, const float* table, const float* scalings, int64_t n, int n_levels, int log2_T,
+                            float* enc, int64_t stride_n, int64_t stride_l, void* workspace, size_t workspace_bytes,
+                            umhs_stream_t stream);
+int umhs_hashgrid_bwd_prepare_counted(const float* pos01, const float* scalings, int64_t n, int n_levels, int log2_T, void* workspace,
+                                      size_t workspace_bytes, umhs_stream_t stream);
+
 /* a sub-range of the prepared [ws_level_begin, +ws_n_levels) in the same workspace; each level once per prepare.          */
 int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalings, int64_t n, int level_begin, int n_levels, int log2_T,
                               void* workspace, size_t workspace_bytes, umhs_stream_t stream);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(built_library):
         assert hasattr(lib, s), f"{s} declared in umhs_hip.h but not exported"
         assert s in _hip.SIGNATURES, f"{s} has no ctypes signature in umhsnerf/_hip.py"
     assert set(_hip.SIGNATURES) == set(syms)
-    assert _hip.lib().umhs_abi_version() == _hip.ABI_VERSION == 9
+    assert _hip.lib().umhs_abi_version() == _hip.ABI_VERSION == 10
     assert _hip.lib().umhs_strerror(-3) == b"workspace missing or too small"
 
 

@@ -207,6 +207,56 @@ def test_hashgrid_bwd_pairs_that_straddle_two_buckets_and_the_overflow_guard():
     assert_close("the other levels", got[keep], gref2[keep], 2e-5)
 
 
+@pytest.mark.parametrize("kind", ["ray_samples", "one_cell", "scattered", "straddling"])
+def test_hashgrid_fwd_count_equals_forward_plus_prepare(kind):
+    """The training step takes the backward's bucket histogram inside the forward gather's launch (umhs_hashgrid_fwd_count +
+    umhs_hashgrid_bwd_prepare_counted).  It must be umhs_hashgrid_fwd + umhs_hashgrid_bwd_prepare bit for bit: the features, every
+    byte the prepare leaves in the workspace (per-workgroup counts, prefixes, bucket offsets), and so the gradient.  Sample sets:
+    consecutive samples along rays (runs merge on the coarse levels), all in one cell, independent positions, and pairs that
+    straddle two buckets; N not a multiple of the 512-sample run."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    N, log2_T = 3 * 512 * 37 + 129, 19
+    sc = T.hash_scalings().clone()
+    if kind == "ray_samples":
+        o = torch.rand(N // 48 + 1, 1, 3, generator=g) * 0.5 + 0.1
+        d = torch.nn.functional.normalize(torch.randn(N // 48 + 1, 1, 3, generator=g), dim=-1)
+        x = (o + d * torch.linspace(0, 0.3, 48).view(1, 48, 1)).reshape(-1, 3)[:N].clamp(0.0, 1.0).contiguous()
+    elif kind == "one_cell":
+        x = 0.4 + torch.rand(N, 3, generator=g) * 1e-3
+    else:
+        x = torch.rand(N, 3, generator=g)
+        if kind == "straddling":
+            sc[12:] = torch.tensor([9000.0, 17000.0, 33000.0, 40000.0])
+            pick = torch.arange(0, N, 4)
+            x[pick, 0] = (8191.0 + 0.25 + 0.5 * torch.rand(pick.numel(), generator=g)) / float(sc[13])
+    x, sc = x.to(DEV), sc.to(DEV)
+    table = ((torch.rand(16 << log2_T, 2, generator=g) - 0.5) * 0.2).to(DEV)
+    d_enc = torch.rand(16, N, 2, generator=g).to(DEV)
+    nbytes = ops._hip.lib().umhs_hashgrid_bwd_workspace_bytes(N, 16, log2_T)
+    assert nbytes > 0
+    ws = ops._workspace(nbytes, x.device, slot=1)
+
+    def run(fused):
+        ws.zero_()
+        if fused:
+            enc = ops.hashgrid_fwd_count(x, table, sc, log2_T)
+            assert ops.hashgrid_bwd_prepare_counted(x, sc, log2_T)
+        else:
+            enc = ops.hashgrid_fwd(x, table, sc, log2_T, True)
+            assert ops.hashgrid_bwd_prepare(x, sc, log2_T)
+        meta = ws[:nbytes].clone()  # (zeroed above; the record regions behind the counts are written by the scatter pass only)
+        d_table = torch.empty(16 << log2_T, 2, device=DEV)
+        ops.hashgrid_bwd_apply(x, d_enc, sc, log2_T, d_table, True, overwrite=True)
+        return enc, meta, d_table
+
+    a, b = run(False), run(True)
+    assert bool(a[1].any())
+    assert torch.equal(a[0], b[0]), "features"
+    assert torch.equal(a[1], b[1]), "histogram / scans in the workspace"
+    assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32)), "gradient"
+
+
 def test_hashgrid_bwd_skewed_all_samples_in_one_cell():
     """Worst case for the bucket partition: every contribution of the coarse levels lands in 8 slots."""
     ops = _ops()

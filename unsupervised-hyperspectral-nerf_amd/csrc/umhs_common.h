@@ -84,24 +84,35 @@ __device__ __forceinline__ HashCorners hash_corners(float px, float py, float pz
 // floor coordinate that is the neighbouring slot of the same 16-byte pair, so ONE 16-byte load serves both -- on average 6 requests
 // per (sample, level) instead of 8, and the gather is bound by the L2 request rate, not by bytes.  The other half of the lanes
 // (odd floor coordinate) fetches its four ceil-x corners separately.  Same values as eight 8-byte loads.
-__device__ __forceinline__ void hash_gather8(const float2* __restrict__ table, const HashCorners& h, float2 (&f)[8]) {
+struct HashGather {
+  float4 q[4];   // the 16-byte slot pairs holding the floor-x corner of the four (y, z) combinations
+  float2 cv[4];  // their ceil-x corners, fetched only when those live in another pair
+  bool apart;
+};
+__device__ __forceinline__ void hash_gather8_issue(const float2* __restrict__ table, const HashCorners& h, HashGather& g) {
   const float4* __restrict__ t4 = reinterpret_cast<const float4*>(table);
   constexpr int FI[4] = {3, 2, 7, 6}, CI[4] = {0, 1, 4, 5};  // floor-x / ceil-x corner of the four (y, z) combinations
-  float4 q[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) q[p] = t4[h.idx[FI[p]] >> 1];
-  const bool apart = (h.idx[CI[0]] >> 1) != (h.idx[FI[0]] >> 1);  // (a property of the x coordinate: the same for all four pairs)
-  float2 cv[4];
-  if (apart) {
+  for (int p = 0; p < 4; ++p) g.q[p] = t4[h.idx[FI[p]] >> 1];
+  g.apart = (h.idx[CI[0]] >> 1) != (h.idx[FI[0]] >> 1);  // (a property of the x coordinate: the same for all four pairs)
+  if (g.apart) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) cv[p] = table[h.idx[CI[p]]];
+    for (int p = 0; p < 4; ++p) g.cv[p] = table[h.idx[CI[p]]];
   }
+}
+__device__ __forceinline__ void hash_gather8_select(const HashCorners& h, const HashGather& g, float2 (&f)[8]) {
+  constexpr int FI[4] = {3, 2, 7, 6}, CI[4] = {0, 1, 4, 5};
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const float2 lo = make_float2(q[p].x, q[p].y), hi = make_float2(q[p].z, q[p].w);
+    const float2 lo = make_float2(g.q[p].x, g.q[p].y), hi = make_float2(g.q[p].z, g.q[p].w);
     f[FI[p]] = (h.idx[FI[p]] & 1u) ? hi : lo;
-    f[CI[p]] = apart ? cv[p] : ((h.idx[CI[p]] & 1u) ? hi : lo);
+    f[CI[p]] = g.apart ? g.cv[p] : ((h.idx[CI[p]] & 1u) ? hi : lo);
   }
+}
+__device__ __forceinline__ void hash_gather8(const float2* __restrict__ table, const HashCorners& h, float2 (&f)[8]) {
+  HashGather g;
+  hash_gather8_issue(table, h, g);
+  hash_gather8_select(h, g, f);
 }
 
 // trilinear blend of the 8 corner features (corner order above), one expression tree shared by the stand-alone gather kernel and

@@ -584,6 +584,80 @@ __device__ __forceinline__ void hg_partition_body(const HbArgs& a, const int wg,
   HG_STAMP_FLUSH(0, l);
 }
 
+// The histogram half of hg_partition_body for ONE sample per lane, as a function of its own: which records the scatter pass will emit
+// for the sample (run detection over the 16-lane DPP row, the wave-wide merge decision, pair / single / split records), counted into
+// the workgroup's bucket counters.  hashgrid_fwd_count_kernel below calls it: the forward gather has hashed every (sample, level)
+// anyway and is bound by the vector-memory path with the VALU idle, so the histogram pass of the backward -- 45 us of hashing, DPP and
+// LDS atomics, hidden on the side stream but 16 us of the step all the same (measured: the step without it) -- rides along for free.
+// MUST stay the exact mirror of hg_partition_body<false> (tests/test_hip_parity.py compares the counts bit for bit).
+__device__ __forceinline__ void hb_count_sample(const uint32_t (&slot)[8], const uint32_t kx, const uint32_t ky, const uint32_t kz, const uint32_t kf,
+                                                const bool act, const int bb, const int lane, uint32_t* __restrict__ cursor) {
+  const int l16 = lane & 15;
+  const uint32_t px_ = row_shr_u<1>(kx), py_ = row_shr_u<1>(ky), pz_ = row_shr_u<1>(kz), pf_ = row_shr_u<1>(kf);
+  bool head = (l16 == 0) | (px_ != kx) | (py_ != ky) | (pz_ != kz) | (pf_ != kf);
+  const bool merging = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!head)) >= HB_MERGE_MIN;
+  if (!merging) head = true;
+  const int nhead = merging ? row_shl1((int)head) : 1;
+  const bool tail = act && (l16 == 15 || nhead);
+  const bool solo = head && tail;
+  if (tail) {
+    if (solo) {
+      // (written out: left as loops the compiler kept them rolled and moved slot[] into LDS for the dynamic index)
+      const uint32_t pm = slot[3] ^ slot[0];  // HB_FI[0], HB_CI[0]
+      static_assert(HB_FI[0] == 3 && HB_FI[1] == 2 && HB_FI[2] == 7 && HB_FI[3] == 6 && HB_CI[0] == 0, "corner order");
+      atomicAdd(&cursor[slot[3] >> bb], 1u), atomicAdd(&cursor[slot[2] >> bb], 1u);
+      atomicAdd(&cursor[slot[7] >> bb], 1u), atomicAdd(&cursor[slot[6] >> bb], 1u);
+      if ((pm >> bb) != 0) {  // the x-neighbours live in two buckets: every pair becomes two singles
+        atomicAdd(&cursor[slot[0] >> bb], 1u), atomicAdd(&cursor[slot[1] >> bb], 1u);
+        atomicAdd(&cursor[slot[4] >> bb], 1u), atomicAdd(&cursor[slot[5] >> bb], 1u);
+      }
+    } else {
+      atomicAdd(&cursor[slot[0] >> bb], 1u), atomicAdd(&cursor[slot[1] >> bb], 1u);
+      atomicAdd(&cursor[slot[2] >> bb], 1u), atomicAdd(&cursor[slot[3] >> bb], 1u);
+      atomicAdd(&cursor[slot[4] >> bb], 1u), atomicAdd(&cursor[slot[5] >> bb], 1u);
+      atomicAdd(&cursor[slot[6] >> bb], 1u), atomicAdd(&cursor[slot[7] >> bb], 1u);
+    }
+  }
+}
+
+// hashgrid_fwd_kernel + the backward's bucket histogram: one workgroup = one run of 512 samples of one level (the scatter pass's unit)
+static_assert(256 * HB_SPT == 512, "hashgrid_fwd_count_kernel's workgroup is one run of the partition");
+__global__ __launch_bounds__(512) void hashgrid_fwd_count_kernel(const float2* __restrict__ table, float* __restrict__ enc, int64_t stride_n,
+                                                                 int64_t stride_l, HbArgs a) {
+  __shared__ uint32_t cursor[HB_MAX_NB];
+  const int tid = threadIdx.x, lane = tid & 63, wg = blockIdx.x, l = blockIdx.y;  // (workspace range starts at level 0: lev == l)
+  if (tid < HB_MAX_NB) cursor[tid] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)wg * 512 + tid;
+  const bool act = i < a.n;
+  const int64_t ii = act ? i : a.n - 1;
+  const uint32_t mask = (1u << a.log2_T) - 1u, base = (uint32_t)l << a.log2_T;
+  const HashCorners h = hash_corners(a.pos01[3 * ii], a.pos01[3 * ii + 1], a.pos01[3 * ii + 2], a.scalings[l], mask, base);
+  HashGather hg;
+  hash_gather8_issue(table, h, hg);  // the loads are in flight while the wave counts
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t slot[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) slot[c] = h.idx[c] - base;
+  const uint32_t kx = act ? h.fx : 0xffffffffu, ky = act ? h.fy : 0u, kz = act ? h.fz : 0u;
+  const uint32_t kf = act ? (h.eqx | (h.eqy << 1) | (h.eqz << 2)) : (0x80000000u | (uint32_t)lane);  // unique per lane when inactive
+  hb_count_sample(slot, kx, ky, kz, kf, act, a.bucket_bits, lane, cursor);
+  __syncthreads();
+  if (tid < a.nb) a.wg_counts[((size_t)l * a.nwg + wg) * a.nb + tid] = cursor[tid];
+  __builtin_amdgcn_sched_barrier(0);
+  float2 f[8];
+  hash_gather8_select(h, hg, f);
+  const float2 r = hash_trilerp(f, h.ox, h.oy, h.oz);
+  if (act) {
+    float* o = enc + i * stride_n + (int64_t)l * stride_l;
+    if (((stride_n | stride_l) & 1) == 0) {
+      *reinterpret_cast<float2*>(o) = r;
+    } else {
+      o[0] = r.x, o[1] = r.y;
+    }
+  }
+}
+
 // Scatter pass: PERSISTENT workgroups, gridDim.x (a multiple of 8) per level; each walks its runs of samples with the next run's
 // inputs in flight (hb_load above).  Which runs: workgroups go to the 8 XCDs round-robin by their linear index, and the runs wg,
 // wg + 1 write ADJACENT record runs in every bucket (short ones on the coarse levels: most 128-byte lines of the record stream are
@@ -972,6 +1046,39 @@ extern "C" int umhs_hashgrid_bwd_prepare(const float* pos01, const float* scalin
   if (rc) return rc;
   const int throttle = 16;  // workgroups per level of the hidden histogram pass (unthrottled it delays the forward's workgroups)
   return hb_run_prepare(a, n_levels, throttle, stream);
+}
+
+// umhs_hashgrid_fwd for ALL levels of the workspace range [0, n_levels) + the histogram pass of umhs_hashgrid_bwd_prepare for the same
+// positions in one launch; umhs_hashgrid_bwd_prepare_counted then only runs the two small scans (a caller may put it on a side stream).
+extern "C" int umhs_hashgrid_fwd_count(const float* pos01, const float* table, const float* scalings, int64_t n, int n_levels, int log2_T,
+                                       float* enc, int64_t stride_n, int64_t stride_l, void* workspace, size_t workspace_bytes,
+                                       umhs_stream_t stream) {
+  if (n < 0 || !table || !scalings) return UMHS_ERR_ARG;
+  if (n_levels < 1 || n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (n == 0) return UMHS_OK;
+  if (!pos01 || !enc) return UMHS_ERR_ARG;
+  if (((uintptr_t)table & 15) || ((uintptr_t)enc & 7)) return UMHS_ERR_ARG;
+  HbArgs a;
+  int rc = hb_args(&a, pos01, scalings, n, 0, n_levels, log2_T, workspace, workspace_bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(hashgrid_fwd_count_kernel, dim3((unsigned)a.nwg, (unsigned)n_levels), dim3(512), 0, umhs_s(stream),
+                     reinterpret_cast<const float2*>(table), enc, stride_n, stride_l, a);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
+}
+
+extern "C" int umhs_hashgrid_bwd_prepare_counted(const float* pos01, const float* scalings, int64_t n, int n_levels, int log2_T,
+                                                 void* workspace, size_t workspace_bytes, umhs_stream_t stream) {
+  if (n < 0 || !pos01 || !scalings) return UMHS_ERR_ARG;
+  if (n_levels < 1 || n_levels > 32 || log2_T < 2 || log2_T > 24) return UMHS_ERR_UNSUPPORTED;
+  if (n == 0) return UMHS_OK;
+  HbArgs a;
+  int rc = hb_args(&a, pos01, scalings, n, 0, n_levels, log2_T, workspace, workspace_bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(hg_wgscan_kernel, dim3((unsigned)a.nb, (unsigned)n_levels), dim3(256), 0, umhs_s(stream), a);
+  hipLaunchKernelGGL(hg_scan_kernel, dim3((unsigned)n_levels), dim3(64), 0, umhs_s(stream), a);
+  UMHS_CHECK_LAUNCH();
+  return UMHS_OK;
 }
 
 // Gradient-dependent half: scatter the records of levels [level_begin, +n_levels) into their buckets and reduce every bucket

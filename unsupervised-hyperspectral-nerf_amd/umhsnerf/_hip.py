@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 9  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
+ABI_VERSION = 10  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
 LIB_PATH = os.environ.get("UMHS_LIB_PATH") or os.path.join(_HERE, "libumhs_hip.so")  # override: A/B builds of tools/ab_lib.sh
 MAX_STREAMS = 4
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "umhs_ssim": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp]),
     "umhs_adam_step_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "umhs_adam_step_rows_range": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _i64, _i64, _vp]),
+    "umhs_hashgrid_fwd_count": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp, _i64, _i64, _vp, C.c_size_t, _vp]),
+    "umhs_hashgrid_bwd_prepare_counted": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "umhs_rgb_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int, _i64]),
     "umhs_rgb_base_fwd": (C.c_int, [_vp] * 6 + [_i64] + [_vp] * 4),
     "umhs_rgb_head_fwd": (C.c_int, [_vp] * 8 + [_i64] + [_vp] * 2),

@@ -192,6 +192,32 @@ def hashgrid_bwd_prepare(pos01, scalings, log2_T: int, level_begin: int = 0, lev
     return True
 
 
+def hashgrid_fwd_count(pos01, table, scalings, log2_T: int):
+    """hashgrid_fwd (level-major) whose launch also takes the bucket histogram of the partitioned backward for the same positions
+    into the cached workspace (reserve_step_workspaces sized it); hashgrid_bwd_prepare_counted finishes the prepare.  None: this
+    shape has no partitioned path."""
+    n = pos01.shape[0]
+    nbytes = _hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, NUM_LEVELS, log2_T)
+    if nbytes == 0 or n == 0:
+        return None
+    ws = _workspace(nbytes, pos01.device, slot=1)
+    enc = torch.empty((NUM_LEVELS, n, 2), device=pos01.device, dtype=torch.float32)
+    sn, sl = enc_strides(n, True)
+    _hip.check(_hip.lib().umhs_hashgrid_fwd_count(ptr(pos01), ptr(table), ptr(scalings), n, NUM_LEVELS, log2_T, ptr(enc), sn, sl, ptr(ws),
+                                                  ws.numel(), _hip.stream()), "umhs_hashgrid_fwd_count")
+    return enc
+
+
+def hashgrid_bwd_prepare_counted(pos01, scalings, log2_T: int) -> bool:
+    """The two scans of hashgrid_bwd_prepare over the histogram hashgrid_fwd_count left in the workspace (all levels)."""
+    n = pos01.shape[0]
+    ws = _workspace(_hip.lib().umhs_hashgrid_bwd_workspace_bytes(n, NUM_LEVELS, log2_T), pos01.device, slot=1)
+    _hip.check(_hip.lib().umhs_hashgrid_bwd_prepare_counted(ptr(pos01), ptr(scalings), n, NUM_LEVELS, log2_T, ptr(ws), ws.numel(),
+                                                            _hip.stream()), "umhs_hashgrid_bwd_prepare_counted")
+    _lease(pos01.device, WS_HASH_BWD, "hashgrid_bwd_prepare")
+    return True
+
+
 def hashgrid_bwd_apply(pos01, d_enc, scalings, log2_T: int, d_table, level_major: bool = True, overwrite: bool = False,
                        level_begin: int = 0, level_count: int = NUM_LEVELS, ws_range=(0, NUM_LEVELS), adam=None):
     """Scatter + reduce of levels [level_begin, +level_count) using the workspace hashgrid_bwd_prepare filled for ws_range.

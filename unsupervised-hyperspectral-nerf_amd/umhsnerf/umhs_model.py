@@ -388,6 +388,7 @@ class UMHSModel(ModelBase):
         flat = f.flat.detach()
         wpos, pos01, sel = ops.positions_fwd(o, d, t0, t1, spec)
         cached = (getattr(ray_samples, "metadata", None) or {}).get("umhs_enc")
+        enc, counted = None, False
         if cached is not None and cached[1].numel() == n:
             enc = ops.enc_gather(cached[0], cached[1])  # encoded once, by the sampler's density query (same positions, same table)
         else:
@@ -484,19 +485,28 @@ class UMHSModel(ModelBase):
                     ops.field_bwd_prepare(spec, flat, n)
                 ev_ready.record(side)  # one event for all three: every cross-stream wait is a barrier packet (~5 us) on main
         cached = (getattr(ray_samples, "metadata", None) or {}).get("umhs_enc")
+        enc, counted = None, False
         if cached is not None and cached[1].numel() == n:
             enc = ops.enc_gather(cached[0], cached[1])  # encoded once, by the sampler's density query (same positions, same table)
         else:
-            enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
+            # The gather kernel has every (sample, level) hashed and its vector ALU idle: the bucket histogram of the hash-grid
+            # backward rides in the same launch (as a kernel of its own it cost 16 us of the step even hidden on the side stream).
+            if side is not None and can_partition and n > 0 and os.environ.get("UMHS_FUSED_COUNT", "1") != "0":
+                enc = ops.hashgrid_fwd_count(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size)
+            if enc is None:
+                enc = ops.hashgrid_fwd(pos01, L.view(flat, "mlp_base.encoder.hash_table"), spec.scalings, L.log2_hashmap_size, True)
+            else:
+                counted = True
         if side is not None:
-            # The bucket histogram is LDS-atomic / VALU heavy: under the (L2-bound) hash gather it cost more than it hid, even
-            # throttled.  It starts when the gather is done and, a few workgroups per level, trickles along under everything up
-            # to the scatter pass of the hash-grid backward, the first kernel that needs it.
+            # What is left of the backward's prepare (the scans; with an encoding taken from the sampler's cache the histogram too,
+            # a few workgroups per level) trickles along under everything up to the scatter pass, the first kernel that needs it.
             ev_hash = torch.cuda.Event()
             ev_hash.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_hash)
-                if can_partition and n > 0:
+                if counted:
+                    prepared = ops.hashgrid_bwd_prepare_counted(pos01, spec.scalings, L.log2_hashmap_size)
+                elif can_partition and n > 0:
                     prepared = ops.hashgrid_bwd_prepare(pos01, spec.scalings, L.log2_hashmap_size)
                 ev_done.record(side)
             main.wait_event(ev_ready)
