@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UMHS_ABI_VERSION 10
+#define UMHS_ABI_VERSION 11
 
 enum {
   UMHS_OK = 0,
@@ -354,26 +354,37 @@ int umhs_ray_train_tail(const float* spectral, const float* M, const float* endm
 /* roi_aabb_host6 = 6 HOST floats (min xyz, max xyz).  Samples have size dt = max(t*cone_angle, step_size) and are   */
 /* emitted while their mid-point lies in an occupied voxel; a run restarts at the voxel entry after empty space.     */
 /* nears / fars: optional per-ray planes [R] (stratified jitter, collider).                                          */
+/* umhs_march_walk (optional, in front of the entry points below): the voxel sequence of every ray -- pure geometry, it never     */
+/* looks at the occupancy -- with one WAVE per ray: lane j starts somewhere inside the ray's range, falls onto the sequential       */
+/* walk at its first voxel face and must land exactly on lane j+1's start (else the window ends there), so the lists are the        */
+/* one-thread-per-ray walk bit for bit (occupied voxels only).  `walked`: umhs_march_walk_workspace_bytes(n_rays) bytes (4.6 KB per ray); pass it to*/
+/* count / write / scratch, which then only replay it (walked == NULL: they walk the grid themselves, one thread per ray).          */
 /* Two passes: umhs_march_count -> counts [R] (caller scans them into packed_info), umhs_march_write -> packed        */
 /* t_starts / t_ends [N] fp32 and ray_indices [N] int64.  umhs_visibility: mask[n] = T_n >= early_stop_eps &&         */
 /* (alpha_thre <= 0 || alpha_n >= alpha_thre) with sigma from the density-only field forward.                        */
 /* ------------------------------------------------------------------------------------------ */
+size_t umhs_march_walk_workspace_bytes(int64_t n_rays);
+int umhs_march_walk(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
+                    const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane, const float* nears,
+                    const float* fars, const float* jitter, float jitter_step, void* walked, size_t walked_bytes,
+                    umhs_stream_t stream);
 int umhs_march_count(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
                      const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
                      float step_size, float cone_angle, const float* nears, const float* fars, const float* jitter,
-                     float jitter_step, int64_t* counts, umhs_stream_t stream);
+                     float jitter_step, int64_t* counts, const void* walked, size_t walked_bytes, umhs_stream_t stream);
 int umhs_march_write(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
                      const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
                      float step_size, float cone_angle, const float* nears, const float* fars, const float* jitter,
                      float jitter_step, const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,
-                     umhs_stream_t stream);
+                     const void* walked, size_t walked_bytes, umhs_stream_t stream);
 /* Single pass instead of count + write: umhs_march_scratch counts AND parks the first `cap` samples of ray r in             */
 /* scratch_t0/t1[r*cap + i]; after the caller's scan, umhs_march_compact moves them to their packed places.  A count > cap     */
 /* means that ray overflowed its row: fall back to umhs_march_write for the batch.                                            */
 int umhs_march_scratch(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
                        const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
                        float step_size, float cone_angle, const float* nears, const float* fars, const float* jitter,
-                       float jitter_step, int cap, int64_t* counts, float* scratch_t0, float* scratch_t1, umhs_stream_t stream);
+                       float jitter_step, int cap, int64_t* counts, float* scratch_t0, float* scratch_t1, const void* walked,
+                       size_t walked_bytes, umhs_stream_t stream);
 int umhs_march_compact(const int64_t* packed_info, int64_t n_rays, int cap, const float* scratch_t0, const float* scratch_t1,
                        float* t_starts, float* t_ends, int64_t* ray_indices, umhs_stream_t stream);
 int umhs_visibility(const float* sigma, const float* t_starts, const float* t_ends, const int64_t* packed_info,

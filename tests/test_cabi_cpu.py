@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(built_library):
         assert hasattr(lib, s), f"{s} declared in umhs_hip.h but not exported"
         assert s in _hip.SIGNATURES, f"{s} has no ctypes signature in umhsnerf/_hip.py"
     assert set(_hip.SIGNATURES) == set(syms)
-    assert _hip.lib().umhs_abi_version() == _hip.ABI_VERSION == 10
+    assert _hip.lib().umhs_abi_version() == _hip.ABI_VERSION == 11
     assert _hip.lib().umhs_strerror(-3) == b"workspace missing or too small"
 
 
@@ -80,7 +80,7 @@ def test_argument_errors_are_reported_before_anything_is_launched():
     assert lib.umhs_compact_samples(*([None] * 3), 4, *([None] * 13)) == ARG
     assert lib.umhs_compact_samples(*([None] * 3), 0, *([None] * 13)) == 0
     assert lib.umhs_visibility_count(dummy, dummy, dummy, dummy, 4, 16, 1e-4, 0.01, dummy, None, None) == ARG  # kept[] missing
-    assert lib.umhs_march_scratch(None, None, 8, None, None, 1, 16, 0.05, 1e3, 0.01, 0.0, None, None, None, 0.0, 8, None, None, None, None) == ARG
+    assert lib.umhs_march_scratch(None, None, 8, None, None, 1, 16, 0.05, 1e3, 0.01, 0.0, None, None, None, 0.0, 8, None, None, None, None, 0, None) == ARG
     assert lib.umhs_hashgrid_fwd(None, None, None, 16, 16, 19, None, 2, 0, None) == ARG
     assert lib.umhs_hashgrid_fwd(dummy, ctypes.c_void_p(4096 + 8), dummy, 16, 16, 19, dummy, 2, 0, None) == ARG  # table not 16-byte aligned
     assert lib.umhs_hashgrid_bwd_apply_adam(dummy, dummy, 2, 0, dummy, 0, 0, 16, 0, 16, 19, dummy, dummy, 1 << 20, dummy, dummy, dummy,

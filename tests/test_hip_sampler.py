@@ -66,6 +66,64 @@ def test_marcher_matches_oracle(levels, res, cone, step, far):
         assert torch.equal(ri2, ri) and torch.equal(s2, s) and torch.equal(e2, e) and torch.equal(p2, pinfo), cap
 
 
+def _env(**kv):
+    import contextlib
+    import os
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: os.environ.get(k) for k in kv}
+        os.environ.update({k: str(v) for k, v in kv.items()})
+        try:
+            yield
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+    return cm()
+
+
+@pytest.mark.parametrize("levels,res,cone,per_ray", [(4, 128, 0.004, False), (4, 128, 0.0, True), (1, 64, 0.004, True), (6, 32, 0.01, False)])
+def test_walk_split_over_the_lanes_of_a_wave_is_the_serial_walk_bit_for_bit(levels, res, cone, per_ray):
+    """The default march takes the voxel walk out of the one-thread-per-ray kernel: umhs_march_walk gives every ray a wave, every lane a
+    start somewhere in the ray's range; a lane falls onto the sequential walk at its first voxel face and must land EXACTLY on the next
+    lane's start, else the window ends there; the emission kernel replays the lists.  UMHS_MARCH_SERIAL=1 is the form the oracle is
+    written in (test_marcher_matches_oracle pins both to it on small grids).  Here: the bench scene's grid shape and a few thousand
+    rays, a blob + noise occupancy, optional per-ray near / far planes and jitter -- identical samples, also with the lanes' voxel
+    budget cut to 1 / 2 / 5 (many windows, lanes that run out in front of the next lane's start), with lists too short for the ray
+    (the emission kernel walks on by itself from where the list ends) and in the two-pass form."""
+    from umhsnerf.sampler import march_rays
+
+    R = 3000
+    g = torch.Generator().manual_seed(levels * 7 + res)
+    ax = torch.linspace(-1, 1, res)
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    blob = ((X * X + Y * Y * 1.7 + Z * Z) < 0.35)
+    binaries = torch.stack([(blob if l == 0 else torch.zeros_like(blob)) | (torch.rand(res, res, res, generator=g) < (0.02 if l else 0.05)) for l in range(levels)])
+    o, d = _rays(R, seed=res + 1)
+    o[:64] = o[:64] * 40.0  # far outside: most of them miss the grid or cross it far from the centre
+    d[64:96, 0] *= 0.004  # almost parallel to a grid axis: the walk creeps ulp by ulp at the faces of that axis
+    d[64:96] = d[64:96] / d[64:96].norm(dim=-1, keepdim=True)
+    roi = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+    kw = {}
+    if per_ray:
+        kw = dict(nears=torch.rand(R, generator=g) * 0.5, fars=2.0 + torch.rand(R, generator=g) * 8.0, jitter=torch.rand(R, generator=g), jitter_step=0.005)
+        kw = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    bin_u8 = binaries.to(torch.uint8).to(DEV)
+    args = (o.to(DEV), d.to(DEV), bin_u8, roi, levels, res, 0.05, 1e3, 0.005, cone)
+    with _env(UMHS_MARCH_SERIAL=1):
+        ref = march_rays(*args, **kw)
+    assert ref[0].shape[0] > 50 * R // 8
+    for knobs in ({}, dict(UMHS_MARCH_VSEG=1), dict(UMHS_MARCH_VSEG=2), dict(UMHS_MARCH_VSEG=5), dict(UMHS_MARCH_VCAP=16), dict(UMHS_MARCH_VCAP=128, UMHS_MARCH_VSEG=3),
+                  dict(UMHS_MARCH_VCAP=64), dict(UMHS_MARCH_CAP=0), dict(UMHS_MARCH_CAP=8, UMHS_MARCH_VCAP=96)):
+        with _env(**knobs):
+            got = march_rays(*args, **kw)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), knobs
+
+
 def test_visibility_matches_oracle():
     from umhsnerf import ops
     from umhsnerf.sampler import visibility_mask

@@ -25,7 +25,7 @@ counts = torch.empty(R, dtype=torch.int64, device=o.device)
 roi = (C.c_float * 6)(*g._roi)
 c = m.config
 print("levels", g.levels, "res", g.res, "roi", g._roi, "near", c.near_plane, "far", c.far_plane, "step", c.render_step_size, "cone", c.cone_angle, "occupied frac", float(g.binaries.float().mean()))
-_hip.check(_hip.lib().umhs_march_count(ptr(o), ptr(d), R, ptr(g.binaries.view(torch.uint8)), roi, g.levels, g.res, c.near_plane, c.far_plane if c.far_plane else 1e10, c.render_step_size, c.cone_angle, None, None, None, 0.0, ptr(counts), _hip.stream()), "x")
+_hip.check(_hip.lib().umhs_march_count(ptr(o), ptr(d), R, ptr(g.binaries.view(torch.uint8)), roi, g.levels, g.res, c.near_plane, c.far_plane if c.far_plane else 1e10, c.render_step_size, c.cone_angle, None, None, None, 0.0, ptr(counts), None, 0, _hip.stream()), "x")
 cc = counts.float().cpu()
 print("per-ray value: mean %.1f median %.1f p99 %.1f max %.0f" % (cc.mean(), cc.median(), cc.quantile(0.99), cc.max()))
 def timeit(fn, reps=20):
@@ -37,7 +37,7 @@ def timeit(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 lib = _hip.lib()
-call = lambda: lib.umhs_march_count(ptr(o), ptr(d), R, ptr(g.binaries.view(torch.uint8)), roi, g.levels, g.res, c.near_plane, 1000.0, c.render_step_size, c.cone_angle, None, None, None, 0.0, ptr(counts), _hip.stream())
+call = lambda: lib.umhs_march_count(ptr(o), ptr(d), R, ptr(g.binaries.view(torch.uint8)), roi, g.levels, g.res, c.near_plane, 1000.0, c.render_step_size, c.cone_angle, None, None, None, 0.0, ptr(counts), None, 0, _hip.stream())
 print("march_count, empty grid: %.1f us" % timeit(call))
 g.mark_all_occupied()
 print("march_count, full grid : %.1f us  (samples/ray mean %.0f)" % (timeit(call), float(counts.float().mean())))

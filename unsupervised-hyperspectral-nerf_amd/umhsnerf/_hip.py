@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 10  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
+ABI_VERSION = 11  # include/umhs_hip.h UMHS_ABI_VERSION: bumped with every signature change
 LIB_PATH = os.environ.get("UMHS_LIB_PATH") or os.path.join(_HERE, "libumhs_hip.so")  # override: A/B builds of tools/ab_lib.sh
 MAX_STREAMS = 4
 
@@ -93,9 +93,11 @@ SIGNATURES = {
     "umhs_ray_epilogue_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "umhs_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp]),
     "umhs_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "umhs_march_count": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, _vp, _vp]),
-    "umhs_march_write": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "umhs_march_scratch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, C.c_int, _vp, _vp, _vp, _vp]),
+    "umhs_march_walk_workspace_bytes": (C.c_size_t, [_i64]),
+    "umhs_march_walk": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _vp, _vp, _vp, _f32, _vp, C.c_size_t, _vp]),
+    "umhs_march_count": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, _vp, _vp, C.c_size_t, _vp]),
+    "umhs_march_write": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "umhs_march_scratch": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(_f32), C.c_int, C.c_int, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _f32, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "umhs_march_compact": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "umhs_visibility": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "umhs_visibility_count": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp, _vp]),

@@ -21,35 +21,36 @@ from ._hip import ptr
 from ._ns_compat import RayBundle, RaySamples, packed_ray_samples
 
 
-_scratch_pool = {}  # device index -> [(t_starts rows, t_ends rows, event of the last reader)]
+_scratch_pool = {}  # device index -> [(t_starts rows, t_ends rows, voxel lists, event of the last reader)]
 
 
-def _scratch_acquire(n: int, dev) -> Tuple[Tensor, Tensor]:
-    """[R, cap] scratch rows of the single-pass march.  A march in flight owns its pair (a prefetched march and an eval-time march
-    may be outstanding together); ``_scratch_release`` hands it back once the compaction that read it has been issued."""
+def _scratch_acquire(n: int, nwalk: int, dev) -> Tuple[Tensor, Tensor, Tensor]:
+    """[R, cap] scratch rows of the single-pass march + the ``nwalk`` bytes of voxel lists of ``umhs_march_walk``.  A march in flight
+    owns its set (a prefetched march and an eval-time march may be outstanding together); ``_scratch_release`` hands it back once
+    the compaction that read it has been issued."""
     pool = _scratch_pool.setdefault(dev.index or 0, [])
     cur = torch.cuda.current_stream(dev)
-    for i, (a, b, ev) in enumerate(pool):
-        if a.numel() >= n:
+    for i, (a, b, w, ev) in enumerate(pool):
+        if a.numel() >= n and w.numel() >= nwalk:
             pool.pop(i)
             cur.wait_event(ev)
-            _use_on(cur, a, b)
-            return a, b
+            _use_on(cur, a, b, w)
+            return a, b, w
     pool.clear()  # too small for this batch size: let them go
-    return torch.empty(n, device=dev), torch.empty(n, device=dev)
+    return torch.empty(n, device=dev), torch.empty(n, device=dev), torch.empty(nwalk, device=dev, dtype=torch.uint8)
 
 
-def _scratch_release(pair, dev) -> None:
+def _scratch_release(trio, dev) -> None:
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    _scratch_pool.setdefault(dev.index or 0, []).append((pair[0], pair[1], ev))
+    _scratch_pool.setdefault(dev.index or 0, []).append((trio[0], trio[1], trio[2], ev))
 
 
 class MarchHandle:
     """A ray march in flight (``march_begin``): the walk has been issued, the sample count is on its way to the host."""
 
-    __slots__ = ("o", "d", "R", "bin", "args", "nears", "fars", "jitter", "cap", "scratch", "counts", "packed_info", "stats", "host",
-                 "event", "stream")
+    __slots__ = ("o", "d", "R", "bin", "args", "nears", "fars", "jitter", "cap", "scratch", "walked", "counts", "packed_info", "stats",
+                 "host", "event", "stream")
 
 
 def _use_on(stream, *tensors) -> None:
@@ -96,17 +97,23 @@ def march_begin(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aa
     h.counts = torch.empty((h.R,), device=dev, dtype=torch.int64)
     h.cap = int(os.environ.get("UMHS_MARCH_CAP", "1024"))  # scratch row per ray of the single-pass form (0: always two passes)
     h.stream = torch.cuda.current_stream(dev)
-    h.scratch = _scratch_acquire(h.R * h.cap, dev) if (h.cap > 0 and h.R > 0) else None
     lib = _hip.lib()
     roi = h.args[0]
-    if h.scratch is not None:  # one walk: counts + the samples themselves parked in [R, cap] rows
+    # the walk on its own, one wave per ray (UMHS_MARCH_SERIAL=1: the emission kernel walks the grid itself, one thread per ray)
+    nwalk = lib.umhs_march_walk_workspace_bytes(h.R) if os.environ.get("UMHS_MARCH_SERIAL", "0") != "1" else 0
+    h.scratch = _scratch_acquire(h.R * h.cap, nwalk, dev) if h.R > 0 else None
+    h.walked = (h.scratch[2], nwalk) if (h.scratch is not None and nwalk > 0) else (None, 0)
+    if h.walked[0] is not None:
+        _hip.check(lib.umhs_march_walk(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, ptr(h.nears), ptr(h.fars),
+                                       ptr(h.jitter[0]), h.jitter[1], ptr(h.walked[0]), h.walked[1], _hip.stream()), "umhs_march_walk")
+    if h.scratch is not None and h.cap > 0:  # one emission pass: counts + the samples themselves parked in [R, cap] rows
         _hip.check(lib.umhs_march_scratch(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone, ptr(h.nears),
-                                          ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], h.cap, ptr(h.counts), ptr(h.scratch[0]), ptr(h.scratch[1]), _hip.stream()),
-                   "umhs_march_scratch")
+                                          ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], h.cap, ptr(h.counts), ptr(h.scratch[0]), ptr(h.scratch[1]),
+                                          ptr(h.walked[0]), h.walked[1], _hip.stream()), "umhs_march_scratch")
     else:
         _hip.check(lib.umhs_march_count(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone,
-                                        ptr(h.nears), ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], ptr(h.counts), _hip.stream()),
-                   "umhs_march_count")
+                                        ptr(h.nears), ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], ptr(h.counts), ptr(h.walked[0]), h.walked[1],
+                                        _hip.stream()), "umhs_march_count")
     h.packed_info, h.stats = ray_prefix(h.counts)
     # the sample count sizes the outputs: one host sync per batch, as in nerfacc (the row-overflow flag rides along)
     h.host = torch.zeros(2, dtype=torch.int64).pin_memory()
@@ -132,13 +139,13 @@ def march_finish(h: MarchHandle):
     if n > 0:
         lib = _hip.lib()
         roi, levels, resolution, near, far, step, cone = h.args
-        if h.scratch is not None and cmax <= h.cap:
+        if h.scratch is not None and h.cap > 0 and cmax <= h.cap:
             _hip.check(lib.umhs_march_compact(ptr(h.packed_info), h.R, h.cap, ptr(h.scratch[0]), ptr(h.scratch[1]), ptr(t0), ptr(t1), ptr(ri),
                                               _hip.stream()), "umhs_march_compact")
-        else:  # some ray overflowed its scratch row: second walk writing straight to the packed places
+        else:  # some ray overflowed its scratch row: second emission pass writing straight to the packed places
             _hip.check(lib.umhs_march_write(ptr(h.o), ptr(h.d), h.R, ptr(h.bin), roi, levels, resolution, near, far, step, cone,
                                             ptr(h.nears), ptr(h.fars), ptr(h.jitter[0]), h.jitter[1], ptr(h.packed_info), ptr(t0),
-                                            ptr(t1), ptr(ri), _hip.stream()),
+                                            ptr(t1), ptr(ri), ptr(h.walked[0]), h.walked[1], _hip.stream()),
                        "umhs_march_write")
     if h.scratch is not None:
         _scratch_release(h.scratch, dev)
