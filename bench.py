@@ -95,7 +95,8 @@ def trained_like_init(field, seed):
 
 
 # operators that have a roofline entry (the dominant one of them is timed live inside the timed region)
-ROOFLINE_OPS = ("field_bwd", "hashgrid_bwd_apply", "hashgrid_bwd", "field_fwd", "field_heads_fwd", "hashgrid_fwd", "composite_fwd", "composite_bwd")
+ROOFLINE_OPS = ("field_bwd", "hashgrid_bwd_apply", "hashgrid_bwd", "field_fwd", "field_heads_fwd", "hashgrid_fwd", "hashgrid_fwd_count", "composite_fwd",
+                "composite_bwd")
 
 
 class KernelTimer:
@@ -331,9 +332,9 @@ def sampler_step(cfg, device, pipe, steps=40, warm=300):
                               frac=round(ach / HBM_PEAK_GBS, 4), ms_per_step=round(t, 4)))
 
     if n_cand:
-        # march: one dependent chain of ~150 instructions per voxel per ray -- bound by the LATENCY of its longest ray, not by bytes
-        # and not by occupancy (rays per wave 16 / 8 / 4 / 2: sample() 1.44 / 1.45 / 1.46 / 1.77 ms); it runs one step
-        # ahead on its own stream.  Reported as what it is: voxels walked per second, no peak to divide by.
+        # march: the walk is one wave per ray (lanes = segments of the ray, 0.03 ms), the sample emission one dependent chain per ray
+        # (t += max(t * cone, step) in float): bound by the LATENCY of the longest ray's chain, not by bytes; it runs one
+        # step ahead on its own stream.  Reported as what it is: candidates per second, no peak to divide by.
         t_m = sum(per_step.get(o, 0.0) for o in ("march_begin", "march_finish"))
         if t_m > 0:
             roofs.append(dict(kernel="march (walk + compaction)", operators=["march_begin", "march_finish"], bound="latency (longest ray's chain)",
@@ -472,7 +473,8 @@ def roofline_tables(case, ksum, dom, world, config_name):
     # levels 5..15, the same bytes the separate adam_step would move -- so that operator's algorithmic bytes include them)
     sink = getattr(pipe.model.field, "_grad_sink", None)
     fused_adam_bytes = 28 * (16 - int(getattr(sink, "sparse_levels", 0) or 0)) * (1 << 19) * 2 if world == 1 else 0
-    alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12),
+    # (hashgrid_fwd_count = the gather with the backward's bucket histogram in the same launch: the gather's bytes, nothing added)
+    alg_bytes = {"hashgrid_fwd": N * (1024 + 128 + 12), "hashgrid_fwd_count": N * (1024 + 128 + 12), "hashgrid_bwd": N * (1024 + 128 + 12),
                  "hashgrid_bwd_apply": N * (1024 + 128 + 12) + fused_adam_bytes,
                  # (above 32 bands the compositing pass carries no value stream -- the band sums are formed inside the heads kernel and
                  # the value half of its backward inside field_bwd, DESIGN 4.3: sigma, t0, t1 in, weights out + two floats per ray)
@@ -497,6 +499,7 @@ def roofline_tables(case, ksum, dom, world, config_name):
     op_kernels = {"field_bwd": ("field_bwd_tf_kernel", "field_bwd_tfz0_kernel", "field_bwd_tfz1_kernel", "field_slab_fold", "field_reduce_tf", "field_mix_"),
                   "field_fwd": ("field_fwd_kernel", "field_pack_all"), "field_base_fwd": ("field_fwd_kernel<false, true",),
                   "field_heads_fwd": ("field_fwd_kernel", "field_heads_finish"), "hashgrid_fwd": ("hashgrid_fwd_kernel",),
+                  "hashgrid_fwd_count": ("hashgrid_fwd_count_kernel",),
                   "hashgrid_bwd": ("hg_partition_kernel", "hg_reduce_kernel", "hg_scan_kernel", "hg_pairs_kernel", "hg_level_absmax"),
                   "hashgrid_bwd_apply": ("hg_partition_kernel<true>", "hg_reduce_kernel", "hg_pairs_kernel<true>", "hg_level_absmax"),
                   "adam_step": ("adam_kernel",),
