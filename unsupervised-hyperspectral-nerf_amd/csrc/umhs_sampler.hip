@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64, 4) void march_kernel(MarchArgs a, int rpw) {
   if (t < t_end) {
     bool continuous = false, left_grid = false;
     float t_last = t;
+    float q0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the samples of the scratch row's current group of four
     // one voxel [entry, t_clip) of the walk: samples while their mid-point lies inside it, if it is occupied
     auto emit = [&](const float entry, const float t_clip, const bool occupied) __attribute__((always_inline)) {
       if (occupied) {
@@ -153,8 +154,16 @@ __global__ __launch_bounds__(64, 4) void march_kernel(MarchArgs a, int rpw) {
           if (WRITE) {
             a.t_starts[w] = t_last, a.t_ends[w] = t_last + dt, a.ray_indices[w] = r;
             ++w;
-          } else if (a.cap > 0 && cnt < a.cap) {  // single pass: park the sample in the ray's scratch row
-            a.t_starts[r * a.cap + cnt] = t_last, a.t_ends[r * a.cap + cnt] = t_last + dt;
+          } else if (a.cap > 0) {
+            // single pass: park the sample in the ray's scratch row -- four at a time (a batch of 32 k rays issued 2 x 10 M four-byte
+            // stores to 16 different lines per instruction: the L2's request rate, not its bytes, was the emission's bound there)
+            const int slot = (int)cnt & 3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q0[u] = slot == u ? t_last : q0[u], q1[u] = slot == u ? t_last + dt : q1[u];
+            if (slot == 3 && cnt < a.cap) {
+              *reinterpret_cast<float4*>(a.t_starts + r * a.cap + (cnt - 3)) = make_float4(q0[0], q0[1], q0[2], q0[3]);
+              *reinterpret_cast<float4*>(a.t_ends + r * a.cap + (cnt - 3)) = make_float4(q1[0], q1[1], q1[2], q1[3]);
+            }
           }
           ++cnt;
           t_last = t_last + dt;
@@ -235,6 +244,10 @@ __global__ __launch_bounds__(64, 4) void march_kernel(MarchArgs a, int rpw) {
 #pragma unroll
       for (int k = 0; k < KB; ++k)
         if (k < na) emit(at0[k], atc[k], aocc[k] != 0);
+    }
+    if (!WRITE && a.cap > 0 && (cnt & 3) != 0 && (cnt & ~(int64_t)3) < a.cap) {  // the last, partial group (the row's tail is never read)
+      *reinterpret_cast<float4*>(a.t_starts + r * a.cap + (cnt & ~(int64_t)3)) = make_float4(q0[0], q0[1], q0[2], q0[3]);
+      *reinterpret_cast<float4*>(a.t_ends + r * a.cap + (cnt & ~(int64_t)3)) = make_float4(q1[0], q1[1], q1[2], q1[3]);
     }
   }
 #ifdef MARCH_DEBUG_ITERS  // diagnostic build only: voxel steps instead of sample counts
@@ -553,7 +566,8 @@ extern "C" int umhs_march_scratch(const float* origins, const float* directions,
                       step_size, cone_angle, nears, fars, jitter, jitter_step);
   if (rc) return rc;
   if (n_rays == 0) return UMHS_OK;
-  if (!counts || !scratch_t0 || !scratch_t1 || cap < 1) return UMHS_ERR_ARG;
+  if (!counts || !scratch_t0 || !scratch_t1 || cap < 4 || (cap & 3) != 0) return UMHS_ERR_ARG;  // (rows are written four samples at a time)
+  if (((uintptr_t)scratch_t0 & 15) || ((uintptr_t)scratch_t1 & 15)) return UMHS_ERR_ARG;
   a.counts = counts, a.t_starts = scratch_t0, a.t_ends = scratch_t1, a.cap = cap;
   rc = march_use_walked(&a, walked, walked_bytes);
   if (rc) return rc;
