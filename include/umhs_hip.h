@@ -379,8 +379,7 @@ int umhs_march_write(const float* origins, const float* directions, int64_t n_ra
                      const void* walked, size_t walked_bytes, umhs_stream_t stream);
 /* Single pass instead of count + write: umhs_march_scratch counts AND parks the first `cap` samples of ray r in             */
 /* scratch_t0/t1[r*cap + i]; after the caller's scan, umhs_march_compact moves them to their packed places.  A count > cap     */
-/* means that ray overflowed its row: fall back to umhs_march_write for the batch.  cap: a multiple of 4, rows 16-byte aligned   */
-/* (samples are parked four at a time; what lies behind a ray's count in its row is unspecified).                            */
+/* means that ray overflowed its row (whose last slot then holds garbage): fall back to umhs_march_write for the batch.       */
 int umhs_march_scratch(const float* origins, const float* directions, int64_t n_rays, const uint8_t* binaries,
                        const float* roi_aabb_host6, int levels, int resolution, float near_plane, float far_plane,
                        float step_size, float cone_angle, const float* nears, const float* fars, const float* jitter,

@@ -141,32 +141,41 @@ __global__ __launch_bounds__(64, 4) void march_kernel(MarchArgs a, int rpw) {
   if (t < t_end) {
     bool continuous = false, left_grid = false;
     float t_last = t;
-    float q0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the samples of the scratch row's current group of four
+    int cnt32 = 0;  // (count / scratch forms: a ray has at most 2^31 samples)
+    float* __restrict__ row0 = a.t_starts + r * a.cap;
+    float* __restrict__ row1 = a.t_ends + r * a.cap;
     // one voxel [entry, t_clip) of the walk: samples while their mid-point lies inside it, if it is occupied
     auto emit = [&](const float entry, const float t_clip, const bool occupied) __attribute__((always_inline)) {
       if (occupied) {
         if (!continuous) t_last = entry;
-        // (four speculative samples per round -- the recurrence 4 deep without a branch, unconditional stores into the scratch row --
-        //  measured SLOWER than this loop: 151 vs 127 us at 16 rays per wave, 122 vs 88 at one)
-        while (true) {
-          const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
-          if (!(t_last + dt * 0.5f < t_clip)) break;
-          if (WRITE) {
+        // One compare -> exec mask -> branch round trip per sample and nothing else divergent inside: the scratch row takes every
+        // sample unconditionally (a ray with more than `cap` keeps overwriting its row's last slot -- its count then sends the batch
+        // to the write pass anyway).  (Four speculative samples per round without a branch measured SLOWER: 151 vs 127 us at 16 rays
+        // per wave; four-sample store groups: neutral.)
+        if (WRITE) {
+          while (true) {
+            const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
+            if (!(t_last + dt * 0.5f < t_clip)) break;
             a.t_starts[w] = t_last, a.t_ends[w] = t_last + dt, a.ray_indices[w] = r;
-            ++w;
-          } else if (a.cap > 0) {
-            // single pass: park the sample in the ray's scratch row -- four at a time (a batch of 32 k rays issued 2 x 10 M four-byte
-            // stores to 16 different lines per instruction: the L2's request rate, not its bytes, was the emission's bound there)
-            const int slot = (int)cnt & 3;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q0[u] = slot == u ? t_last : q0[u], q1[u] = slot == u ? t_last + dt : q1[u];
-            if (slot == 3 && cnt < a.cap) {
-              *reinterpret_cast<float4*>(a.t_starts + r * a.cap + (cnt - 3)) = make_float4(q0[0], q0[1], q0[2], q0[3]);
-              *reinterpret_cast<float4*>(a.t_ends + r * a.cap + (cnt - 3)) = make_float4(q1[0], q1[1], q1[2], q1[3]);
-            }
+            ++w, ++cnt;
+            t_last = t_last + dt;
           }
-          ++cnt;
-          t_last = t_last + dt;
+        } else if (a.cap > 0) {
+          while (true) {
+            const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
+            if (!(t_last + dt * 0.5f < t_clip)) break;
+            const int at = min(cnt32, a.cap - 1);
+            row0[at] = t_last, row1[at] = t_last + dt;
+            ++cnt32;
+            t_last = t_last + dt;
+          }
+        } else {
+          while (true) {
+            const float dt = fminf(fmaxf(t_last * a.cone, a.step), BIG);
+            if (!(t_last + dt * 0.5f < t_clip)) break;
+            ++cnt32;
+            t_last = t_last + dt;
+          }
         }
         continuous = true;
       } else {
@@ -245,10 +254,7 @@ __global__ __launch_bounds__(64, 4) void march_kernel(MarchArgs a, int rpw) {
       for (int k = 0; k < KB; ++k)
         if (k < na) emit(at0[k], atc[k], aocc[k] != 0);
     }
-    if (!WRITE && a.cap > 0 && (cnt & 3) != 0 && (cnt & ~(int64_t)3) < a.cap) {  // the last, partial group (the row's tail is never read)
-      *reinterpret_cast<float4*>(a.t_starts + r * a.cap + (cnt & ~(int64_t)3)) = make_float4(q0[0], q0[1], q0[2], q0[3]);
-      *reinterpret_cast<float4*>(a.t_ends + r * a.cap + (cnt & ~(int64_t)3)) = make_float4(q1[0], q1[1], q1[2], q1[3]);
-    }
+    if (!WRITE) cnt = cnt32;
   }
 #ifdef MARCH_DEBUG_ITERS  // diagnostic build only: voxel steps instead of sample counts
   if (!WRITE) a.counts[r] = iters;
@@ -566,8 +572,7 @@ extern "C" int umhs_march_scratch(const float* origins, const float* directions,
                       step_size, cone_angle, nears, fars, jitter, jitter_step);
   if (rc) return rc;
   if (n_rays == 0) return UMHS_OK;
-  if (!counts || !scratch_t0 || !scratch_t1 || cap < 4 || (cap & 3) != 0) return UMHS_ERR_ARG;  // (rows are written four samples at a time)
-  if (((uintptr_t)scratch_t0 & 15) || ((uintptr_t)scratch_t1 & 15)) return UMHS_ERR_ARG;
+  if (!counts || !scratch_t0 || !scratch_t1 || cap < 1) return UMHS_ERR_ARG;
   a.counts = counts, a.t_starts = scratch_t0, a.t_ends = scratch_t1, a.cap = cap;
   rc = march_use_walked(&a, walked, walked_bytes);
   if (rc) return rc;

@@ -95,7 +95,7 @@ def march_begin(origins: Tensor, directions: Tensor, binaries_u8: Tensor, roi_aa
     h.fars = _hip.f32c(fars) if fars is not None else None
     h.jitter = (_hip.f32c(jitter), float(jitter_step)) if jitter is not None else (None, 0.0)
     h.counts = torch.empty((h.R,), device=dev, dtype=torch.int64)
-    h.cap = (int(os.environ.get("UMHS_MARCH_CAP", "1024")) + 3) & ~3  # scratch row per ray of the single-pass form (0: always two passes)
+    h.cap = int(os.environ.get("UMHS_MARCH_CAP", "1024"))  # scratch row per ray of the single-pass form (0: always two passes)
     h.stream = torch.cuda.current_stream(dev)
     lib = _hip.lib()
     roi = h.args[0]
