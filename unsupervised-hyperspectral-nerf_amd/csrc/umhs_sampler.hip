@@ -22,9 +22,10 @@ struct MarchArgs {
   float *t_starts, *t_ends;
   int64_t* ray_indices;
   int cap;  // single-pass mode (count kernel with scratch): the first `cap` samples of ray r go to t_starts/t_ends[r * cap + i]
-  // lists of umhs_march_walk (all NULL: the kernel walks the grid itself): the OCCUPIED voxels of the first vox_nv[r] voxels of ray r in
-  // walk order -- entry parameter, clipped exit parameter, whether the voxel in front of it was occupied too (the run of samples
-  // continues) --, the chain value behind those voxels, flags (1: the walk ended there, 2: the last of them was occupied)
+  // lists of umhs_march_walk (all NULL: the kernel walks the grid itself): the RUNS of consecutive occupied voxels among the first
+  // vox_nv[r] voxels of ray r in walk order -- entry parameter of the run's first voxel, clipped exit parameter of its last, whether it
+  // goes on from the entry in front of it (a run cut by a window of the walk: no reset of the sample recurrence) --, the chain value
+  // behind those voxels, flags (1: the walk ended there, 2: the last of them was occupied)
   const float* vox_a;
   const float* vox_b;
   const uint8_t* vox_c;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64, 4) void march_kernel(MarchArgs a, int rpw) {
 // step stops; the following windows give lane j the chain value j ulps ahead and one step each: 64 creeping steps per window.  The s_j divide the
 // remaining range evenly in VOXELS, not in t (level l voxels are 2^l wide: the ray's intervals inside the nested level boxes give a
 // piecewise-linear voxel measure).  The occupancy bytes are fetched by the walking lanes (nothing waits for them).  The voxels go to
-// OCCUPIED ones (a fifth of them on the bench scene) go to the ray's list [vcap]; march_kernel replays it (emission on one lane of the walking wave was measured first: 15 k single-lane
+// runs of occupied ones go to the ray's list [vcap] (start, end; ~20 per ray); march_kernel replays it (emission on one lane of the walking wave was measured first: 15 k single-lane
 // instructions per ray, 0.26 ms for 4,096 rays and no faster than the serial marcher at 32,768 -- issue slots, not latency).
 #define MARCH_VSEG 12
 __device__ __forceinline__ float march_segment_start(const RayGeo& g, const float cur, const int lane) {
@@ -396,16 +397,34 @@ __global__ __launch_bounds__(64) void march_walk_kernel(MarchArgs a, WalkOut out
       const bool joined = !mine || tt == nb || (nb == INFINITY && (lleft || !(tt < t_end)));
       const uint64_t open = __builtin_amdgcn_ballot_w64(!joined);
       const int J = open ? (int)__builtin_ctzll(open) : 63;  // lanes 0 .. J are the sequential walk
-      // lanes 0 .. J in order are the next voxels of the walk; the occupied ones go to the list
+      // Lanes 0 .. J in order are the next voxels of the walk.  The list takes one entry per RUN of consecutive occupied voxels (the
+      // emission only looks at a run's first entry parameter and its last exit: within a run the sample recurrence goes on from voxel
+      // to voxel and "mid-point < exit" with the growing exit stops at the same sample) -- a run that crosses lanes is followed with
+      // ballots to the lane it ends in; one that began in an earlier window goes on as an entry flagged "continues".
       const int ne = lane <= J ? n : 0;
       uint32_t obits = 0;
 #pragma unroll
       for (int i = 0; i < MARCH_VSEG; ++i) obits |= (i < ne && occ[i] != 0 ? 1u : 0u) << i;
-      const bool lastocc = ne > 0 && ((obits >> (ne - 1)) & 1u) != 0;
-      const uint64_t nonempty = __builtin_amdgcn_ballot_w64(ne > 0), lastm = __builtin_amdgcn_ballot_w64(lastocc);
-      const uint64_t lower = nonempty & ((1ull << lane) - 1ull);
+      const bool F = (obits & 1u) != 0;                                                // first voxel occupied
+      const bool L = ne > 0 && ((obits >> (ne - 1)) & 1u) != 0;                       // last voxel occupied
+      const bool A = ne > 0 && obits == ((1u << ne) - 1u);                            // all of them
+      const uint64_t nonempty = __builtin_amdgcn_ballot_w64(ne > 0), lastm = __builtin_amdgcn_ballot_w64(L), firstm = __builtin_amdgcn_ballot_w64(F);
+      const uint64_t lower = nonempty & ((1ull << lane) - 1ull), higher = lane < 63 ? nonempty & ~((2ull << lane) - 1ull) : 0ull;
       const bool pred = lower ? ((lastm >> (63 - __builtin_clzll(lower))) & 1ull) != 0 : carry;  // the voxel in front of this lane's first
-      const int no = __builtin_popcount(obits);
+      const bool link = L && higher != 0 && ((firstm >> __builtin_ctzll(higher)) & 1ull) != 0;   // this lane's last run goes on in the next lane
+      const uint64_t stops = __builtin_amdgcn_ballot_w64(ne > 0 && !(A && link));                 // lanes a run that enters them ends in
+      float fse = tclip[0];  // exit of the run that starts at this lane's first voxel
+#pragma unroll
+      for (int i = 1; i < MARCH_VSEG; ++i)
+        if ((obits & ((2u << i) - 1u)) == ((2u << i) - 1u)) fse = tclip[i];
+      const uint64_t after = lane < 63 ? stops & ~((2ull << lane) - 1ull) : 0ull;
+      const float chain_end = __shfl(fse, after ? (int)__builtin_ctzll(after) : lane, 64);  // (read only when link: then `after` is not empty)
+      // this lane's entries: every run that starts inside it, and its first run if that one starts a run of the ray (no occupied voxel
+      // in front of it) or goes on from the previous window (first lane with voxels: entry flagged "continues")
+      const uint32_t starts = obits & ~(obits << 1);
+      const bool first_emits = F && (!pred || lower == 0);
+      const uint32_t emits = (starts & ~1u) | (first_emits ? 1u : 0u);
+      const int no = __builtin_popcount(emits);
       int incl = no, vincl = ne;
 #pragma unroll
       for (int dd = 1; dd < 64; dd <<= 1) {
@@ -415,13 +434,25 @@ __global__ __launch_bounds__(64) void march_walk_kernel(MarchArgs a, WalkOut out
       const int sum = __shfl(incl, 63, 64);
       if (total + sum > out.vcap) break;  // (uniform) the list is full: the emission kernel walks on from cur by itself
       int at = total + incl - no;
+      {
+        bool open_run = false, emit_it = false, cont_it = false;
+        float run_start = 0.0f;
 #pragma unroll
-      for (int i = 0; i < MARCH_VSEG; ++i) {
-        if ((obits >> i) & 1u) {
-          va[at] = i == 0 ? b : tclip[i > 0 ? i - 1 : 0];
-          vb[at] = tclip[i];
-          vc[at] = (i == 0 ? pred : ((obits >> (i > 0 ? i - 1 : 0)) & 1u) != 0) ? 1 : 0;
-          ++at;
+        for (int i = 0; i < MARCH_VSEG; ++i) {
+          const bool bit = ((obits >> i) & 1u) != 0;
+          if (bit && !open_run) {
+            open_run = true, run_start = i == 0 ? b : tclip[i > 0 ? i - 1 : 0];
+            emit_it = ((emits >> i) & 1u) != 0, cont_it = i == 0 && pred;
+          }
+          if (open_run && !((obits >> (i + 1)) & 1u)) {  // the run ends with voxel i (obits has no bit at or above ne)
+            if (emit_it) {
+              va[at] = run_start;
+              vb[at] = (i == ne - 1 && link) ? chain_end : tclip[i];
+              vc[at] = cont_it ? 1 : 0;
+              ++at;
+            }
+            open_run = false;
+          }
         }
       }
       total += sum, voxels += __shfl(vincl, 63, 64);
@@ -448,11 +479,13 @@ static int march_vcap() {  // occupied voxels per ray a list holds (tests shrink
 }
 static size_t walk_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int march_rpw(int64_t n_rays) {  // rays per wave of the emission kernel: about 2,048 waves (two per SIMD), 16 rays at most
-  const char* e = getenv("UMHS_MARCH_RPW");  // (4,096 rays, replay alone: 16 / 8 / 4 / 2 / 1 rays per wave = 127 / 131 / 145 / 90 / 88 us)
+static int march_rpw(int64_t n_rays) {  // rays per wave of the emission kernel: about 8,192 waves (eight per SIMD), 16 rays at most
+  // (with the scratch rows: 4,096 rays 16 / 4 / 2 / 1 rays per wave = 196 / 147 / 71 / 58 us; 32,768 consecutive pixels of an eval
+  //  image 280 / 185 / 195 / 232 us -- lanes wait for the ray with the longest run at their position)
+  const char* e = getenv("UMHS_MARCH_RPW");
   if (e && atoi(e) >= 1 && atoi(e) <= 64) return atoi(e);
   int rpw = 1;
-  while (rpw < 16 && n_rays > 2048 * (int64_t)rpw) rpw *= 2;
+  while (rpw < 16 && n_rays > 8192 * (int64_t)rpw) rpw *= 2;
   return rpw;
 }
 template <bool WRITE>
