@@ -64,7 +64,7 @@ def run(lib, reps=1, walk=False):
         off_n = base + 2 * al(R * vcap * 4) + al(R * vcap)
         n_ent = WS[off_n:off_n + 4 * R].view(torch.int32).cpu().numpy()
         n_vox = WS[off_n + al(4 * R):off_n + al(4 * R) + 4 * R].view(torch.int32).cpu().numpy()
-        print("lists: occupied voxels per ray mean %.1f p90 %.0f max %d; voxels walked per ray mean %.1f max %d" % (n_ent.mean(), np.percentile(n_ent, 90), n_ent.max(), n_vox.mean(), n_vox.max()))
+        print("lists: entries (runs of occupied voxels) per ray mean %.1f p90 %.0f max %d; voxels walked per ray mean %.1f max %d" % (n_ent.mean(), np.percentile(n_ent, 90), n_ent.max(), n_vox.mean(), n_vox.max()))
     else:
         WS = None
     return run1(lib, reps)
