@@ -90,6 +90,20 @@ def test_argument_errors_are_reported_before_anything_is_launched():
     assert lib.umhs_adam_step(dummy, dummy, dummy, dummy, 16, 1e-2, 0.9, 0.999, 1e-15, 0, 1.0, 0, 0, None) == ARG  # step < 1
     assert lib.umhs_hashgrid_bwd_workspace_bytes(1000, 16, 22) == 0  # 2^22 table: only the atomic path (more than 128 buckets)
     assert lib.umhs_hashgrid_bwd_workspace_bytes(1000, 16, 20) > 0
+    # round 4: the gather that also takes the backward's histogram, and the walk of the marcher on its own
+    WS = -3
+    assert lib.umhs_hashgrid_fwd_count(None, None, None, 16, 16, 19, None, 2, 0, None, 0, None) == ARG
+    assert lib.umhs_hashgrid_fwd_count(dummy, dummy, dummy, 0, 16, 19, None, 2, 0, None, 0, None) == 0  # nothing to do
+    assert lib.umhs_hashgrid_fwd_count(dummy, dummy, dummy, 16, 16, 19, dummy, 2, 0, None, 0, None) == WS  # no workspace
+    assert lib.umhs_hashgrid_fwd_count(dummy, dummy, dummy, 16, 16, 22, dummy, 2, 0, dummy, 1 << 30, None) == UNSUP  # no partitioned path
+    assert lib.umhs_hashgrid_bwd_prepare_counted(dummy, dummy, 16, 16, 19, dummy, 64, None) == WS  # workspace too small
+    roi = (ctypes.c_float * 6)(-1, -1, -1, 1, 1, 1)
+    assert lib.umhs_march_walk_workspace_bytes(0) == 0 and lib.umhs_march_walk_workspace_bytes(4096) >= 4096 * 512 * 9
+    assert lib.umhs_march_walk(None, None, 8, None, roi, 4, 128, 0.05, 1e3, None, None, None, 0.0, None, 0, None) == ARG
+    assert lib.umhs_march_walk(dummy, dummy, 0, dummy, roi, 4, 128, 0.05, 1e3, None, None, None, 0.0, None, 0, None) == 0
+    assert lib.umhs_march_walk(dummy, dummy, 8, dummy, roi, 4, 128, 0.05, 1e3, None, None, None, 0.0, dummy, 16, None) == WS
+    assert lib.umhs_march_walk(dummy, dummy, 8, dummy, roi, 9, 128, 0.05, 1e3, None, None, None, 0.0, dummy, 1 << 20, None) == UNSUP  # levels > 8
+    assert lib.umhs_march_count(dummy, dummy, 8, dummy, roi, 4, 128, 0.05, 1e3, 0.01, 0.0, None, None, None, 0.0, dummy, dummy, 16, None) == WS  # lists too small
 
 
 def test_null_pointers_of_the_field_and_hashgrid_entries_are_argument_errors():
