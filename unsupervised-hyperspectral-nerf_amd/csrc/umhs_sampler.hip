@@ -2,8 +2,11 @@
 // Replaces nerfacc==0.5.2 OccGridEstimator.sampling (CUDA-only traverse_grids + render_visibility_from_density) reached
 // through nerfstudio's VolumetricSampler at umhs_model.py:201-209,229-237.  nerfacc's source is not available offline: the
 // traversal below restates its published behaviour (see oracle/torch_ref.py march_ray_ref, which this kernel reproduces
-// bit for bit: float32, fixed operation order, fp contraction off).  One thread per ray; two passes (count, then write at
-// the offsets of an exclusive scan) because the number of samples per ray is data dependent.
+// bit for bit: float32, fixed operation order, fp contraction off).  Two kernels: the voxel walk (march_walk_kernel: one WAVE per
+// ray, the lanes start inside the ray and fall onto the sequential walk at their first voxel face -- exact, see there) leaves the runs
+// of occupied voxels in a per-ray list; the emission (march_kernel: one thread per ray, the form the oracle is written in -- it walks
+// the grid itself when it is given no lists) turns them into samples, counted and parked in per-ray scratch rows in one pass, or
+// counted and then written at the offsets of an exclusive scan in two (the number of samples per ray is data dependent).
 #include "umhs_common.h"
 
 struct MarchArgs {

@@ -3,7 +3,7 @@
 Mirror of what the reference gets from nerfacc==0.5.2 ``OccGridEstimator`` + nerfstudio's ``VolumetricSampler``
 (``umhs_model.py:201-209`` construction, ``:229-237`` sampling, ``:549-554`` grid update): same constructor arguments,
 buffers (``aabbs``, ``occs``, ``binaries``) and method names.  nerfacc ships CUDA kernels only; the ray marching and the
-visibility pruning run in libumhs_hip.so (``umhs_march_count/write``, ``umhs_visibility``), the density queries in the
+visibility pruning run in libumhs_hip.so (``umhs_march_walk`` + ``umhs_march_scratch/count/write``, ``umhs_visibility``), the density queries in the
 density-only field kernel.  The grid bookkeeping of ``update_every_n_steps`` is index arithmetic in torch (runs every 16
 steps).  nerfacc's source is not available offline: behaviour is restated from its published algorithm (parity unpinned).
 """
