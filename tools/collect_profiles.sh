@@ -14,4 +14,7 @@ for c in C2 C3 C5; do
   done
   [ $found = 1 ] && python tools/pmc_summarize.py gpurun_out profiles/$rd/pmc_summary_$c.json $c
 done
+f=$(ls -t $(find gpurun_out/prof_eval -name "*kernel_stats.csv") 2>/dev/null | head -1)
+[ -n "$f" ] && cp "$f" profiles/$rd/eval_kernel_stats.csv
+[ -s gpurun_out/march_walk_timing.txt ] && cp gpurun_out/march_walk_timing.txt profiles/$rd/
 ls -la profiles/$rd

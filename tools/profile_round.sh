@@ -21,3 +21,7 @@ for c in C2 C3 C5; do
   (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python $R/bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-sampler-step --no-other-configs --no-eval-image > $R/gpurun_out/prof_$c.log 2>&1) || exit 1
   echo "kernel-trace $c done"
 done
+# the eval-image path (tools/bench_eval.py: 300 training steps, then get_outputs_for_camera_ray_bundle on a 256 x 256 camera)
+(cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_eval -- python $R/tools/bench_eval.py > $R/gpurun_out/prof_eval.log 2>&1) || exit 1
+echo "kernel-trace eval done: $(grep 'eval image' gpurun_out/prof_eval.log)"
+
