@@ -278,6 +278,47 @@ def test_march_prefetched_one_step_ahead_is_the_same_training_run(monkeypatch):
     assert torch.equal(res["1"][1], res["0"][1])
 
 
+@pytest.mark.parametrize("knob", ["UMHS_MARCH_SERIAL=1", "UMHS_FUSED_COUNT=0", "UMHS_REUSE_ENC=0"])
+def test_round4_shortcuts_do_not_change_the_training_run(monkeypatch, knob):
+    """The walk split over the lanes of a wave (vs one thread per ray) and the backward's bucket histogram taken inside the forward
+    gather's launch (vs its own kernel; exercised with UMHS_REUSE_ENC=0, where the step hashes the survivors itself) are exact
+    rearrangements: 40 sampler-driven steps -- grid updates, random backgrounds, Adam -- end in the same losses and the same
+    parameters, bit for bit, with and without each."""
+    import sys, os
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_hip_data import _split
+    from umhsnerf.data.umhs_datamanager import UMHSDataManager, UMHSDataManagerConfig
+    from umhsnerf.umhs_model import UMHSConfig
+    from umhsnerf.umhs_pipeline import UMHSPipeline
+
+    name, value = knob.split("=")
+    fixed = {"UMHS_REUSE_ENC": "0"} if name == "UMHS_FUSED_COUNT" else {}
+    res = []
+    for on in (False, True):
+        for k, v in fixed.items():
+            monkeypatch.setenv(k, v)
+        if on:
+            monkeypatch.setenv(name, value)
+        else:
+            monkeypatch.delenv(name, raising=False)
+        torch.manual_seed(11)
+        B = 8
+        split, _, _, _ = _split(n=4, B=B, const=0.5)
+        dm = UMHSDataManager(UMHSDataManagerConfig(train_num_rays_per_batch=1024), device=DEV, seed=4, train=split)
+        cfg = UMHSConfig(method="rgb+spectral", pred_specular=True, temperature=0.4, background_color="random")
+        pipe = UMHSPipeline.from_packed_samples(cfg, DEV, metadata={"wavelengths": list(np.linspace(420, 680, B)), "num_classes": 3}, seed=5, datamanager=dm)
+        losses = []
+        for step in range(40):
+            _, loss, _ = pipe.get_train_loss_dict(step)
+            losses.append(tuple(float(v) for v in loss.values()))
+        torch.cuda.synchronize()
+        res.append((losses, pipe.model.field.flat.detach().clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][0][-1] != res[0][0][0]  # (the run trains: the comparison is not between two constant sequences)
+
+
 def test_fused_sampler_steps_match_the_torch_ops_they_replace():
     """ray_prefix / in-walk jitter / sample_midpoints / visibility_count + compact_samples vs cumsum, nears + rand * step, the
     sigma_fn expression, nonzero + index_select + gathers + pack_info: every one bit for bit."""
